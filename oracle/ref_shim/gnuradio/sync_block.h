@@ -1,0 +1,54 @@
+// ORACLE-ONLY API SHIM (test infrastructure): the GNU Radio 3.7 runtime symbols that
+// /root/reference/lib/baz_music_doa.{h,cc} touch, so that the
+// reference's own source compiles here without GNU Radio/Boost.  Not part of the product
+// (the product's own host-block shim lives in gr_baz_amd/host/).
+#ifndef BAZ_ORACLE_GR_SYNC_BLOCK_SHIM
+#define BAZ_ORACLE_GR_SYNC_BLOCK_SHIM
+
+#include <cassert>
+#include <complex>
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace boost { template <class T> using shared_ptr = std::shared_ptr<T>; }
+
+typedef std::complex<float> gr_complex;
+typedef std::complex<double> gr_complexd;
+typedef std::vector<const void*> gr_vector_const_void_star;
+typedef std::vector<void*> gr_vector_void_star;
+
+namespace gr {
+
+class io_signature {
+public:
+    typedef boost::shared_ptr<io_signature> sptr;
+    int min_streams, max_streams;
+    std::vector<int> sizeof_stream_items;
+    static sptr make(int mn, int mx, int s0)
+    { sptr p(new io_signature); p->min_streams = mn; p->max_streams = mx; p->sizeof_stream_items = {s0}; return p; }
+    static sptr make3(int mn, int mx, int s0, int s1, int s2)
+    { sptr p(new io_signature); p->min_streams = mn; p->max_streams = mx; p->sizeof_stream_items = {s0, s1, s2}; return p; }
+};
+
+class sync_block {
+public:
+    sync_block(const std::string& name, io_signature::sptr in, io_signature::sptr out)
+        : d_name(name), d_in(in), d_out(out), d_id(next_id()++) {}
+    virtual ~sync_block() {}
+    std::string name() const { return d_name; }
+    long unique_id() const { return d_id; }
+    io_signature::sptr input_signature() const { return d_in; }
+    io_signature::sptr output_signature() const { return d_out; }
+    virtual int work(int noutput_items, gr_vector_const_void_star& input_items,
+                     gr_vector_void_star& output_items) = 0;
+private:
+    static long& next_id() { static long id = 0; return id; }
+    std::string d_name;
+    io_signature::sptr d_in, d_out;
+    long d_id;
+};
+
+}  // namespace gr
+#endif
