@@ -1,0 +1,93 @@
+"""Builds the in-tree native artefacts of gr_baz_amd (gfx950 only, no JIT cache):
+
+  csrc/libbaz_music_hip.so   HIP kernels + the C-ABI of include/baz_music_hip.h   (hipcc)
+  host/libgnuradio_baz_music.so   the gr::sync_block host block on the GNU Radio API shim (g++)
+  host/_baz_music*.so        pybind11 module exposing baz.music_doa (SWIG stand-in)
+
+`python -m gr_baz_amd.build` rebuilds everything; build_all() is what __graft_entry__.build() calls.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+INCLUDE = os.path.join(ROOT, "include")
+
+HIP_LIB = os.path.join(CSRC, "libbaz_music_hip.so")
+HOST_LIB = os.path.join(HOST, "libgnuradio_baz_music.so")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm toolchain required to build the gfx950 kernels)")
+
+
+def build_hip(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, "baz_music_hip.hip"), os.path.join(CSRC, "music_kernels.hip.h"),
+            os.path.join(INCLUDE, "baz_music_hip.h")]
+    if force or _newer(HIP_LIB, srcs):
+        cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", HIP_LIB, srcs[0]]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
+    return HIP_LIB
+
+
+def pybind_module_path():
+    ext = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+    return os.path.join(HOST, "_baz_music" + ext)
+
+
+def build_host(force=False, verbose=False):
+    """C++ host block (gr::sync_block surface) + pybind11 module; both link libbaz_music_hip.so."""
+    block_srcs = [os.path.join(HOST, "baz_music_doa.cc"), os.path.join(HOST, "baz_music_doa.h"),
+                  os.path.join(INCLUDE, "baz_music_hip.h")]
+    if not os.path.exists(block_srcs[0]):
+        return None
+    shim_inc = os.path.join(HOST, "gr_shim")
+    common = ["-O2", "-std=c++14", "-fPIC", "-I", INCLUDE, "-I", HOST, "-I", shim_inc]
+    link = ["-L", CSRC, "-lbaz_music_hip", "-Wl,-rpath,$ORIGIN/../csrc"]
+    if force or _newer(HOST_LIB, block_srcs + [HIP_LIB]):
+        cmd = ["g++"] + common + ["-shared", "-o", HOST_LIB, block_srcs[0]] + link
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=HOST)
+    mod = pybind_module_path()
+    mod_src = os.path.join(HOST, "baz_pybind.cc")
+    if os.path.exists(mod_src) and (force or _newer(mod, [mod_src, HOST_LIB])):
+        import pybind11
+        cmd = ["g++"] + common + ["-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"],
+                                   "-shared", "-fvisibility=hidden", "-o", mod, mod_src,
+                                   "-L", HOST, "-lgnuradio_baz_music", "-Wl,-rpath,$ORIGIN"] + link
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=HOST)
+    return HOST_LIB
+
+
+def build_all(force=False, verbose=False):
+    build_hip(force, verbose)
+    build_host(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)
+    print("built:", HIP_LIB)

@@ -1,0 +1,206 @@
+"""ctypes binding of the C-ABI declared in include/baz_music_hip.h.
+
+This is the same binding a maintainer of the reference would write on the python side if the
+SWIG module were bypassed; the GNU Radio host block binds the same symbols
+from C++.  There is no fallback: a missing library raises ImportError at first use, a missing
+gfx950 device raises MusicError from Context().
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbaz_music_hip.so")
+
+OK = 0
+E_INVALID, E_NOMEM, E_HIP, E_UNSUPPORTED, E_NODEVICE = -1, -2, -3, -4, -5
+STAGE_COV, STAGE_EVD, STAGE_SCAN, NUM_STAGES = 0, 1, 2, 3
+MAX_M, MAX_N = 8, 16
+
+# every symbol include/baz_music_hip.h declares (tests/test_abi.py checks the .so exports them all)
+SYMBOLS = [
+    "baz_music_create", "baz_music_destroy", "baz_music_set_table", "baz_music_process",
+    "baz_music_process_device", "baz_music_set_stream", "baz_music_sync", "baz_music_reserve",
+    "baz_music_profile", "baz_music_stage_ms", "baz_music_stage_name", "baz_music_debug_cov",
+    "baz_music_debug_evd", "baz_music_q_stride", "baz_music_bytes_per_item", "baz_music_strerror",
+    "baz_music_last_hip_error", "baz_music_version",
+]
+
+_vp = ctypes.c_void_p
+_u32 = ctypes.c_uint32
+_f32p = ctypes.POINTER(ctypes.c_float)
+
+_lib = None
+
+
+class MusicError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        msg = "%s failed: %s (%d)" % (where, lib().baz_music_strerror(code).decode(), code)
+        if detail:
+            msg += " [" + detail + "]"
+        super().__init__(msg)
+
+
+def lib():
+    """Loads libbaz_music_hip.so (built in-tree by gr_baz_amd.build); never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("gr_baz_amd: %s is missing - run `python -m gr_baz_amd.build` "
+                          "(there is no CPU fallback for the MUSIC-DoA path)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    L.baz_music_create.restype = ctypes.c_int
+    L.baz_music_create.argtypes = [ctypes.POINTER(_vp), _u32, _u32, _u32, _u32, _f32p, ctypes.c_int]
+    L.baz_music_destroy.restype = None
+    L.baz_music_destroy.argtypes = [_vp]
+    L.baz_music_set_table.restype = ctypes.c_int
+    L.baz_music_set_table.argtypes = [_vp, _f32p]
+    L.baz_music_process.restype = ctypes.c_int
+    L.baz_music_process.argtypes = [_vp, _f32p, _u32, _f32p, _f32p, _f32p]
+    L.baz_music_process_device.restype = ctypes.c_int
+    L.baz_music_process_device.argtypes = [_vp, _vp, _u32, _vp, _vp, _vp]
+    L.baz_music_set_stream.restype = ctypes.c_int
+    L.baz_music_set_stream.argtypes = [_vp, _vp]
+    L.baz_music_sync.restype = ctypes.c_int
+    L.baz_music_sync.argtypes = [_vp]
+    L.baz_music_reserve.restype = ctypes.c_int
+    L.baz_music_reserve.argtypes = [_vp, _u32]
+    L.baz_music_profile.restype = ctypes.c_int
+    L.baz_music_profile.argtypes = [_vp, ctypes.c_int]
+    L.baz_music_stage_ms.restype = ctypes.c_int
+    L.baz_music_stage_ms.argtypes = [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                     ctypes.POINTER(ctypes.c_uint64)]
+    L.baz_music_stage_name.restype = ctypes.c_char_p
+    L.baz_music_stage_name.argtypes = [_vp, ctypes.c_int]
+    L.baz_music_debug_cov.restype = ctypes.c_int
+    L.baz_music_debug_cov.argtypes = [_vp, _vp, _u32, _vp]
+    L.baz_music_debug_evd.restype = ctypes.c_int
+    L.baz_music_debug_evd.argtypes = [_vp, _vp, _u32, _vp]
+    L.baz_music_q_stride.restype = _u32
+    L.baz_music_q_stride.argtypes = [_u32]
+    L.baz_music_bytes_per_item.restype = ctypes.c_uint64
+    L.baz_music_bytes_per_item.argtypes = [_vp, ctypes.c_int]
+    L.baz_music_strerror.restype = ctypes.c_char_p
+    L.baz_music_strerror.argtypes = [ctypes.c_int]
+    L.baz_music_last_hip_error.restype = ctypes.c_char_p
+    L.baz_music_last_hip_error.argtypes = [_vp]
+    L.baz_music_version.restype = ctypes.c_char_p
+    L.baz_music_version.argtypes = []
+    _lib = L
+    return L
+
+
+def _table_f32(table, res, m):
+    t = np.ascontiguousarray(np.asarray(table, dtype=np.complex64))
+    if t.shape != (res, m):
+        raise ValueError("array_response must be resolution x m = %dx%d, got %s" % (res, m, t.shape))
+    return t
+
+
+class Context:
+    """One baz_music_ctx: the device-side state of one baz_music_doa block instance."""
+
+    def __init__(self, m, n, nsamples, resolution, table, device_id=-1):
+        L = lib()
+        self.m, self.n, self.nsamples, self.res = int(m), int(n), int(nsamples), int(resolution)
+        t = _table_f32(table, self.res, self.m) if (self.res > 0 and self.m > 0) else \
+            np.zeros((1, 1), np.complex64)
+        h = _vp()
+        r = L.baz_music_create(ctypes.byref(h), self.m, self.n, self.nsamples, self.res,
+                               t.view(np.float32).ctypes.data_as(_f32p), int(device_id))
+        if r != OK:
+            raise MusicError(r, "baz_music_create")
+        self._h = h
+
+    def _chk(self, r, where):
+        if r < 0:
+            raise MusicError(r, where, lib().baz_music_last_hip_error(self._h).decode())
+        return r
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().baz_music_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_table(self, table):
+        t = _table_f32(table, self.res, self.m)
+        self._chk(lib().baz_music_set_table(self._h, t.view(np.float32).ctypes.data_as(_f32p)),
+                  "baz_music_set_table")
+
+    def process(self, items, want_lvl=True, want_spectrum=True):
+        """items: (batch, nsamples) complex64 host array -> (ang, lvl|None, spectrum|None)."""
+        x = np.ascontiguousarray(np.asarray(items, dtype=np.complex64))
+        if x.ndim == 1:
+            x = x[None, :]
+        if x.shape[1] != self.nsamples:
+            raise ValueError("items must be (batch, %d) complex64" % self.nsamples)
+        B = x.shape[0]
+        ang = np.zeros((B, self.n), np.float32)
+        lvl = np.zeros((B, self.n), np.float32) if want_lvl else None
+        spec = np.zeros((B, self.res), np.float32) if want_spectrum else None
+        r = lib().baz_music_process(
+            self._h, x.view(np.float32).ctypes.data_as(_f32p), B, ang.ctypes.data_as(_f32p),
+            lvl.ctypes.data_as(_f32p) if want_lvl else None,
+            spec.ctypes.data_as(_f32p) if want_spectrum else None)
+        self._chk(r, "baz_music_process")
+        return ang, lvl, spec
+
+    # ---- device-resident path (pointers are plain integers, e.g. torch.Tensor.data_ptr()) ----
+    def process_device(self, d_in, batch, d_ang, d_lvl=None, d_spec=None):
+        self._chk(lib().baz_music_process_device(self._h, _vp(d_in), int(batch), _vp(d_ang),
+                                                 _vp(d_lvl) if d_lvl else None,
+                                                 _vp(d_spec) if d_spec else None),
+                  "baz_music_process_device")
+
+    def set_stream(self, hip_stream):
+        self._chk(lib().baz_music_set_stream(self._h, _vp(hip_stream) if hip_stream else None),
+                  "baz_music_set_stream")
+
+    def sync(self):
+        self._chk(lib().baz_music_sync(self._h), "baz_music_sync")
+
+    def reserve(self, max_batch):
+        self._chk(lib().baz_music_reserve(self._h, int(max_batch)), "baz_music_reserve")
+
+    def profile(self, enable):
+        self._chk(lib().baz_music_profile(self._h, 1 if enable else 0), "baz_music_profile")
+
+    def stage_ms(self, stage):
+        ms = ctypes.c_double(0.0)
+        cnt = ctypes.c_uint64(0)
+        self._chk(lib().baz_music_stage_ms(self._h, stage, ctypes.byref(ms), ctypes.byref(cnt)),
+                  "baz_music_stage_ms")
+        return ms.value, cnt.value
+
+    def stage_name(self, stage):
+        return lib().baz_music_stage_name(self._h, stage).decode()
+
+    def debug_cov(self, d_in, batch, d_R):
+        self._chk(lib().baz_music_debug_cov(self._h, _vp(d_in), int(batch), _vp(d_R)), "baz_music_debug_cov")
+
+    def debug_evd(self, d_R, batch, d_Q):
+        self._chk(lib().baz_music_debug_evd(self._h, _vp(d_R), int(batch), _vp(d_Q)), "baz_music_debug_evd")
+
+    def bytes_per_item(self, with_spectrum=True):
+        return int(lib().baz_music_bytes_per_item(self._h, 1 if with_spectrum else 0))
+
+
+def q_stride(batch):
+    return int(lib().baz_music_q_stride(int(batch)))
+
+
+def version():
+    return lib().baz_music_version().decode()

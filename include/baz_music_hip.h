@@ -1,0 +1,126 @@
+/* baz_music_hip.h -- C-ABI of the MI355X (gfx950) MUSIC direction-of-arrival engine.
+ *
+ * This is the drop-in boundary for ONE path of balint256/gr-baz: the body of
+ *     baz_music_doa::work()            /root/reference/lib/baz_music_doa.cc:72-161
+ * plus the state that work() reads:
+ *     baz_music_doa::baz_music_doa()   /root/reference/lib/baz_music_doa.cc:35-53   (m, n, nsamples, resolution, table)
+ *     set_array_response()             /root/reference/lib/baz_music_doa.cc:60-70   (table replacement)
+ * The GNU Radio host block (gr_baz_amd/host/baz_music_doa.{h,cc}) keeps the reference's
+ * make()/work()/set_array_response() signatures (lib/baz_music_doa.h:36,48,59) and does
+ * nothing but marshal gr_complex / float buffers across this ABI.
+ *
+ * Conventions: plain C types, no exceptions, no torch/GNU Radio types.  The caller owns
+ * every host buffer; the library owns all device memory it allocates.  0 == success,
+ * negative == error (baz_music_strerror).  A context is single-producer: one thread calls
+ * process*(); baz_music_set_table() may be called from any other thread (it is serialised
+ * against process*() like the reference's d_mutex, lib/baz_music_doa.cc:67,101).
+ *
+ * Data layouts (identical to what the reference block sees on its ports):
+ *   in        : batch items, each nsamples gr_complex (float re, float im), antenna-
+ *               interleaved  x(r,c) = in[c*m + r]              (lib/baz_music_doa.cc:82-84)
+ *   table     : resolution x m gr_complex, row-major [bin][antenna]  (array_response_t,
+ *               lib/baz_music_doa.h:32-33, as delivered by swig/baz_swig.i:564)
+ *   ang, lvl  : batch x n float   (output ports 0 and 1, lib/baz_music_doa.cc:146-155)
+ *   spectrum  : batch x resolution float (optional port 2, lib/baz_music_doa.cc:120-121)
+ */
+#ifndef INCLUDED_BAZ_MUSIC_HIP_H
+#define INCLUDED_BAZ_MUSIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define BAZ_MUSIC_API __attribute__((visibility("default")))
+#else
+#define BAZ_MUSIC_API
+#endif
+
+typedef struct baz_music_ctx baz_music_ctx;
+
+enum {
+    BAZ_MUSIC_OK = 0,
+    BAZ_MUSIC_E_INVALID = -1,     /* bad argument (the reference only assert()s, .cc:45-50,62-63) */
+    BAZ_MUSIC_E_NOMEM = -2,       /* host or device allocation failed */
+    BAZ_MUSIC_E_HIP = -3,         /* HIP runtime error (baz_music_last_hip_error) */
+    BAZ_MUSIC_E_UNSUPPORTED = -4, /* valid for the reference but not built here (m > BAZ_MUSIC_MAX_M ...) */
+    BAZ_MUSIC_E_NODEVICE = -5     /* no gfx950 device / device_id out of range */
+};
+
+#define BAZ_MUSIC_MAX_M 8u        /* antennas handled by the register-resident kernels */
+#define BAZ_MUSIC_MAX_N 16u       /* top-n list length handled on device (n < m anyway) */
+
+/* Stage indices for baz_music_stage_ms / baz_music_stage_name. */
+enum { BAZ_MUSIC_STAGE_COV = 0, BAZ_MUSIC_STAGE_EVD = 1, BAZ_MUSIC_STAGE_SCAN = 2, BAZ_MUSIC_NUM_STAGES = 3 };
+
+/* Replaces baz_music_doa::baz_music_doa (lib/baz_music_doa.cc:35-53).  Validates what the
+ * reference only assert()s: m>0, 0<n<m (n==m underflows .cc:93), nsamples>0, nsamples%m==0,
+ * resolution>0.  table_ri = resolution*m complex64 as interleaved floats.  device_id < 0
+ * selects the current HIP device. */
+BAZ_MUSIC_API int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamples,
+                                   uint32_t resolution, const float* table_ri, int device_id);
+
+/* Replaces baz_music_doa::~baz_music_doa (lib/baz_music_doa.cc:55-58). */
+BAZ_MUSIC_API void baz_music_destroy(baz_music_ctx* ctx);
+
+/* Replaces baz_music_doa::set_array_response (lib/baz_music_doa.cc:60-70): takes effect for
+ * every item submitted after it returns. Thread-safe against process*(). */
+BAZ_MUSIC_API int baz_music_set_table(baz_music_ctx* ctx, const float* table_ri);
+
+/* Replaces the body of baz_music_doa::work (lib/baz_music_doa.cc:72-161) for `batch`
+ * consecutive items held in HOST memory; blocks until ang/lvl/spectrum are filled.
+ * lvl and spectrum may be NULL (ports 1 / 2 not wired; guards the reference's NULL-lvl
+ * dereference, .cc:147-154). Returns the number of items processed (== batch) or <0. */
+BAZ_MUSIC_API int baz_music_process(baz_music_ctx* ctx, const float* in_ri, uint32_t batch,
+                                    float* ang, float* lvl, float* spectrum);
+
+/* Same arithmetic on DEVICE-resident buffers (HBM), asynchronous on the context's stream:
+ * d_in batch*nsamples complex64; d_ang, d_lvl batch*n float; d_spectrum batch*resolution
+ * float or NULL. d_lvl may be NULL. Returns 0 or <0. */
+BAZ_MUSIC_API int baz_music_process_device(baz_music_ctx* ctx, const void* d_in, uint32_t batch,
+                                           void* d_ang, void* d_lvl, void* d_spectrum);
+
+/* Use an externally owned hipStream_t (e.g. the host framework's current stream) for all
+ * subsequent launches; NULL restores the context's own stream. */
+BAZ_MUSIC_API int baz_music_set_stream(baz_music_ctx* ctx, void* hip_stream);
+
+/* Blocks until everything submitted on the context's stream has finished. */
+BAZ_MUSIC_API int baz_music_sync(baz_music_ctx* ctx);
+
+/* Pre-allocates device workspace (covariances, projector coefficients) for `max_batch`
+ * items so that process_device() never allocates inside a timed / captured region. */
+BAZ_MUSIC_API int baz_music_reserve(baz_music_ctx* ctx, uint32_t max_batch);
+
+/* Per-stage device timing with hipEvents recorded on the launch stream around each
+ * kernel of process_device().  enable: 1 = start recording (and reset), 0 = stop. */
+BAZ_MUSIC_API int baz_music_profile(baz_music_ctx* ctx, int enable);
+/* Synchronises, then returns total milliseconds and number of launches recorded for `stage`. */
+BAZ_MUSIC_API int baz_music_stage_ms(baz_music_ctx* ctx, int stage, double* total_ms, uint64_t* launches);
+/* Kernel (symbol) name launched for `stage` with the context's configuration. */
+BAZ_MUSIC_API const char* baz_music_stage_name(baz_music_ctx* ctx, int stage);
+
+/* Test / diagnostic taps (device pointers): run a single stage.
+ *   cov : d_in -> d_R      batch * m*m complex128 (row-major R[i][j], (re,im) doubles)   .cc:82-85
+ *   evd : d_R  -> d_Q      m*m doubles per item, item-minor: d_Q[e*q_stride + item]; the
+ *                          real coefficients of the noise-subspace projector G G^H         .cc:88-93
+ * q_stride is returned by baz_music_q_stride() for the given batch. */
+BAZ_MUSIC_API int baz_music_debug_cov(baz_music_ctx* ctx, const void* d_in, uint32_t batch, void* d_R);
+BAZ_MUSIC_API int baz_music_debug_evd(baz_music_ctx* ctx, const void* d_R, uint32_t batch, void* d_Q);
+BAZ_MUSIC_API uint32_t baz_music_q_stride(uint32_t batch);
+
+/* Algorithmic HBM bytes per item: 8*nsamples + 8*n + 4*resolution (the last
+ * term only when the spectrum port is wired). */
+BAZ_MUSIC_API uint64_t baz_music_bytes_per_item(const baz_music_ctx* ctx, int with_spectrum);
+
+BAZ_MUSIC_API const char* baz_music_strerror(int code);
+/* hipGetErrorString of the last failing HIP call in this context ("" if none). */
+BAZ_MUSIC_API const char* baz_music_last_hip_error(const baz_music_ctx* ctx);
+BAZ_MUSIC_API const char* baz_music_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INCLUDED_BAZ_MUSIC_HIP_H */
