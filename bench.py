@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""MUSIC-DoA benchmark (driver contract: python bench.py --gpus N --steps K --warmup W).
+
+metric   : BASELINE.json's "MUSIC-DoA snapshots/s (4 ant, 1024 samp, 3600 bins)".
+workload : BASELINE.json configs[1] = SURVEY.md 8d cfg2: m=4, n=2, nsamples=1024 (K=256 columns),
+           resolution=3600, spectrum port wired; per GPU 8 independent synthetic streams of 8,192
+           items (65,536 items = one "step" = one pass of the hot path: covariance -> EVD -> scan),
+           device-resident in HBM before the timed region.
+N GPUs   : one process per GPU (torch.distributed.run), streams dealt s mod N, NO data-path
+           collective; torch.distributed (RCCL) only provides the barrier and the max-over-ranks
+           clock.  scaling = weak (per-GPU work fixed).
+roofline : dominant kernel = the scan (scan_mfma_kernel); achieved = its algorithmic bytes per launch
+           (4*resolution + 8*n per item) / its average launch duration, measured with
+           hipEvents recorded on the launch stream inside the timed region (baz_music_profile).
+cpu_baseline : rank 0, N=1 only: the plain-C restatement of the reference's work() (oracle/music_ref.c,
+           kind "port"), one work() per item like the GNU Radio scheduler drives the reference, on
+           all host cores (one independent block instance per thread) for a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+M, N_EMIT, NSAMPLES, RES = 4, 2, 1024, 3600
+FREQUENCY, SPACING = 299792458.0, 0.5
+STREAMS_PER_GPU, ITEMS_PER_STREAM = 8, 8192
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(table, seconds_per_thread=2.0):
+    """Oracle leg (the ONLY use of oracle/ in this file): times the C restatement on host cores."""
+    import numpy as np
+    from oracle import music_oracle as mo
+    from oracle import music_ref as mr
+    sample = 512
+    items = mo.synth_items(sample, M, NSAMPLES, mo.array_geometry(M), FREQUENCY, SPACING, seed=1002)
+    mr.work_batch(items[:16], table, M, N_EMIT)            # warm-up / page-in
+    t0 = time.perf_counter()
+    mr.work_batch(items, table, M, N_EMIT)
+    one = sample / (time.perf_counter() - t0)
+    cores = os.cpu_count() or 1
+    counts = [0] * cores
+    stop_at = time.perf_counter() + seconds_per_thread
+
+    def worker(i):
+        x = np.ascontiguousarray(items[(i * 37) % sample:] if (i * 37) % sample < sample - 64 else items)
+        while time.perf_counter() < stop_at:
+            mr.work_batch(x[:64], table, M, N_EMIT)        # ctypes releases the GIL
+            counts[i] += 64
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(cores)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": sum(counts) / dt, "unit": "snapshots/s", "cores": cores, "kind": "port",
+            "value_1thread": one,
+            "sample": "%d items in %.1f s on %d threads (+%d items on 1 thread); oracle/music_ref.c, "
+                      "one work() per item, cfg2 inputs" % (sum(counts), dt, cores, sample)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from gr_baz_amd import capi, sharding, synth
+    from gr_baz_amd.baz.music_doa_helper import calculate_antenna_array_response
+
+    rank, local_rank, world = sharding.dist_env()
+    if world != max(1, args.gpus) and world > 1:
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MUSIC-DoA path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    active = sharding.init_process_group(use_gpu=True, local_rank=local_rank)
+
+    # steering table exactly as music_doa_helper builds it, rounded to complex64 like SWIG does
+    arr = synth.array_geometry(M)
+    lam = synth.C_LIGHT / FREQUENCY
+    table = np.array(calculate_antenna_array_response([[SPACING * x, SPACING * y] for x, y in arr], RES, lam)
+                     ).astype(np.complex64)
+
+    # this rank's streams: global stream s lives on rank s mod world (config 4), seed = 1002 + s
+    n_streams = STREAMS_PER_GPU * world
+    mine = sharding.streams_of_rank(n_streams, world, rank)
+    batch = len(mine) * ITEMS_PER_STREAM
+    x = torch.cat([synth.synth_stream(torch, dev, ITEMS_PER_STREAM, M, NSAMPLES, arr, FREQUENCY, SPACING,
+                                      seed=1002 + s) for s in mine], dim=0)
+    ang = torch.zeros(batch, N_EMIT, dtype=torch.float32, device=dev)
+    lvl = torch.zeros_like(ang)
+    spec = torch.zeros(batch, RES, dtype=torch.float32, device=dev)
+
+    ctx = capi.Context(M, N_EMIT, NSAMPLES, RES, table, device_id=local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.reserve(batch)
+
+    def step():
+        ctx.process_device(x.data_ptr(), batch, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    sharding.barrier(active, True)
+    ctx.profile(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    sharding.barrier(active, True)
+    stage = [ctx.stage_ms(s) for s in range(capi.NUM_STAGES)]
+    ctx.profile(False)
+
+    value, tmax, total_items = sharding.whole_job_rate(batch * args.steps, elapsed, active, True)
+
+    if rank == 0:
+        scan_ms, scan_n = stage[capi.STAGE_SCAN]
+        scan_avg_s = scan_ms / max(scan_n, 1) * 1e-3
+        scan_bytes = (4 * RES + 8 * N_EMIT) * batch                 # spectrum + ang + lvl written per launch
+        achieved = scan_bytes / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r01_scan_pmc_traffic.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get("scan_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "MUSIC-DoA snapshots/s (4 ant, 1024 samp, 3600 bins)",
+            "value": value, "unit": "snapshots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": tmax / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cfg2 (BASELINE.json configs[1]): m=4 n=2 nsamples=1024 (K=256) resolution=3600, "
+                                   "spectrum port wired, %d streams x %d items per GPU per step, device-resident"
+                                   % (STREAMS_PER_GPU, ITEMS_PER_STREAM),
+                       "items_per_gpu_per_step": batch, "parallelism": "independent streams, s mod %d, no collective" % world,
+                       "algorithmic_bytes_per_item": ctx.bytes_per_item(True),
+                       "pipeline_hbm_fraction_of_8TBs": value / world * ctx.bytes_per_item(True) / 8e12,
+                       "stage_ms_per_launch": {nm: stage[s][0] / max(stage[s][1], 1)
+                                               for s, nm in enumerate(("cov_mfma", "evd_proj", "scan_mfma"))}},
+            "roofline": {"bound": "hbm", "kernel": "scan_mfma_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_avg_s * 1e3,
+                         "launches": scan_n},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(table)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if active:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

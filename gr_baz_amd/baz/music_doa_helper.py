@@ -1,0 +1,124 @@
+"""MUSIC DOA helper -- python-3 counterpart of /root/reference/python/music_doa_helper.py.
+
+Same public surface: unit_vect(theta), calculate_antenna_array_response(antenna_array,
+angular_resolution, l) (:29-46) and class music_doa_helper(m, n, nsamples, angular_resolution,
+frequency, array_spacing, antenna_array, output_spectrum=False) with set_frequency() (:48-103), used
+by grc/baz_music_doa.xml:6-8.  The steering-table formula, wavelength, array scaling, the
+nsamples % m check and the 2-or-3 output signature are the reference's (python-3 syntax).
+
+With GNU Radio installed the class is a gr.hier_block2 wired exactly like the reference (:61-96).
+Without it (this container) it is a plain object with the same attributes plus work(items), so the
+helper -> baz.music_doa -> host block -> C-ABI -> HIP chain can be exercised end to end.
+"""
+import numpy
+
+try:                                    # real GNU Radio host
+    from gnuradio import gr             # noqa: F401
+    _HAVE_GR = True
+except ImportError:                     # this container / the GPU box
+    gr = None
+    _HAVE_GR = False
+
+C_LIGHT = 299792458.0                   # python/music_doa_helper.py:55
+
+
+def unit_vect(theta):
+    return numpy.array([numpy.cos(theta), numpy.sin(theta)])
+
+
+def calculate_antenna_array_response(antenna_array, angular_resolution, l):
+    """response[step][antenna] = exp(-j 2 pi (p_antenna . u(theta_step)) / l), theta_step =
+    step*360/angular_resolution degrees (python/music_doa_helper.py:32-46).  Returns a list of lists of
+    python complex, which is what baz.music_doa's vector<vector<gr_complex>> typemap takes.
+
+    The phase is formed per element with numpy.inner exactly like the reference (:40): a vectorised
+    multiply-add rounds differently in the last bit (BLAS dot uses FMA), which shows up as 1-ulp
+    differences after the complex64 rounding at the SWIG boundary.  Only the exponential is batched."""
+    antennas = [numpy.asarray(a, dtype=numpy.float64) for a in antenna_array]
+    phase = numpy.empty((angular_resolution, len(antennas)), dtype=numpy.float64)
+    for step in range(0, angular_resolution):
+        angle = (step * 360.0 / angular_resolution) * (numpy.pi / 180.0)
+        u = unit_vect(angle)
+        for t, antenna in enumerate(antennas):
+            phase[step, t] = numpy.inner(antenna, u) / l
+    response = numpy.exp(-1j * 2.0 * numpy.pi * phase)
+    return response.tolist()
+
+
+def _banner(h):
+    print("MUSIC DOA Helper: M: %d, N: %d, # samples: %d, steps of %f degress, lambda: %f, array: %s" % (
+        h.m, h.n, h.nsamples, (360.0 / h.angular_resolution), h.l, str(h.antenna_array)))
+
+
+def _configure(h, m, n, nsamples, angular_resolution, frequency, array_spacing, antenna_array):
+    h.m = m
+    h.n = n
+    h.nsamples = nsamples
+    h.angular_resolution = angular_resolution
+    h.l = C_LIGHT / frequency
+    h.antenna_array = [[array_spacing * x, array_spacing * y] for [x, y] in antenna_array]
+    if (nsamples % m) != 0:
+        raise Exception("nsamples must be multiple of m")
+
+
+def _make_impl(h):
+    from . import music_doa as _music_doa
+    h.array_response = calculate_antenna_array_response(h.antenna_array, h.angular_resolution, h.l)
+    h.impl = _music_doa(h.m, h.n, h.nsamples, h.array_response, h.angular_resolution)
+
+
+def _retune(h, frequency):
+    h.l = C_LIGHT / frequency
+    h.array_response = calculate_antenna_array_response(h.antenna_array, h.angular_resolution, h.l)
+    h.impl.set_array_response(h.array_response)
+
+
+if _HAVE_GR:
+
+    class music_doa_helper(gr.hier_block2):
+        def __init__(self, m, n, nsamples, angular_resolution, frequency, array_spacing, antenna_array,
+                     output_spectrum=False):
+            _configure(self, m, n, nsamples, angular_resolution, frequency, array_spacing, antenna_array)
+            if output_spectrum:
+                output_sig = gr.io_signature3(3, 3, (gr.sizeof_float * n), (gr.sizeof_float * n),
+                                              (gr.sizeof_float * angular_resolution))
+            else:
+                output_sig = gr.io_signature2(2, 2, (gr.sizeof_float * n), (gr.sizeof_float * n))
+            gr.hier_block2.__init__(self, "music_doa_helper",
+                                    gr.io_signature(1, 1, (gr.sizeof_gr_complex * nsamples)), output_sig)
+            _banner(self)
+            _make_impl(self)
+            self.connect(self, self.impl)
+            self.connect((self.impl, 0), (self, 0))
+            self.connect((self.impl, 1), (self, 1))
+            if output_spectrum:
+                self.connect((self.impl, 2), (self, 2))
+
+        def set_frequency(self, frequency):
+            _retune(self, frequency)
+
+else:
+
+    class music_doa_helper(object):
+        """GNU-Radio-less stand-in with the reference's constructor, attributes and set_frequency()."""
+
+        def __init__(self, m, n, nsamples, angular_resolution, frequency, array_spacing, antenna_array,
+                     output_spectrum=False):
+            _configure(self, m, n, nsamples, angular_resolution, frequency, array_spacing, antenna_array)
+            self.output_spectrum = bool(output_spectrum)
+            # (itemsize, ...) of the ports the hier block would declare (:61-71)
+            self.input_item_sizes = [8 * nsamples]
+            self.output_item_sizes = [4 * n, 4 * n] + ([4 * angular_resolution] if output_spectrum else [])
+            _banner(self)
+            _make_impl(self)
+
+        def set_frequency(self, frequency):
+            _retune(self, frequency)
+
+        def work(self, items):
+            """Runs the wrapped block on (k, nsamples) complex64 items: returns (ang, lvl[, spectrum])."""
+            produced, ang, lvl, spec = self.impl.work(numpy.ascontiguousarray(items, dtype=numpy.complex64),
+                                                      3 if self.output_spectrum else 2)
+            if produced != ang.shape[0]:
+                raise RuntimeError("music_doa work() returned %d" % produced)
+            return (ang, lvl, spec) if self.output_spectrum else (ang, lvl)

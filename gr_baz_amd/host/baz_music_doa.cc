@@ -1,0 +1,120 @@
+/* -*- c++ -*- */
+/* Host side of the MI355X MUSIC-DoA block: argument checking, table flattening and buffer
+ * marshalling across the C-ABI (include/baz_music_hip.h).  Mirrors the roles of
+ * /root/reference/lib/baz_music_doa.cc:29-33 (factory), :35-53 (constructor/ports/banner),
+ * :60-70 (setter) and :72-161 (work); all arithmetic of :74-155 runs in the HIP kernels. */
+#ifdef HAVE_CONFIG_H
+#include "config.h"
+#endif
+
+#include <baz_music_doa.h>
+#include <baz_music_hip.h>
+
+#include <gnuradio/io_signature.h>
+
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace {
+
+/* resolution x m nested vectors -> the contiguous [bin][antenna] (re,im) float image of the ABI */
+std::vector<float> flatten_response(const array_response_t& table, unsigned int m, unsigned int resolution)
+{
+    if (table.size() != resolution)
+        throw std::invalid_argument("music_doa: array_response must have `resolution` rows");
+    std::vector<float> flat((size_t)resolution * m * 2);
+    for (unsigned int s = 0; s < resolution; ++s) {
+        if (table[s].size() != m)
+            throw std::invalid_argument("music_doa: every array_response row must have m entries");
+        for (unsigned int t = 0; t < m; ++t) {
+            flat[2 * ((size_t)s * m + t)] = table[s][t].real();
+            flat[2 * ((size_t)s * m + t) + 1] = table[s][t].imag();
+        }
+    }
+    return flat;
+}
+
+void check_config(unsigned int m, unsigned int n, unsigned int nsamples, unsigned int resolution)
+{
+    if (m == 0) throw std::invalid_argument("music_doa: m must be > 0");
+    if (n == 0 || n >= m) throw std::invalid_argument("music_doa: need 0 < n < m");
+    if (nsamples == 0 || (nsamples % m) != 0)
+        throw std::invalid_argument("music_doa: nsamples must be a positive multiple of m");
+    if (resolution == 0) throw std::invalid_argument("music_doa: resolution must be > 0");
+}
+
+}  // namespace
+
+baz_music_doa_sptr baz_make_music_doa(unsigned int m, unsigned int n, unsigned int nsamples,
+                                      const array_response_t& array_response, unsigned int resolution)
+{
+    check_config(m, n, nsamples, resolution);   /* before the io_signature sizes are formed */
+    return baz_music_doa_sptr(new baz_music_doa(m, n, nsamples, array_response, resolution));
+}
+
+baz_music_doa::baz_music_doa(unsigned int m, unsigned int n, unsigned int nsamples,
+                             const array_response_t& array_response, unsigned int resolution)
+    : gr::sync_block("music_doa",
+                     gr::io_signature::make(1, 1, nsamples * sizeof(gr_complex)),
+                     gr::io_signature::make3(1, 3, n * sizeof(float), n * sizeof(float),
+                                             resolution * sizeof(float))),
+      d_m(m), d_n(n), d_nsamples(nsamples), d_resolution(resolution),
+      d_array_response(array_response), d_ctx(NULL)
+{
+    const std::vector<float> flat = flatten_response(array_response, m, resolution);
+    const int rc = baz_music_create(&d_ctx, m, n, nsamples, resolution, flat.data(), -1);
+    if (rc == BAZ_MUSIC_E_INVALID || rc == BAZ_MUSIC_E_UNSUPPORTED)
+        throw std::invalid_argument(std::string("music_doa: ") + baz_music_strerror(rc));
+    if (rc != BAZ_MUSIC_OK)
+        throw std::runtime_error(std::string("music_doa: cannot open the gfx950 engine: ") + baz_music_strerror(rc));
+
+    /* One launch per work() call: ask the scheduler for large calls. */
+    set_max_noutput_items(4096);
+
+    fprintf(stderr, "[%s<%li>] MUSIC DOA: M: %d, N: %d, # samples: %d, angular resolution: %d\n",
+            name().c_str(), unique_id(), m, n, nsamples, resolution);
+}
+
+baz_music_doa::~baz_music_doa()
+{
+    baz_music_destroy(d_ctx);
+}
+
+void baz_music_doa::set_array_response(const array_response_t& array_response)
+{
+    const std::vector<float> flat = flatten_response(array_response, d_m, d_resolution);
+    fprintf(stderr, "[%s<%li>] Updating array response\n", name().c_str(), unique_id());
+
+    gr::thread::scoped_lock guard(d_mutex);
+    const int rc = baz_music_set_table(d_ctx, flat.data());   /* serialised against work() inside */
+    if (rc != BAZ_MUSIC_OK)
+        throw std::runtime_error(std::string("music_doa: set_array_response: ") + baz_music_strerror(rc));
+    d_array_response = array_response;
+}
+
+array_response_t baz_music_doa::array_response()
+{
+    gr::thread::scoped_lock guard(d_mutex);
+    return d_array_response;
+}
+
+int baz_music_doa::work(int noutput_items, gr_vector_const_void_star& input_items,
+                        gr_vector_void_star& output_items)
+{
+    if (noutput_items <= 0) return 0;
+    if (input_items.empty() || output_items.empty()) return -1;
+
+    const float* in = static_cast<const float*>(input_items[0]);   /* gr_complex == (float re, float im) */
+    float* ang = static_cast<float*>(output_items[0]);
+    float* lvl = (output_items.size() > 1) ? static_cast<float*>(output_items[1]) : NULL;
+    float* spectrum = (output_items.size() > 2) ? static_cast<float*>(output_items[2]) : NULL;
+
+    const int rc = baz_music_process(d_ctx, in, (uint32_t)noutput_items, ang, lvl, spectrum);
+    if (rc < 0) {
+        fprintf(stderr, "[%s<%li>] MUSIC DOA: device error: %s (%s)\n", name().c_str(), unique_id(),
+                baz_music_strerror(rc), baz_music_last_hip_error(d_ctx));
+        return -1;   /* WORK_DONE */
+    }
+    return noutput_items;
+}

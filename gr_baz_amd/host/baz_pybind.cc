@@ -1,0 +1,75 @@
+/* pybind11 module `_baz_music`: the in-container stand-in for the reference's SWIG stanza
+ * (swig/baz_swig.i:560-574): `music_doa(m, n, nsamples, array_response, resolution)` returns a
+ * handle on the C++ host block with `.set_array_response(list[list[complex]])`.  `.work(items)` is a
+ * test/demo convenience that drives the block's virtual work() the way the GNU Radio scheduler
+ * does (pointer vectors into numpy buffers). */
+#include <baz_music_doa.h>
+
+#include <pybind11/complex.h>
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+namespace py = pybind11;
+
+namespace {
+
+struct music_doa_handle {
+    baz_music_doa_sptr blk;
+};
+
+py::tuple drive_work(music_doa_handle& h, py::array_t<std::complex<float>, py::array::c_style | py::array::forcecast> items,
+                     int n_outputs)
+{
+    if (n_outputs < 1 || n_outputs > 3) throw std::invalid_argument("n_outputs must be 1, 2 or 3");
+    py::buffer_info bi = items.request();
+    const size_t N = h.blk->nsamples();
+    if (bi.size == 0 || (size_t)bi.size % N != 0) throw std::invalid_argument("items must hold k * nsamples complex64");
+    const int nitems = (int)((size_t)bi.size / N);
+    py::array_t<float> ang({(size_t)nitems, (size_t)h.blk->n()});
+    py::array_t<float> lvl({(size_t)nitems, (size_t)h.blk->n()});
+    py::array_t<float> spec({(size_t)nitems, (size_t)h.blk->resolution()});
+    gr_vector_const_void_star in(1, bi.ptr);
+    gr_vector_void_star out;
+    out.push_back(ang.mutable_data());
+    if (n_outputs > 1) out.push_back(lvl.mutable_data());
+    if (n_outputs > 2) out.push_back(spec.mutable_data());
+    int produced;
+    {
+        py::gil_scoped_release nogil;
+        produced = h.blk->work(nitems, in, out);
+    }
+    py::object none = py::none();
+    return py::make_tuple(produced, ang, n_outputs > 1 ? py::object(lvl) : none, n_outputs > 2 ? py::object(spec) : none);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_baz_music, mod)
+{
+    mod.doc() = "baz.music_doa on the MI355X host block (stand-in for swig/baz_swig.i:560-574)";
+    py::class_<music_doa_handle>(mod, "baz_music_doa_sptr")
+        .def("set_array_response",
+             [](music_doa_handle& h, const array_response_t& t) { h.blk->set_array_response(t); },
+             py::arg("array_response"))
+        .def("array_response", [](music_doa_handle& h) { return h.blk->array_response(); })
+        .def("name", [](music_doa_handle& h) { return h.blk->name(); })
+        .def("unique_id", [](music_doa_handle& h) { return h.blk->unique_id(); })
+        .def("m", [](music_doa_handle& h) { return h.blk->m(); })
+        .def("n", [](music_doa_handle& h) { return h.blk->n(); })
+        .def("nsamples", [](music_doa_handle& h) { return h.blk->nsamples(); })
+        .def("resolution", [](music_doa_handle& h) { return h.blk->resolution(); })
+        .def("input_item_sizes", [](music_doa_handle& h) { return h.blk->input_signature()->sizeof_stream_items(); })
+        .def("output_item_sizes", [](music_doa_handle& h) { return h.blk->output_signature()->sizeof_stream_items(); })
+        .def("output_streams", [](music_doa_handle& h) {
+            return py::make_tuple(h.blk->output_signature()->min_streams(), h.blk->output_signature()->max_streams());
+        })
+        .def("work", &drive_work, py::arg("items"), py::arg("n_outputs") = 3);
+    mod.def("music_doa",
+            [](unsigned int m, unsigned int n, unsigned int nsamples, const array_response_t& table, unsigned int resolution) {
+                music_doa_handle h;
+                h.blk = baz_make_music_doa(m, n, nsamples, table, resolution);
+                return h;
+            },
+            py::arg("m"), py::arg("n"), py::arg("nsamples"), py::arg("array_response"), py::arg("resolution"));
+}

@@ -1,0 +1,82 @@
+"""Multi-GPU layout of the MUSIC-DoA path: independent snapshot streams, no data-path collective.
+
+Every item (one work() call, lib/baz_music_doa.cc:72-161) is independent of every other -- the block
+carries no state across items except the read-only steering table -- so streams shard
+embarrassingly: stream s lives on rank s mod G (BASELINE.json config 4).  One process
+per GPU; torch.distributed (backend "nccl" = RCCL on the GPU box, "gloo" in CPU tests) is used ONLY
+for the start/stop barrier and the max-over-ranks clock of the benchmark contract, never for data.
+"""
+from __future__ import annotations
+
+import os
+
+
+def stream_owner(stream: int, world: int) -> int:
+    return stream % world
+
+
+def streams_of_rank(n_streams: int, world: int, rank: int):
+    """Round-robin deal (s mod G): disjoint over ranks, complete over [0, n_streams)."""
+    return [s for s in range(n_streams) if stream_owner(s, world) == rank]
+
+
+def dist_env():
+    """(rank, local_rank, world) from the torch.distributed.run environment (1 process per GPU)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(use_gpu: bool, local_rank: int = 0):
+    """Initialises torch.distributed when WORLD_SIZE > 1.  Returns True if a group is active."""
+    import torch.distributed as dist
+    rank, _, world = dist_env()
+    if world <= 1:
+        return False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if use_gpu:
+            import torch
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    return True
+
+
+def barrier(active: bool, use_gpu: bool):
+    if active:
+        import torch.distributed as dist
+        if use_gpu:
+            import torch
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
+
+
+def max_over_ranks(value: float, active: bool, use_gpu: bool) -> float:
+    if not active:
+        return value
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device="cuda" if use_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, active: bool, use_gpu: bool) -> float:
+    if not active:
+        return value
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device="cuda" if use_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def whole_job_rate(items_this_rank: float, elapsed_this_rank: float, active: bool, use_gpu: bool):
+    """value of the benchmark contract: units all ranks processed / max-over-ranks time."""
+    total = sum_over_ranks(items_this_rank, active, use_gpu)
+    tmax = max_over_ranks(elapsed_this_rank, active, use_gpu)
+    return total / tmax, tmax, total

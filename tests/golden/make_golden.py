@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz -- run in the build container (needs /root/reference for oracle/_ref).
+
+Each fixture holds: the complex64 input items, the complex64 steering table (helper formula,
+python/music_doa_helper.py:32-46, rounded like SWIG does), and the float32 outputs of
+
+    oracle/_ref/libbaz_music_ref.so  ==  the reference's OWN lib/baz_music_doa.cc::work(),
+    compiled from /root/reference against oracle/ref_shim (Armadillo/GNU Radio API subset),
+    eig_sym backed by LAPACK zheev (scipy's OpenBLAS) -- what Armadillo dispatches to.
+
+plus the fp64 strengths of the numpy restatement (for tie analysis).  Inputs are stored, not
+re-generated, so the fixtures do not depend on numpy's RNG stream.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import music_oracle as mo   # noqa: E402
+from oracle import music_ref as mr      # noqa: E402
+
+
+def fixture(name, m, n, nsamples, res, array, batch, snr_db, seed, angles=(40.3, 121.7),
+            frequency=mo.FREQUENCY, spacing=mo.SPACING):
+    table = mo.steering_table_c64(array, res, frequency, spacing)
+    items = mo.synth_items(batch, m, nsamples, array, frequency, spacing, angles_deg=angles,
+                           snr_db=snr_db, seed=seed)
+    ang, lvl, spec = mr.ref_work_batch(items, table, m, n)
+    _, _, _, strength = mo.music_doa_work_batch(items, table, m, n)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, items=items, table=table, ang=ang, lvl=lvl, spectrum=spec,
+                        strength64=strength, m=m, n=n, nsamples=nsamples, res=res,
+                        array=np.asarray(array, dtype=np.float64), snr_db=snr_db, seed=seed,
+                        angles=np.asarray(angles), frequency=frequency, spacing=spacing,
+                        generator="oracle/_ref (reference lib/baz_music_doa.cc::work on API shim, LAPACK zheev=%d)"
+                                  % int(mr.ref().baz_ref_uses_lapack()))
+    print("%-28s items %s  spectrum %s  %6.1f KiB" % (name, items.shape, spec.shape, os.path.getsize(path) / 1024))
+
+
+def main():
+    if not mr.have_ref():
+        mr.build()
+    if not mr.have_ref():
+        raise SystemExit("oracle/_ref could not be built (no /root/reference?)")
+    print("LAPACK zheev backend:", mr.ref_use_lapack(True))
+    sq = mo.array_geometry(4)
+    # BASELINE.json configs
+    fixture("cfg1_m4_n2_N256_r360", 4, 2, 256, 360, sq, 8, 20.0, 1001)
+    fixture("cfg2_m4_n2_N1024_r3600", 4, 2, 1024, 3600, sq, 4, 20.0, 1002)
+    fixture("cfg3_m8_n2_N4096_r36000", 8, 2, 4096, 36000, mo.array_geometry(8), 2, 20.0, 1003)
+    # SNR sweep at cfg1 (Appendix C: 10 / 40 dB)
+    fixture("cfg1_snr10", 4, 2, 256, 360, sq, 8, 10.0, 2001)
+    fixture("cfg1_snr40", 4, 2, 256, 360, sq, 8, 40.0, 2002)
+    # GRC defaults (grc/baz_music_doa.xml:13-55): m4 n1 N512 res360, ULA, frequency=1 spacing=1 is
+    # degenerate (lambda = 3e8 m), so use lambda = 2 spacing like a real deployment
+    fixture("grc_default_ula", 4, 1, 512, 360, mo.GRC_DEFAULT_ULA, 4, 20.0, 2003, angles=(63.0,),
+            frequency=mo.C_LIGHT / 2.0, spacing=1.0)
+    # shapes that exercise the generic paths: odd m, n = m-1, K % 32 != 0, res % 4 != 0, res % 16 != 0
+    fixture("odd_m3_n1_N300_r357", 3, 1, 300, 357, mo.array_geometry(3), 5, 15.0, 2004, angles=(200.5,))
+    fixture("m5_n3_N1000_r720", 5, 3, 1000, 720, mo.array_geometry(5), 4, 25.0, 2005, angles=(10.0, 95.5, 250.25))
+    fixture("m8_n5_N1024_r1000", 8, 5, 1024, 1000, mo.array_geometry(8), 3, 25.0, 2006,
+            angles=(15.0, 80.0, 140.0, 222.2, 300.0))
+    fixture("m2_n1_N64_r90", 2, 1, 64, 90, [[0.0, 0.0], [1.0, 0.0]], 6, 20.0, 2007, angles=(60.0,))
+    fixture("m6_n2_N1536_r1440", 6, 2, 1536, 1440, mo.array_geometry(6), 3, 20.0, 2008)
+    fixture("m7_n4_N700_r500", 7, 4, 700, 500, mo.array_geometry(7), 3, 30.0, 2009,
+            angles=(33.0, 111.0, 199.0, 287.0))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,97 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports exactly what
+include/baz_music_hip.h declares, validates arguments, and fails loudly without a GPU
+(no compute is attempted here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from gr_baz_amd import capi
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "baz_music_hip.h")).read()
+    return sorted(set(re.findall(r"BAZ_MUSIC_API\s+[\w\s\*]+?\b(baz_music_\w+)\s*\(", src)))
+
+
+def test_library_is_built_in_tree():
+    assert os.path.exists(capi.LIB_PATH), "run `python -m gr_baz_amd.build` (or __graft_entry__.build())"
+    assert os.path.dirname(capi.LIB_PATH).startswith(ROOT)
+
+
+def test_every_declared_symbol_is_exported():
+    declared = header_functions()
+    assert declared == sorted(capi.SYMBOLS), "capi.SYMBOLS is out of sync with include/baz_music_hip.h"
+    raw = ctypes.CDLL(capi.LIB_PATH)
+    for name in declared:
+        assert getattr(raw, name) is not None
+
+
+def test_header_cites_reference_lines():
+    src = open(os.path.join(ROOT, "include", "baz_music_hip.h")).read()
+    for cite in ("lib/baz_music_doa.cc:72-161", "lib/baz_music_doa.cc:35-53", "lib/baz_music_doa.cc:60-70",
+                 "lib/baz_music_doa.h:36,48,59"):
+        assert cite in src
+
+
+def test_strerror_and_version():
+    L = capi.lib()
+    assert L.baz_music_strerror(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5):
+        assert len(L.baz_music_strerror(code)) > 0
+    assert b"gfx950" in L.baz_music_version()
+    assert capi.q_stride(1) == 64 and capi.q_stride(64) == 64 and capi.q_stride(65) == 128
+
+
+@pytest.mark.parametrize("m,n,N,res", [
+    (0, 1, 8, 4),     # m > 0                         lib/baz_music_doa.cc:45
+    (4, 0, 8, 4),     # n > 0
+    (4, 4, 8, 4),     # n == m underflows .cc:93 (assert only demands m >= n, .cc:46)
+    (4, 5, 8, 4),     # m >= n                        .cc:46
+    (4, 2, 0, 4),     # nsamples > 0                  .cc:47
+    (4, 2, 10, 4),    # nsamples % m == 0             .cc:47
+    (4, 2, 8, 0),     # resolution > 0                .cc:48
+])
+def test_create_validates_like_the_reference_asserts(m, n, N, res):
+    """Argument validation precedes any device access, so it is testable without a GPU."""
+    h = ctypes.c_void_p()
+    tab = np.zeros((max(res, 1) * max(m, 1) * 2,), np.float32)
+    r = capi.lib().baz_music_create(ctypes.byref(h), m, n, N, res,
+                                    tab.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), -1)
+    assert r == capi.E_INVALID and not h.value
+
+
+def test_create_rejects_null_and_unsupported():
+    L = capi.lib()
+    h = ctypes.c_void_p()
+    assert L.baz_music_create(ctypes.byref(h), 4, 2, 8, 4, None, -1) == capi.E_INVALID
+    tab = np.zeros(17 * 2 * 4, np.float32)
+    r = L.baz_music_create(ctypes.byref(h), 17, 2, 34, 4, tab.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), -1)
+    assert r == capi.E_UNSUPPORTED     # m > BAZ_MUSIC_MAX_M: no silent CPU fallback
+    assert L.baz_music_process(None, None, 0, None, None, None) == capi.E_INVALID
+    assert L.baz_music_set_table(None, None) == capi.E_INVALID
+    L.baz_music_destroy(None)          # harmless
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.MusicError) as ei:
+        capi.Context(4, 2, 1024, 360, np.zeros((360, 4), np.complex64))
+    assert ei.value.code in (capi.E_NODEVICE, capi.E_HIP)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under gr_baz_amd/ may import, link or load it."""
+    bad = []
+    for dp, _, fns in os.walk(os.path.join(ROOT, "gr_baz_amd")):
+        for fn in fns:
+            if fn.endswith((".py", ".cc", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|libmusic_ref|music_ref\.|oracle/_ref|libbaz_music_ref", txt, re.M):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad

@@ -1,0 +1,227 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C-ABI,
+against (1) the golden vectors produced by the reference's own work() source, (2) the CPU oracle on
+seeded inputs, (3) size-independent properties at BASELINE.json's full sizes.
+
+Tolerance: north_star's 1e-5 relative on float32 spectra / levels; DoA bins identical except at
+reference-side ties (< 2e-5 relative)."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+from helpers import assert_doa_match, assert_spectrum_close
+from oracle import music_oracle as mo
+from oracle import music_ref as mr
+
+pytestmark = pytest.mark.gpu
+
+
+def _capi():
+    from gr_baz_amd import capi
+    return capi
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def device_run(ctx, items, gpu_device, want_lvl=True, want_spec=True):
+    torch = _torch()
+    B = items.shape[0]
+    x = torch.from_numpy(np.ascontiguousarray(items).view(np.float32)).to(gpu_device)
+    ang = torch.full((B, ctx.n), -1.0, dtype=torch.float32, device=gpu_device)
+    lvl = torch.full((B, ctx.n), -1.0, dtype=torch.float32, device=gpu_device) if want_lvl else None
+    spec = torch.full((B, ctx.res), -1.0, dtype=torch.float32, device=gpu_device) if want_spec else None
+    ctx.process_device(x.data_ptr(), B, ang.data_ptr(), lvl.data_ptr() if want_lvl else None,
+                       spec.data_ptr() if want_spec else None)
+    ctx.sync()
+    return (ang.cpu().numpy(), lvl.cpu().numpy() if want_lvl else None,
+            spec.cpu().numpy() if want_spec else None)
+
+
+# ------------------------------------------------------------------ golden vectors
+@pytest.mark.parametrize("name", golden_names())
+def test_hip_matches_golden_device_path(name, gpu_device):
+    g = load_golden(name)
+    with _capi().Context(g["m"], g["n"], g["nsamples"], g["res"], g["table"]) as ctx:
+        ang, lvl, spec = device_run(ctx, g["items"], gpu_device)
+    worst = assert_spectrum_close(spec, g["spectrum"])
+    assert_doa_match(ang, lvl, g["ang"], g["lvl"], g["res"], g["strength64"])
+    assert worst < 1e-6      # measured ~1.2e-7: fp64 accumulation + 2-ulp f32 reciprocal
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_hip_matches_golden_host_path(name, gpu_device):
+    g = load_golden(name)
+    with _capi().Context(g["m"], g["n"], g["nsamples"], g["res"], g["table"]) as ctx:
+        ang, lvl, spec = ctx.process(g["items"])
+    assert_spectrum_close(spec, g["spectrum"])
+    assert_doa_match(ang, lvl, g["ang"], g["lvl"], g["res"], g["strength64"])
+
+
+# ------------------------------------------------------------------ seeded inputs vs the oracle
+@pytest.mark.parametrize("snr", [10.0, 20.0, 40.0])
+@pytest.mark.parametrize("cfg,batch", [("cfg1", 300), ("cfg2", 200), ("cfg3", 24)])
+def test_hip_matches_oracle_on_seeded_batches(cfg, batch, snr, gpu_device):
+    c = mo.make_config(cfg, batch, snr_db=snr, seed=4242 + int(snr))
+    ao, lo, so, st = mo.music_doa_work_batch(c["items"], c["table"], c["m"], c["n"])
+    with _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"]) as ctx:
+        ang, lvl, spec = device_run(ctx, c["items"], gpu_device)
+    assert_spectrum_close(spec, so)
+    assert_doa_match(ang, lvl, ao, lo, c["res"], st)
+
+
+def test_stage_taps_covariance_and_projector(gpu_device):
+    """The two intermediate stages against fp64 numpy: R = x x^H / K (.cc:85) and the projector of
+    the (m-n) smallest eigenvectors (.cc:88-93)."""
+    torch = _torch()
+    capi = _capi()
+    for cfg, B in (("cfg1", 130), ("cfg3", 37)):
+        c = mo.make_config(cfg, B, snr_db=25.0, seed=99)
+        m, n, N = c["m"], c["n"], c["nsamples"]
+        with capi.Context(m, n, N, c["res"], c["table"]) as ctx:
+            x = torch.from_numpy(c["items"].view(np.float32)).to(gpu_device)
+            R = torch.zeros(B, m * m, 2, dtype=torch.float64, device=gpu_device)
+            ctx.debug_cov(x.data_ptr(), B, R.data_ptr())
+            Q = torch.zeros(m * m, capi.q_stride(B), dtype=torch.float64, device=gpu_device)
+            ctx.debug_evd(R.data_ptr(), B, Q.data_ptr())
+            ctx.sync()
+        Rg = R.cpu().numpy()
+        Rg = (Rg[..., 0] + 1j * Rg[..., 1]).reshape(B, m, m)
+        xs = c["items"].astype(np.complex128).reshape(B, N // m, m).transpose(0, 2, 1)
+        Rn = xs @ xs.conj().transpose(0, 2, 1) / (N // m)
+        assert np.abs(Rg - Rn).max() <= 1e-14 * np.abs(Rn).max()
+        assert np.array_equal(Rg, Rg.conj().transpose(0, 2, 1))          # exactly Hermitian
+        w, V = np.linalg.eigh(Rn)
+        G = V[:, :, :m - n]
+        P = G @ G.conj().transpose(0, 2, 1)
+        Qg = Q.cpu().numpy()[:, :B].T.reshape(B, m, m)
+        for i in range(m):
+            assert np.abs(Qg[:, i, i] - P[:, i, i].real).max() < 1e-12
+            for j in range(i + 1, m):
+                assert np.abs(Qg[:, i, j] - 2 * P[:, i, j].real).max() < 1e-12
+                assert np.abs(Qg[:, j, i] + 2 * P[:, i, j].imag).max() < 1e-12
+
+
+@pytest.mark.parametrize("m,n,N,res,batch", [
+    (4, 1, 512, 360, 1),        # a single item (the reference's one-item work())
+    (4, 3, 64, 33, 70),         # n = m-1, res % 4 != 0 (scalar spectrum stores), batch % 16 != 0
+    (2, 1, 6, 5, 17),           # tiny everything, K = 3 (MFMA tail path)
+    (3, 2, 33, 1000, 65),       # odd m: K padding of the 9-term form
+    (5, 1, 40, 121, 100),
+    (6, 5, 96, 250, 33),        # NMAX = 8 list
+    (7, 3, 7 * 37, 77, 48),
+    (8, 7, 8 * 20, 1024, 20),   # n = 7 on the 8-antenna path
+    (8, 1, 8 * 1000, 90, 5),    # long integration, short table
+])
+def test_hip_matches_oracle_on_odd_shapes(m, n, N, res, batch, gpu_device):
+    arr = mo.array_geometry(m) if m != 2 else [[0.0, 0.0], [1.0, 0.0]]
+    table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
+    angles = tuple(np.linspace(17.0, 311.0, n))
+    items = mo.synth_items(batch, m, N, arr, mo.FREQUENCY, mo.SPACING, angles_deg=angles, snr_db=20.0,
+                           seed=100 * m + n)
+    ao, lo, so, st = mo.music_doa_work_batch(items, table, m, n)
+    with _capi().Context(m, n, N, res, table) as ctx:
+        ang, lvl, spec = device_run(ctx, items, gpu_device)
+        a2, l2, s2 = ctx.process(items)
+    assert_spectrum_close(spec, so)
+    assert_doa_match(ang, lvl, ao, lo, res, st)
+    assert np.array_equal(a2, ang) and np.array_equal(l2, lvl) and np.array_equal(s2, spec)
+
+
+def test_optional_ports(gpu_device):
+    """output_items.size() in {1,2,3} (lib/baz_music_doa.cc:97-99,147-154; lvl NULL must not crash)."""
+    c = mo.make_config("cfg1", 50, seed=3)
+    with _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"]) as ctx:
+        a3, l3, s3 = device_run(ctx, c["items"], gpu_device)
+        a2, l2, s2 = device_run(ctx, c["items"], gpu_device, want_spec=False)
+        a1, l1, s1 = device_run(ctx, c["items"], gpu_device, want_lvl=False, want_spec=False)
+        h1 = ctx.process(c["items"], want_lvl=False, want_spectrum=False)
+    assert s2 is None and l1 is None and s1 is None and h1[1] is None and h1[2] is None
+    assert np.array_equal(a3, a2) and np.array_equal(a3, a1) and np.array_equal(l3, l2)
+    assert np.array_equal(h1[0], a3)
+
+
+def test_set_table_takes_effect_from_the_next_item(gpu_device):
+    """set_array_response (lib/baz_music_doa.cc:60-70) == music_doa_helper.set_frequency (:100-103)."""
+    c = mo.make_config("cfg1", 40, seed=8)
+    arr = c["array"]
+    t2 = mo.steering_table_c64(arr, c["res"], mo.FREQUENCY * 0.8, mo.SPACING)
+    with _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"]) as ctx:
+        a0, l0, s0 = device_run(ctx, c["items"], gpu_device)
+        ctx.set_table(t2)
+        a1, l1, s1 = device_run(ctx, c["items"], gpu_device)
+        ctx.set_table(c["table"])
+        a2, l2, s2 = device_run(ctx, c["items"], gpu_device)
+    _, _, so1, _ = mo.music_doa_work_batch(c["items"], t2, c["m"], c["n"])
+    assert_spectrum_close(s1, so1)
+    assert not np.allclose(s1, s0, rtol=1e-3)
+    assert np.array_equal(s2, s0) and np.array_equal(a2, a0)
+    with pytest.raises(ValueError):
+        ctx.set_table(t2[:-1])
+
+
+def test_top_n_semantics_on_device(gpu_device):
+    """Crafted tables so that the spectrum has exact ties / plateaus: earliest bin wins, n largest
+    BINS (adjacent bins of one lobe), lvl == spectrum[bin]."""
+    m, n, N, res = 4, 3, 256, 64
+    arr = mo.array_geometry(m)
+    base = mo.steering_table_c64(arr, 16, mo.FREQUENCY, mo.SPACING)
+    table = np.tile(base, (4, 1))                      # period-16 table: every strength appears 4 times
+    items = mo.synth_items(33, m, N, arr, mo.FREQUENCY, mo.SPACING, angles_deg=(45.0, 200.0, 300.0), snr_db=20.0, seed=21)
+    ao, lo, so, st = mo.music_doa_work_batch(items, table, m, n)
+    with _capi().Context(m, n, N, res, table) as ctx:
+        ang, lvl, spec = device_run(ctx, items, gpu_device)
+    assert np.array_equal(spec[:, :16], spec[:, 16:32]) and np.array_equal(spec[:, :16], spec[:, 48:])
+    bins = np.rint(ang * res / 360.0).astype(int)
+    assert np.all(bins < 32), "ties must resolve to the earliest bin (strict '>', .cc:129-141)"
+    assert_spectrum_close(spec, so)
+    assert_doa_match(ang, lvl, ao, lo, res, st)
+    for b in range(items.shape[0]):
+        assert np.array_equal(lvl[b], spec[b, bins[b]])
+
+
+def test_zero_input_and_scaling(gpu_device):
+    """All-zero items give R = 0: every eigenvalue ties, LAPACK/Jacobi both return the identity basis,
+    so the noise space is e_0..e_{m-n-1}.  Scaling the input by 2^k changes nothing (exact)."""
+    c = mo.make_config("cfg1", 64, seed=17)
+    with _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"]) as ctx:
+        a0, l0, s0 = device_run(ctx, c["items"], gpu_device)
+        a1, l1, s1 = device_run(ctx, (c["items"] * np.float32(2.0 ** 20)).astype(np.complex64), gpu_device)
+        a2, l2, s2 = device_run(ctx, (c["items"] * np.float32(2.0 ** -30)).astype(np.complex64), gpu_device)
+        az, lz, sz = device_run(ctx, np.zeros_like(c["items"][:3]), gpu_device)
+    assert np.array_equal(s0, s1) and np.array_equal(s0, s2) and np.array_equal(a0, a1) and np.array_equal(a0, a2)
+    rz = mr.work_batch(np.zeros_like(c["items"][:3]), c["table"], c["m"], c["n"])
+    assert_spectrum_close(sz, rz[2])
+    assert np.all(np.isfinite(sz))
+
+
+# ------------------------------------------------------------------ full-size properties
+@pytest.mark.parametrize("cfg,batch,distinct", [("cfg2", 65536, 256), ("cfg3", 4096, 16)])
+def test_full_size_properties(cfg, batch, distinct, gpu_device):
+    """BASELINE.json sizes.  The oracle checks `distinct` items; the rest of the batch repeats them, so
+    (a) every repeat must be bit-identical to its first occurrence (no cross-item leakage, any
+    block/wave position), (b) lvl[i] == spectrum[bin_i] and bin_0 == argmax, (c) nothing is left
+    unwritten."""
+    torch = _torch()
+    c = mo.make_config(cfg, distinct, snr_db=20.0)
+    ao, lo, so, st = mo.music_doa_work_batch(c["items"], c["table"], c["m"], c["n"])
+    reps = batch // distinct
+    with _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"]) as ctx:
+        x = torch.from_numpy(c["items"].view(np.float32)).to(gpu_device).repeat(reps, 1).contiguous()
+        ang = torch.full((batch, c["n"]), -1.0, dtype=torch.float32, device=gpu_device)
+        lvl = torch.full_like(ang, -1.0)
+        spec = torch.full((batch, c["res"]), -1.0, dtype=torch.float32, device=gpu_device)
+        ctx.process_device(x.data_ptr(), batch, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr())
+        ctx.sync()
+    first = spec[:distinct]
+    assert bool((spec.view(reps, distinct, -1) == first.unsqueeze(0)).all())
+    assert bool((ang.view(reps, distinct, -1) == ang[:distinct].unsqueeze(0)).all())
+    assert bool((lvl.view(reps, distinct, -1) == lvl[:distinct].unsqueeze(0)).all())
+    assert bool((spec > 0).all())
+    assert_spectrum_close(first.cpu().numpy(), so)
+    assert_doa_match(ang[:distinct].cpu().numpy(), lvl[:distinct].cpu().numpy(), ao, lo, c["res"], st)
+    bins = torch.round(ang * (c["res"] / 360.0)).long()
+    assert bool((bins[:, 0] == spec.argmax(dim=1)).all())
+    assert bool((torch.gather(spec, 1, bins) == lvl).all())
+    assert bool((lvl[:, :-1] >= lvl[:, 1:]).all())
