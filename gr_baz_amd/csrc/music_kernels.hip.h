@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void cov_mfma_kernel(const float* __restrict__
     constexpr int ROWS = 2 * M;
     constexpr int IPT = 16 / ROWS;
     constexpr int MM = M * M;
+    constexpr int CH = 32;            // MFMA steps per chunk = loads in flight per lane per buffer
     static_assert(ROWS <= 16, "single-tile covariance handles m <= 8");
     __shared__ double gram[4][16 * 17];
 
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void cov_mfma_kernel(const float* __restrict__
     const uint32_t ntiles = (batch + IPT - 1) / IPT;
     const size_t item_floats = (size_t)K * ROWS;
     const uint32_t steps = (K + 3) >> 2;
-    const bool fast = (K & 31u) == 0; // 8 full MFMA steps per trip
+    const bool fast = (K % (4 * CH)) == 0;   // whole chunks, no column tail
     double* g = gram[wave];
 
     for (uint32_t tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
@@ -70,21 +71,37 @@ __global__ __launch_bounds__(256) void cov_mfma_kernel(const float* __restrict__
         const bool live = (sub < IPT) && (item < batch);
         const float* p = in + (size_t)(live ? item : 0) * item_floats + kk * ROWS + row;
         const float keep = live ? 1.0f : 0.0f;
-        v4f64 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};
+        v4f64 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 
         if (fast) {
-            for (uint32_t t = 0; t < steps; t += 8) {
-                float v[8];
+            // Two register buffers of CH loads each: the next chunk's 32 loads (8 KiB per wave) are in
+            // flight while the current chunk's 32 MFMAs (~2k cycles) retire.
+            float va[CH], vb[CH];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(t + u) * (4 * ROWS)];
+            for (int u = 0; u < CH; ++u) va[u] = p[(size_t)u * (4 * ROWS)];
+            for (uint32_t t = 0; t < steps; t += 2 * CH) {
+                const bool more_b = (t + CH) < steps;
+                if (more_b) {
 #pragma unroll
-                for (int u = 0; u < 8; u += 4) {
-                    double a0 = (double)(v[u + 0] * keep), a1 = (double)(v[u + 1] * keep);
-                    double a2 = (double)(v[u + 2] * keep), a3 = (double)(v[u + 3] * keep);
+                    for (int u = 0; u < CH; ++u) vb[u] = p[(size_t)(t + CH + u) * (4 * ROWS)];
+                }
+#pragma unroll
+                for (int u = 0; u < CH; u += 2) {
+                    const double a0 = (double)(va[u] * keep), a1 = (double)(va[u + 1] * keep);
                     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, a2, acc2, 0, 0, 0);
-                    acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a3, acc3, 0, 0, 0);
+                }
+                if (more_b) {
+                    if ((t + 2 * CH) < steps) {
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) va[u] = p[(size_t)(t + 2 * CH + u) * (4 * ROWS)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < CH; u += 2) {
+                        const double a0 = (double)(vb[u] * keep), a1 = (double)(vb[u + 1] * keep);
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
+                    }
                 }
             }
         } else {
@@ -95,14 +112,14 @@ __global__ __launch_bounds__(256) void cov_mfma_kernel(const float* __restrict__
                 acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc0, 0, 0, 0);
             }
         }
-        const v4f64 acc = (acc0 + acc1) + (acc2 + acc3);
+        const v4f64 acc = acc0 + acc1;
 
         // C/D layout of the f64 MFMA: col = lane&15, row = (lane>>4) + 4*reg.
 #pragma unroll
         for (int r = 0; r < 4; ++r) g[(kk + 4 * r) * 17 + i] = acc[r];
         wave_lds_fence();
 
-        const double invK = (double)K;
+        const double dK = (double)K;
         for (int e = lane; e < IPT * MM; e += 64) {
             const int s2 = e / MM, ab = e - s2 * MM;
             const int a = ab / M, b = ab - a * M;
@@ -110,7 +127,7 @@ __global__ __launch_bounds__(256) void cov_mfma_kernel(const float* __restrict__
             const double re = g[(base + 2 * a) * 17 + base + 2 * b] + g[(base + 2 * a + 1) * 17 + base + 2 * b + 1];
             const double im = g[(base + 2 * a + 1) * 17 + base + 2 * b] - g[(base + 2 * a) * 17 + base + 2 * b + 1];
             const uint32_t it2 = tile * IPT + s2;
-            if (it2 < batch) R[(size_t)it2 * MM + ab] = make_double2(re / invK, im / invK);   // .cc:85 "/ (double)average_over"
+            if (it2 < batch) R[(size_t)it2 * MM + ab] = make_double2(re / dK, im / dK);   // .cc:85 "/ (double)average_over"
         }
         wave_lds_fence();
     }
