@@ -132,7 +132,7 @@ def main():
     if rank == 0:
         scan_ms, scan_n = stage[capi.STAGE_SCAN]
         scan_avg_s = scan_ms / max(scan_n, 1) * 1e-3
-        scan_bytes = (4 * RES + 8 * N_EMIT) * batch                 # spectrum + ang + lvl written per launch
+        scan_bytes = (4 * RES + 8 * N_EMIT) * batch                 # spectrum + ang/lvl-equivalent written per launch
         achieved = scan_bytes / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
         traffic = None
         tj = os.path.join(ROOT, "profiles", "r01_scan_pmc_traffic.json")
@@ -153,7 +153,7 @@ def main():
                        "algorithmic_bytes_per_item": ctx.bytes_per_item(True),
                        "pipeline_hbm_fraction_of_8TBs": value / world * ctx.bytes_per_item(True) / 8e12,
                        "stage_ms_per_launch": {nm: stage[s][0] / max(stage[s][1], 1)
-                                               for s, nm in enumerate(("cov_mfma", "evd_proj", "scan_mfma"))}},
+                                               for s, nm in enumerate(("cov_mfma", "evd_proj", "scan_mfma", "topn_merge"))}},
             "roofline": {"bound": "hbm", "kernel": "scan_mfma_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_avg_s * 1e3,

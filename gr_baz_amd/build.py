@@ -23,7 +23,9 @@ INCLUDE = os.path.join(ROOT, "include")
 HIP_LIB = os.path.join(CSRC, "libbaz_music_hip.so")
 HOST_LIB = os.path.join(HOST, "libgnuradio_baz_music.so")
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden"]
+# -amdgpu-mfma-vgpr-form: MFMA accumulators in VGPRs (gfx950 has a unified file): no v_accvgpr_read per result
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+               "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _newer(target, sources):

@@ -35,14 +35,14 @@ struct baz_music_ctx {
     uint32_t m = 0, n = 0, nsamples = 0, res = 0, K = 0;
     int device = 0;
     hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    // steering table as the real bilinear-form table F[bin][m*m] (fp64) in MFMA A-operand order:
-    // FA[tile][lane][ks] (see build_F / build_FA), NaN padded
-    double* dFA = nullptr;
-    uint32_t fa_tiles = 0;   // number of real 16-bin tiles (one extra NaN tile is stored after them)
-    // per-bin-range top-n candidates (scan_mfma_kernel -> topn_merge_kernel)
-    double* dCandD = nullptr;
-    uint32_t* dCandB = nullptr;
+    hipStream_t stream = nullptr;      // the stream process_device() launches on (own or caller's)
+    // steering table as the real bilinear-form table F[bin][m*m] (fp64) in MFMA B-operand order:
+    // FB[step][chunk][lane] (double2), see build_FB
+    double2* dFB = nullptr;
+    uint32_t fb_steps = 0;   // 64-bin steps
+    uint32_t keep_mask = 0;  // low-word mask of the top-n key (bin index lives in the cleared bits)
+    // per-range top-n candidate keys (scan_mfma_kernel -> topn_merge_kernel)
+    double* dCand = nullptr;
     size_t cand_cap = 0;     // entries
     // workspace
     double2* dR = nullptr;
@@ -111,27 +111,32 @@ void build_F(const float* table_ri, uint32_t m, uint32_t res, std::vector<double
     }
 }
 
-// MFMA A-operand image of the table: FA[tile][lane][s], lane = (g = lane>>4, rho = lane&15):
-//   value = F[bin = 16*tile + 4*(rho&3) + (rho>>2)][e = 4*s + g]      (0 for e >= m*m)
-// so that accumulator register r of lane (g, c) holds bin 16*tile + 4*g + r (see scan_mfma_kernel).
-// Bins >= res are NaN: their d is NaN, which never enters a top-n list and is never stored.
-void build_FA(const std::vector<double>& F, uint32_t m, uint32_t res, uint32_t tiles, std::vector<double>& FA)
+// MFMA B-operand image of the table (scan_mfma_kernel): FB[step][c2][lane] (double2), c2 = 2*s + (t>>1),
+// component t&1, lane = (g = lane>>4, c = lane&15):
+//     value = F[bin = 64*step + 4*c + t][e = 4*s + g]          (0 for the K padding e >= m*m)
+// i.e. tile t of a 64-bin step carries the bins 4c + t in its columns, so that a lane's accumulator
+// registers of the 4 tiles are 4 consecutive bins.  Bins >= res (only in the last step) get a huge
+// diagonal: d = BIG * trace(Q) = BIG * (m - n), finite, never stored, never among the top n.
+void build_FB(const std::vector<double>& F, uint32_t m, uint32_t res, uint32_t steps, std::vector<double>& FB)
 {
     const uint32_t mm = m * m;
     const uint32_t ks = (mm + 3) / 4;
-    const double nan = std::nan("");
-    FA.assign((size_t)(tiles + 1) * 64 * ks, nan);
-    for (uint32_t t = 0; t < tiles; ++t)
-        for (uint32_t lane = 0; lane < 64; ++lane) {
-            const uint32_t g = lane >> 4, rho = lane & 15;
-            const uint32_t bin = 16 * t + 4 * (rho & 3) + (rho >> 2);
-            for (uint32_t s = 0; s < ks; ++s) {
-                const uint32_t e = 4 * s + g;
-                double v = nan;
-                if (bin < res) v = (e < mm) ? F[(size_t)bin * mm + e] : 0.0;
-                FA[((size_t)t * 64 + lane) * ks + s] = v;
-            }
-        }
+    const double BIG = 1e300;
+    FB.assign((size_t)steps * 2 * ks * 64 * 2, 0.0);
+    for (uint32_t st = 0; st < steps; ++st)
+        for (uint32_t s = 0; s < ks; ++s)
+            for (uint32_t t = 0; t < 4; ++t)
+                for (uint32_t lane = 0; lane < 64; ++lane) {
+                    const uint32_t g = lane >> 4, c = lane & 15;
+                    const uint32_t bin = 64 * st + 4 * c + t;
+                    const uint32_t e = 4 * s + g;
+                    double v = 0.0;
+                    if (e < mm) {
+                        if (bin < res) v = F[(size_t)bin * mm + e];
+                        else v = ((e / m) == (e % m)) ? BIG : 0.0;
+                    }
+                    FB[(((size_t)st * 2 * ks + 2 * s + (t >> 1)) * 64 + lane) * 2 + (t & 1)] = v;
+                }
 }
 
 uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
@@ -222,8 +227,14 @@ int launch_cov(baz_music_ctx* c, const float* d_in, uint32_t batch, double2* dR)
 template <int M>
 int launch_evd_t(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ, uint32_t qstride)
 {
-    const uint32_t blocks = (batch + 63) / 64;
-    hipLaunchKernelGGL((evd_proj_kernel<M>), dim3(blocks), dim3(64), 0, c->stream, dR, dQ, batch, c->n, qstride);
+    if constexpr (M <= 4) {   // one item per lane, register resident
+        const uint32_t blocks = (batch + 63) / 64;
+        hipLaunchKernelGGL((evd_proj_kernel<M>), dim3(blocks), dim3(64), 0, c->stream, dR, dQ, batch, c->n, qstride);
+    } else {                  // M lanes per item, matrices in LDS
+        constexpr uint32_t IPW = 64 / M;
+        const uint32_t blocks = (batch + IPW - 1) / IPW;
+        hipLaunchKernelGGL((evd_proj_lds_kernel<M>), dim3(blocks), dim3(64), 0, c->stream, dR, dQ, batch, c->n, qstride);
+    }
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
 }
@@ -243,58 +254,31 @@ int launch_evd(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ, 
     }
 }
 
-// How many bin ranges to split each item group into so that the launch fills the chip
-// (>= ~8 waves per SIMD) even for small batches / long tables (config 3: 4096 items x 36000 bins).
-uint32_t pick_nsplit(uint32_t groups, uint32_t ntiles)
+// Launch geometry of the scan: (16-item groups) x (`nsplit` ranges of 64-bin steps), chosen so that a launch
+// has >= ~8 waves/SIMD worth of wave tasks even for small batches / long tables (config 3: 4,096 items x
+// 36,000 bins).  Every range of every item yields NMAX candidate keys for topn_merge_kernel.
+struct ScanGeom {
+    uint32_t groups, nsplit, blocks;
+};
+
+ScanGeom scan_geometry(uint32_t batch, uint32_t nsteps)
 {
-    const uint32_t want_waves = 256u * 4u * 8u;
-    uint32_t ns = (want_waves + groups - 1) / groups;
-    ns = std::max<uint32_t>(1u, std::min<uint32_t>(ns, std::max<uint32_t>(1u, ntiles / 8u)));
-    return std::min<uint32_t>(ns, 64u);
+    ScanGeom G;
+    G.groups = (batch + 15) / 16;
+    const uint32_t want_tasks = 256u * 4u * 8u * 4u;
+    uint32_t ns = (want_tasks + G.groups - 1) / G.groups;
+    G.nsplit = std::max<uint32_t>(1u, std::min<uint32_t>(ns, std::min<uint32_t>(nsteps, 64u)));
+    G.blocks = ((G.groups + 3) / 4) * G.nsplit;
+    return G;
 }
 
 int ensure_candidates(baz_music_ctx* c, size_t entries)
 {
     if (entries <= c->cand_cap) return BAZ_MUSIC_OK;
-    if (c->dCandD) { (void)hipFree(c->dCandD); c->dCandD = nullptr; }
-    if (c->dCandB) { (void)hipFree(c->dCandB); c->dCandB = nullptr; }
+    if (c->dCand) { (void)hipFree(c->dCand); c->dCand = nullptr; }
     c->cand_cap = 0;
-    HIP_TRY(c, hipMalloc((void**)&c->dCandD, entries * sizeof(double)));
-    HIP_TRY(c, hipMalloc((void**)&c->dCandB, entries * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->dCand, entries * sizeof(double)));
     c->cand_cap = entries;
-    return BAZ_MUSIC_OK;
-}
-
-template <int M, int NMAX, int IT>
-int launch_scan_mfma(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t batch, float* d_ang,
-                     float* d_lvl, float* d_spec)
-{
-    constexpr uint32_t ITEMS = 16 * IT;
-    const uint32_t groups = (batch + ITEMS - 1) / ITEMS;
-    const uint32_t ntiles = c->fa_tiles;
-    const uint32_t nsplit = pick_nsplit(groups, ntiles);
-    const uint32_t waves = groups * nsplit;
-    const uint32_t blocks = (waves + 3) / 4;
-    if (nsplit > 1) {
-        int r = ensure_candidates(c, (size_t)batch * nsplit * NMAX);
-        if (r) return r;
-    }
-    const bool spec = d_spec != nullptr;
-    const bool vec4 = (c->res % 4u) == 0 && (reinterpret_cast<uintptr_t>(d_spec) % 16u) == 0;
-#define BAZ_SCAN_LAUNCH(SPEC, VEC4)                                                                        \
-    hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, IT, SPEC, VEC4>), dim3(blocks), dim3(256), 0, c->stream, \
-                       dQ, c->dFA, d_spec, d_ang, d_lvl, c->dCandD, c->dCandB, batch, c->res, c->n,        \
-                       qstride, ntiles, nsplit)
-    if (spec && vec4) BAZ_SCAN_LAUNCH(true, true);
-    else if (spec) BAZ_SCAN_LAUNCH(true, false);
-    else BAZ_SCAN_LAUNCH(false, false);
-#undef BAZ_SCAN_LAUNCH
-    HIP_TRY(c, hipGetLastError());
-    if (nsplit > 1) {
-        hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream,
-                           c->dCandD, c->dCandB, d_ang, d_lvl, batch, c->res, c->n, nsplit);
-        HIP_TRY(c, hipGetLastError());
-    }
     return BAZ_MUSIC_OK;
 }
 
@@ -302,9 +286,30 @@ template <int M, int NMAX>
 int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t batch, float* d_ang,
                   float* d_lvl, float* d_spec)
 {
-    // item tiles per wave: bounded by the VGPR budget (B operand IT*KS pairs + IT accumulators + lists)
-    constexpr int IT = (M <= 4) ? ((NMAX <= 2) ? 4 : ((NMAX <= 4) ? 2 : 1)) : ((M <= 6 && NMAX <= 4) ? 2 : 1);
-    return launch_scan_mfma<M, NMAX, IT>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec);
+    const ScanGeom G = scan_geometry(batch, c->fb_steps);
+    double* cand = c->dCand;
+    if ((size_t)batch * G.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;   // reserve_candidates() sized it
+    const bool spec = d_spec != nullptr;
+    const bool vec4 = (c->res % 4u) == 0 && (reinterpret_cast<uintptr_t>(d_spec) % 16u) == 0;
+#define BAZ_SCAN_LAUNCH(SPEC, VEC4)                                                                          \
+    hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4>), dim3(G.blocks), dim3(256), 0, c->stream, dQ, \
+                       c->dFB, d_spec, cand, batch, c->res, qstride, c->fb_steps, G.nsplit, G.groups, c->keep_mask)
+    if (spec && vec4) BAZ_SCAN_LAUNCH(true, true);
+    else if (spec) BAZ_SCAN_LAUNCH(true, false);
+    else BAZ_SCAN_LAUNCH(false, false);
+#undef BAZ_SCAN_LAUNCH
+    HIP_TRY(c, hipGetLastError());
+    return BAZ_MUSIC_OK;
+}
+
+template <int NMAX>
+int launch_merge_t(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl, float* d_spec)
+{
+    const ScanGeom G = scan_geometry(batch, c->fb_steps);
+    hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream, c->dCand,
+                       d_spec, d_ang, d_lvl, batch, c->res, c->n, G.nsplit, c->keep_mask);
+    HIP_TRY(c, hipGetLastError());
+    return BAZ_MUSIC_OK;
 }
 
 template <int M>
@@ -314,6 +319,26 @@ int launch_scan_m(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
     if (c->n <= 2) return launch_scan_t<M, 2>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec);
     if (c->n <= 4) return launch_scan_t<M, 4>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec);
     return launch_scan_t<M, 8>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec);
+}
+
+// candidate keys one scan launch over `nb` items produces (mirrors launch_scan_t's geometry)
+size_t cand_entries(const baz_music_ctx* c, uint32_t nb)
+{
+    const uint32_t nmax = c->n <= 2 ? 2u : (c->n <= 4 ? 4u : 8u);
+    return (size_t)nb * scan_geometry(nb, c->fb_steps).nsplit * nmax;
+}
+
+int reserve_candidates(baz_music_ctx* c, uint32_t batch)
+{
+    return ensure_candidates(c, cand_entries(c, batch));
+}
+
+int launch_merge(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl, float* d_spec)
+{
+    ProfScope ps(c, BAZ_MUSIC_STAGE_MERGE);
+    if (c->n <= 2) return launch_merge_t<2>(c, batch, d_ang, d_lvl, d_spec);
+    if (c->n <= 4) return launch_merge_t<4>(c, batch, d_ang, d_lvl, d_spec);
+    return launch_merge_t<8>(c, batch, d_ang, d_lvl, d_spec);
 }
 
 int launch_scan(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t batch, float* d_ang,
@@ -336,25 +361,34 @@ int upload_table(baz_music_ctx* c, const float* table_ri)
 {
     std::vector<double> F;
     build_F(table_ri, c->m, c->res, F);
-    std::vector<double> FA;
-    build_FA(F, c->m, c->res, c->fa_tiles, FA);
+    std::vector<double> FB;
+    build_FB(F, c->m, c->res, c->fb_steps, FB);
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // no batch in flight reads the old table
-    HIP_TRY(c, hipMemcpy(c->dFA, FA.data(), FA.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->dFB, FB.data(), FB.size() * sizeof(double), hipMemcpyHostToDevice));
     return BAZ_MUSIC_OK;
 }
 
+// One pass of the hot path over `batch` device-resident items: three launches (+ the tiny top-n merge) back
+// to back on the context's stream.  (Cutting the batch into sub-batches and overlapping covariance/EVD of
+// sub-batch i+1 with the scan of sub-batch i on two extra streams was measured and is SLOWER -- 0.53 ms ->
+// 0.60 / 0.70 / 1.05 ms at 2 / 4 / 8 sub-batches, profiles/r01_two_stream_pipeline_negative.txt: the
+// cross-stream event dependencies cost more than the overlap buys.)
 int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void* d_ang, void* d_lvl,
                           void* d_spec)
 {
     int r = ensure_workspace(c, batch);
+    if (r) return r;
+    r = reserve_candidates(c, batch);
     if (r) return r;
     const uint32_t qstride = baz_music_q_stride(batch);
     r = launch_cov(c, static_cast<const float*>(d_in), batch, c->dR);
     if (r) return r;
     r = launch_evd(c, c->dR, batch, c->dQ, qstride);
     if (r) return r;
-    return launch_scan(c, c->dQ, qstride, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl),
-                       static_cast<float*>(d_spec));
+    r = launch_scan(c, c->dQ, qstride, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl),
+                    static_cast<float*>(d_spec));
+    if (r) return r;
+    return launch_merge(c, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), static_cast<float*>(d_spec));
 }
 
 }  // namespace
@@ -391,8 +425,11 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     do {
         if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         c->stream = c->own_stream;
-        c->fa_tiles = (resolution + 15) / 16;
-        if (hipMalloc((void**)&c->dFA, (size_t)(c->fa_tiles + 1) * 64 * ((m * m + 3) / 4) * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+        c->fb_steps = (resolution + 63) / 64;
+        // bin field of the top-n key: 16 bits up to 65,536 bins (d truncated by <= 2^-36), else 20 bits
+        if (resolution > (1u << 20)) { r = BAZ_MUSIC_E_UNSUPPORTED; break; }
+        c->keep_mask = (resolution <= (1u << 16)) ? 0xFFFF0000u : 0xFFF00000u;
+        if (hipMalloc((void**)&c->dFB, (size_t)c->fb_steps * 2 * ((m * m + 3) / 4) * 64 * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         r = upload_table(c, table_ri);
     } while (0);
     if (r != BAZ_MUSIC_OK) {
@@ -402,10 +439,12 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     char buf[128];
     snprintf(buf, sizeof(buf), "bazmusic::cov_mfma_kernel<%u>", m);
     c->stage_name[BAZ_MUSIC_STAGE_COV] = buf;
-    snprintf(buf, sizeof(buf), "bazmusic::evd_proj_kernel<%u>", m);
+    snprintf(buf, sizeof(buf), m <= 4 ? "bazmusic::evd_proj_kernel<%u>" : "bazmusic::evd_proj_lds_kernel<%u>", m);
     c->stage_name[BAZ_MUSIC_STAGE_EVD] = buf;
     snprintf(buf, sizeof(buf), "bazmusic::scan_mfma_kernel<%u,", m);
     c->stage_name[BAZ_MUSIC_STAGE_SCAN] = buf;
+    snprintf(buf, sizeof(buf), "bazmusic::topn_merge_kernel<%u>", n <= 2 ? 2u : (n <= 4 ? 4u : 8u));
+    c->stage_name[BAZ_MUSIC_STAGE_MERGE] = buf;
     *out = c;
     return BAZ_MUSIC_OK;
 }
@@ -418,9 +457,8 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         for (auto& p : c->prof)
             for (auto e : p.ev) (void)hipEventDestroy(e);
-        if (c->dFA) (void)hipFree(c->dFA);
-        if (c->dCandD) (void)hipFree(c->dCandD);
-        if (c->dCandB) (void)hipFree(c->dCandB);
+        if (c->dFB) (void)hipFree(c->dFB);
+        if (c->dCand) (void)hipFree(c->dCand);
         if (c->dR) (void)hipFree(c->dR);
         if (c->dQ) (void)hipFree(c->dQ);
         if (c->s_in) (void)hipFree(c->s_in);
@@ -464,7 +502,8 @@ int baz_music_reserve(baz_music_ctx* c, uint32_t max_batch)
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return ensure_workspace(c, max_batch);
+    int r = ensure_workspace(c, max_batch);
+    return r ? r : reserve_candidates(c, max_batch);
 }
 
 uint32_t baz_music_q_stride(uint32_t batch) { return round_up(batch ? batch : 1, 64); }

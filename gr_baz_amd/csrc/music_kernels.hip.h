@@ -4,8 +4,8 @@
 //   cov_mfma_kernel   .cc:74-85   widen c64->c128, x = reshape(m,K), R = x x^H / K
 //   evd_proj_kernel   .cc:88-93   Hermitian EVD (ascending), noise basis G = first m-n eigenvectors;
 //                                 emitted as the real coefficients of the projector Q = G G^H
-//   scan_mfma_kernel  .cc:101-155 per-bin strength 1/||G^H a||^2 (as 1/(a^H Q a), an fp64 MFMA GEMM),
-//                                 optional spectrum port, strict-">" top-n insertion
+//   scan_mfma_kernel  .cc:101-141 per-bin strength 1/||G^H a||^2 (as 1/(a^H Q a), an fp64 MFMA GEMM),
+//                                 optional spectrum port, per-range top-n candidates
 //   topn_merge_kernel .cc:129-155 final top-n across bin ranges, ang/lvl outputs
 //
 // Precision contract: inputs and the steering table stay fp32 in HBM
@@ -19,6 +19,7 @@
 namespace bazmusic {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void wave_lds_fence()
 {
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict_
                                                        uint32_t batch, uint32_t n, uint32_t qstride)
 {
     constexpr int MM = M * M;
-    constexpr bool UNROLL = (M <= 4);   // register-resident, statically indexed; larger M uses private arrays
+    constexpr bool UNROLL = (M <= 4);   // register-resident, statically indexed (m >= 5 uses evd_proj_lds_kernel)
     constexpr int MAX_SWEEPS = 16;
     const uint32_t item = blockIdx.x * 64 + threadIdx.x;
     const bool valid = item < batch;
@@ -296,36 +297,223 @@ __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict_
         }
 }
 
+// -------------------------------------------------------------------------------------
+// 2b. The same EVD for m >= 5: M lanes per item, A and V live in LDS (complex128, 2*M*M*16 B per item).
+//     A rotation (p,q) is two lane-parallel phases: lane j applies the column operation to ITS ROW of
+//     A and V (A J, V J), then -- after a wave-level LDS hand-over -- the row operation to ITS COLUMN
+//     of A (J^H (A J)).  Rotation parameters are recomputed by every lane of the item (SIMD: free).
+//     Compact code (runtime p,q loops) instead of a >64 KiB fully unrolled register kernel or the
+//     private-array (scratch) form, which took 1.17 ms per 4,096 8x8 items.
+// -------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restrict__ R,
+                                                           double* __restrict__ Qs,
+                                                           uint32_t batch, uint32_t n, uint32_t qstride)
+{
+    constexpr int MM = M * M;
+    constexpr int IPW = 64 / M;           // items per wave
+    constexpr int MAX_SWEEPS = 24;
+    __shared__ double2 sA[IPW][M][M + 1]; // +1: rows of different lanes start on different banks
+    __shared__ double2 sV[IPW][M][M + 1];
+    __shared__ double sPart[IPW][M];
+
+    const int lane = threadIdx.x;
+    const int slot = lane / M;            // item within the wave
+    const int j = lane - slot * M;        // this lane's row (phase 1) / column (phase 2)
+    const bool lane_used = slot < IPW;
+    const int sl = lane_used ? slot : 0;
+    const uint32_t item = blockIdx.x * IPW + sl;
+    const bool valid = lane_used && item < batch;
+    const uint32_t itc = (item < batch) ? item : (batch - 1);
+    double2(*A)[M + 1] = sA[sl];
+    double2(*V)[M + 1] = sV[sl];
+
+    if (lane_used) {
+        const double2* Rp = R + (size_t)itc * MM + j * M;
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+            double2 v = Rp[k];
+            if (k == j) v.y = 0.0;
+            A[j][k] = v;
+            V[j][k] = make_double2(k == j ? 1.0 : 0.0, 0.0);
+        }
+    }
+    wave_lds_fence();
+    // exact power-of-two normalisation (see evd_proj_kernel)
+    double dmax = 0.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) dmax = fmax(dmax, fabs(A[k][k].x));
+    int ex = 0;
+    (void)frexp(dmax, &ex);
+    const double scl = (dmax > 0.0 && dmax < __builtin_huge_val()) ? ldexp(1.0, -ex) : 1.0;
+    wave_lds_fence();
+    if (lane_used) {
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+            double2 v = A[j][k];
+            v.x *= scl; v.y *= scl;
+            A[j][k] = v;
+        }
+    }
+    wave_lds_fence();
+
+    for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
+        double off = 0.0, dj = 0.0;
+        if (lane_used) {
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+                const double2 v = A[j][k];
+                if (k == j) dj = v.x * v.x; else off += v.x * v.x + v.y * v.y;
+            }
+            sPart[sl][j] = off;
+        }
+        wave_lds_fence();
+        double offsum = 0.0, dia = 0.0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) { offsum += sPart[sl][k]; const double a = A[k][k].x; dia += a * a; }
+        (void)dj;
+        const bool done = !(offsum > 2e-33 * dia);   // offsum counts every off-diagonal twice
+        wave_lds_fence();
+        if (__all(done || !lane_used)) break;
+
+        for (int p = 0; p < M - 1; ++p)
+            for (int q = p + 1; q < M; ++q) {
+                const double2 apq = A[p][q];
+                const double app = A[p][p].x, aqq = A[q][q].x;
+                const double g2 = apq.x * apq.x + apq.y * apq.y;
+                const bool rot = g2 > 1e-40;
+                const double gg = sqrt(g2);
+                const double ig = rot ? 1.0 / gg : 0.0;
+                const double ur = rot ? apq.x * ig : 1.0;
+                const double ui = rot ? apq.y * ig : 0.0;
+                const double tau = (aqq - app) * 0.5 * ig;
+                double t = copysign(1.0, tau) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                t = rot ? t : 0.0;
+                const double c = 1.0 / sqrt(1.0 + t * t);
+                const double s = t * c;
+                const double sur = s * ur, sui = s * ui, cur = c * ur, cui = c * ui;
+                // phase 1: this lane's row j of A and V, columns p and q  (A J, V J)
+                if (lane_used) {
+                    {
+                        const double2 x = A[j][p], y = A[j][q];
+                        A[j][p] = make_double2(c * x.x - (sur * y.x + sui * y.y), c * x.y - (sur * y.y - sui * y.x));
+                        A[j][q] = make_double2(s * x.x + (cur * y.x + cui * y.y), s * x.y + (cur * y.y - cui * y.x));
+                    }
+                    {
+                        const double2 x = V[j][p], y = V[j][q];
+                        V[j][p] = make_double2(c * x.x - (sur * y.x + sui * y.y), c * x.y - (sur * y.y - sui * y.x));
+                        V[j][q] = make_double2(s * x.x + (cur * y.x + cui * y.y), s * x.y + (cur * y.y - cui * y.x));
+                    }
+                }
+                wave_lds_fence();
+                // phase 2: this lane's column j of A, rows p and q  (J^H (A J))
+                if (lane_used) {
+                    const double2 x = A[p][j], y = A[q][j];
+                    double2 np = make_double2(c * x.x - (sur * y.x - sui * y.y), c * x.y - (sur * y.y + sui * y.x));
+                    double2 nq = make_double2(s * x.x + (cur * y.x - cui * y.y), s * x.y + (cur * y.y + cui * y.x));
+                    if (j == q) np = make_double2(0.0, 0.0);        // a_pq := 0
+                    if (j == p) { nq = make_double2(0.0, 0.0); np.y = 0.0; }   // a_qp := 0, real diagonal
+                    if (j == q) nq.y = 0.0;
+                    A[p][j] = np;
+                    A[q][j] = nq;
+                }
+                wave_lds_fence();
+            }
+    }
+
+    // ascending rank of each eigenvalue (ties -> lower column first), noise = rank < m-n
+    double wk[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) wk[k] = A[k][k].x;
+    double msk[M];
+    const int nnoise = (int)M - (int)n;
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        int rank = 0;
+#pragma unroll
+        for (int l = 0; l < M; ++l) rank += (wk[l] < wk[k] || (wk[l] == wk[k] && l < k)) ? 1 : 0;
+        msk[k] = (rank < nnoise) ? 1.0 : 0.0;
+    }
+    // lane j emits row j of Q (upper part): Q_jl = sum_k msk_k V[j][k] conj(V[l][k])
+    if (valid) {
+        double2 vj[M];
+#pragma unroll
+        for (int k = 0; k < M; ++k) vj[k] = V[j][k];
+        for (int l = j; l < M; ++l) {
+            double re = 0.0, im = 0.0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+                const double2 vl = V[l][k];
+                re += msk[k] * (vj[k].x * vl.x + vj[k].y * vl.y);
+                im += msk[k] * (vj[k].y * vl.x - vj[k].x * vl.y);
+            }
+            if (l == j) {
+                Qs[(size_t)(j * M + j) * qstride + item] = re;
+            } else {
+                Qs[(size_t)(j * M + l) * qstride + item] = 2.0 * re;
+                Qs[(size_t)(l * M + j) * qstride + item] = -2.0 * im;
+            }
+        }
+    }
+}
+
 // =====================================================================================
-// 3. Top-n bookkeeping shared by the scan and merge kernels (lib/baz_music_doa.cc:95,129-141).
-//    Lists are kept in d = 1/strength ascending order; strict "<" on d while bins arrive in
-//    ascending order reproduces the reference's strict ">" insertion on strength (earliest bin
-//    wins ties); NaN never inserts; untouched slots stay (d = +inf, bin 0) = (strength 0, angle 0).
+// 3. Top-n bookkeeping (lib/baz_music_doa.cc:95,129-141) on packed fp64 keys.
+//
+//    key = bits(d) with the low `binbits` mantissa bits replaced by the bin index, d = ||G^H a||^2 >= 0.
+//    For non-negative doubles the IEEE order is the integer order of the bits, so keys order by
+//    (d truncated by <= 2^-36 relative, then bin): the n SMALLEST keys are the reference's n largest
+//    strengths with the earliest bin winning ties -- exactly the outcome of its strict-">" insertion
+//    over ascending bins -- except between bins whose d agree to 1.5e-11 relative (the parity rule
+//    tolerates 2e-5).  Lists are kept ascending with a branch-free v_min_f64 / v_max_f64 network
+//    (2*NMAX-1 instructions per candidate, no divergence, no data-dependent slow path).
+//    Non-finite d (NaN / +inf -> strength 0) form NaN keys, which min/max drop: never inserted, like
+//    the reference.  EMPTY marks an unused slot = (angle 0, strength 0).
 // =====================================================================================
+#define BAZ_KEY_EMPTY_BITS 0x7FEFFFFFFFF00000ull   /* ~DBL_MAX, low 20 bits clear */
+
+__device__ __forceinline__ double key_empty() { return __builtin_bit_cast(double, (uint64_t)BAZ_KEY_EMPTY_BITS); }
+
+__device__ __forceinline__ double vmin64(double a, double b)
+{
+    double r;   // raw v_min_f64: no canonicalisation pass over the hand-built keys
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vmax64(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ double make_key(const double d, const uint32_t bin, const uint32_t keep_mask)
+{
+    const uint64_t b = __builtin_bit_cast(uint64_t, d);
+    const uint32_t hi = (uint32_t)(b >> 32) & 0x7FFFFFFFu;          // |d|
+    const uint32_t lo = ((uint32_t)b & keep_mask) | bin;
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
 template <int NMAX>
-__device__ __forceinline__ void topn_insert(double (&td)[NMAX], uint32_t (&tb)[NMAX], const double d, const uint32_t bin)
+__device__ __forceinline__ void key_insert(double (&t)[NMAX], double k)
 {
 #pragma unroll
-    for (int i = NMAX - 1; i >= 0; --i) {
-        const bool ci = d < td[i];
-        const bool cp = (i > 0) ? (d < td[(i > 0) ? i - 1 : 0]) : false;
-        td[i] = ci ? (cp ? td[(i > 0) ? i - 1 : 0] : d) : td[i];
-        tb[i] = ci ? (cp ? tb[(i > 0) ? i - 1 : 0] : bin) : tb[i];
+    for (int i = 0; i < NMAX; ++i) {
+        const double lo = vmin64(k, t[i]);
+        if (i + 1 < NMAX) k = vmax64(k, t[i]);
+        t[i] = lo;
     }
 }
 
 template <int NMAX>
-__device__ __forceinline__ void topn_insert_lex(double (&td)[NMAX], uint32_t (&tb)[NMAX], const double d, const uint32_t bin)
+__device__ __forceinline__ void key_merge_xor(double (&t)[NMAX], const int mask)
 {
-    // merge step: candidates arrive out of bin order -> explicit (d, bin) lexicographic order
+    double o[NMAX];
 #pragma unroll
-    for (int i = NMAX - 1; i >= 0; --i) {
-        const int im = (i > 0) ? i - 1 : 0;
-        const bool ci = (d < td[i]) || (d == td[i] && bin < tb[i]);
-        const bool cp = (i > 0) ? ((d < td[im]) || (d == td[im] && bin < tb[im])) : false;
-        td[i] = ci ? (cp ? td[im] : d) : td[i];
-        tb[i] = ci ? (cp ? tb[im] : bin) : tb[i];
-    }
+    for (int i = 0; i < NMAX; ++i) o[i] = __shfl_xor(t[i], mask, 64);
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) key_insert<NMAX>(t, o[i]);
 }
 
 __device__ __forceinline__ float strength_f32(const double d)
@@ -336,189 +524,169 @@ __device__ __forceinline__ float strength_f32(const double d)
 }
 
 // =====================================================================================
-// 4. Pseudo-spectrum scan as an fp64 MFMA GEMM  D[bins x items] = F[bins x MM] * Q^T[MM x items].
+// 4. Pseudo-spectrum scan as an fp64 MFMA GEMM  D[items x bins] = Q[items x MM] * F^T[MM x bins].
 //
-//    Measured on gfx950 (scripts/ubench.hip, profiles/): v_mfma_f64_16x16x4_f64 retires 1024 FMAs in
-//    65 cycles/SIMD (77 TFLOP/s) -- the same rate as v_fma_f64 (16 wave-instructions = 78 cycles) --
-//    but its operands are lane-distributed, so the shared table F needs NO wave-uniform broadcast:
-//    it streams through plain coalesced vector loads (deeply pipelined with vmcnt).  (A lane=item
-//    v_fma_f64 form fed by scalar loads of F was measured first: 0.495 ms per 65,536 cfg-2 items,
-//    72 % of its wave cycles in s_waitcnt on scalar-cache misses; this form: 0.289 ms. DESIGN.md 5.)
+//    Measured on gfx950 (scripts/ubench*.hip, profiles/): v_mfma_f64_16x16x4_f64 retires 1024 FMAs in
+//    65 cycles/SIMD (77 TFLOP/s), v_fma_f64 64 FMAs in 4.9; NO other VALU work overlaps with the fp64
+//    MFMA (SIMD time = MFMA cycles + VALU cycles).  What the matrix core buys is operand delivery:
+//    the shared table F is a lane-distributed B operand, not a wave-uniform scalar (a lane=item
+//    v_fma_f64 form fed by s_load spent 72 % of its wave cycles waiting on scalar-cache misses).
 //
-//    Tile: A = F (16 bin-rows x 4 k), B = Q^T (4 k x 16 items), K = MM (KS = ceil(MM/4) steps).
-//    A-operand rows are permuted on the host (build_FA) so that accumulator register r of lane
-//    l = (g = l>>4, c = l&15) is bin  bin0 + 4g + r  of item  item0 + 16*ti + c :
-//    every lane owns 4 CONSECUTIVE bins of one item -> one 16-B store, 64 B contiguous per item
-//    per store instruction, no LDS transpose.  A wave owns IT item-tiles (16*IT items) and a
-//    contiguous range of 16-bin tiles; its per-lane top-n lists (over the bins it sees, ascending)
-//    are merged across the 4 lanes of an item with wave shuffles, then across bin ranges by
-//    topn_merge_kernel.
+//    A wave owns 16 items and a contiguous range of 64-bin steps.  Per step: A = q (16 items x 4 k,
+//    held in registers for the whole range), B_t = F for 4 bin tiles t = 0..3 whose COLUMNS are
+//    permuted on the host (build_FB) so that tile t, column c is bin 64*step + 4c + t.  The fp64 MFMA
+//    accumulator layout (col = lane&15, row = (lane>>4) + 4*reg) then gives lane (g, c), register r,
+//    tile t  <->  item g + 4r, bin 64*step + 4c + t: a lane holds 4 CONSECUTIVE bins of one item in
+//    acc[0..3][r] -> one 16-B store, and the 16 lanes c = 0..15 of a row write 256 B contiguous.
+//    (A first version with rows = bins wrote 64-B pieces scattered over 16 item rows per instruction:
+//    ablation showed the store pattern and a branchy top-n, not the MFMAs, bound it -- DESIGN.md 5.)
+//
+//    FB streams from L2 (452 KiB at cfg2, shared by every wave).  An LDS-stationary slice per block and a
+//    per-row fp32 vote in front of the key network were both measured and dropped (no gain:
+//    profiles/r01_scan_v3_variants.txt, r01_scan_v3_ablation.txt).  ABL is a lab-only ablation mask
+//    (scripts/scan_lab.hip); product launches use ABL = 0.
 // =====================================================================================
-template <int NMAX>
-__device__ __forceinline__ void topn_merge_xor(double (&td)[NMAX], uint32_t (&tb)[NMAX], const int mask)
-{
-    double od[NMAX];
-    uint32_t ob[NMAX];
-#pragma unroll
-    for (int i = 0; i < NMAX; ++i) {
-        od[i] = __shfl_xor(td[i], mask, 64);
-        ob[i] = (uint32_t)__shfl_xor((int)tb[i], mask, 64);
-    }
-#pragma unroll
-    for (int i = 0; i < NMAX; ++i) topn_insert_lex<NMAX>(td, tb, od[i], ob[i]);
-}
-
-template <int M, int NMAX, int IT, bool SPEC, bool VEC4>
+template <int M, int NMAX, bool SPEC, bool VEC4, int ABL = 0>
 __global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict__ Qs,
-                                                         const double* __restrict__ FA,
+                                                         const double2* __restrict__ FB,
                                                          float* __restrict__ spec,
-                                                         float* __restrict__ ang,
-                                                         float* __restrict__ lvl,
-                                                         double* __restrict__ cand_d,
-                                                         uint32_t* __restrict__ cand_b,
-                                                         uint32_t batch, uint32_t res, uint32_t n,
-                                                         uint32_t qstride, uint32_t ntiles, uint32_t nsplit)
+                                                         double* __restrict__ cand,
+                                                         uint32_t batch, uint32_t res, uint32_t qstride,
+                                                         uint32_t nsteps, uint32_t nsplit, uint32_t ngroups,
+                                                         uint32_t keep_mask)
 {
     constexpr int MM = M * M;
     constexpr int KS = (MM + 3) / 4;        // MFMA k-steps
-    constexpr int ITEMS = 16 * IT;          // items per wave
+    constexpr int C2 = 2 * KS;              // double2 chunks per lane per step
 
     const int lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
-    const uint32_t wglob = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t igroup = wglob / nsplit;
-    const uint32_t split = wglob - igroup * nsplit;
-    const uint32_t item0 = igroup * ITEMS;
-    if (item0 >= batch) return;             // wave-uniform
-    const uint32_t t_begin = (uint32_t)(((uint64_t)ntiles * split) / nsplit);
-    const uint32_t t_end = (uint32_t)(((uint64_t)ntiles * (split + 1)) / nsplit);
 
-    // B operand: q[item0 + 16 ti + c][e = 4 s + g]   (zero for the K padding e >= MM)
-    double qb[IT][KS];
-#pragma unroll
-    for (int ti = 0; ti < IT; ++ti) {
-        const uint32_t it = item0 + 16 * ti + c;
+    // wave task = (16-item group, range of 64-bin steps); the 4 waves of a block take 4 consecutive groups
+    const uint32_t split = blockIdx.x % nsplit;
+    const uint32_t igroup = (blockIdx.x / nsplit) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (igroup >= ngroups) return;          // wave-uniform
+    const uint32_t st_begin = (uint32_t)(((uint64_t)nsteps * split) / nsplit);
+    const uint32_t st_end = (uint32_t)(((uint64_t)nsteps * (split + 1)) / nsplit);
+    const uint32_t item0 = igroup * 16;
+
+    // A operand: q[item0 + c][e = 4 s + g]   (zero for the K padding e >= MM)
+    double qa[KS];
+    {
+        const uint32_t it = item0 + c;
         const uint32_t itc = (it < batch) ? it : (batch - 1);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int e = 4 * s + g;
-            qb[ti][s] = (e < MM) ? Qs[(size_t)e * qstride + itc] : 0.0;
+            qa[s] = (e < MM) ? Qs[(size_t)e * qstride + itc] : 0.0;
         }
     }
 
-    double td[IT][NMAX];
-    uint32_t tb[IT][NMAX];
+    double key[4][NMAX];                    // per item row r = 0..3 (item g + 4r)
 #pragma unroll
-    for (int ti = 0; ti < IT; ++ti)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int i = 0; i < NMAX; ++i) { td[ti][i] = __builtin_huge_val(); tb[ti][i] = 0; }   // .cc:95
+        for (int i = 0; i < NMAX; ++i) key[r][i] = key_empty();
 
-    // A operand stream: FA[tile][lane][s] (KS doubles per lane per tile, contiguous per wave)
-    const double* __restrict__ fa = FA + ((size_t)t_begin * 64 + lane) * KS;
-    double a_cur[KS], a_nxt[KS];
-    if (t_begin < t_end) {
+    for (uint32_t st = st_begin; st < st_end; ++st) {
+        const double2* __restrict__ fp = FB + (size_t)st * C2 * 64 + lane;
+        v4f64 acc[4];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) a_cur[s] = fa[s];
-    }
+        for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const double2 f01 = fp[(2 * s) * 64];       // tiles (0,1) of k-step s
+            const double2 f23 = fp[(2 * s + 1) * 64];   // tiles (2,3)
+            if constexpr (ABL & 8) {   // lab only
+                acc[0][s & 3] += qa[s] * f01.x; acc[1][s & 3] += qa[s] * f01.y;
+                acc[2][s & 3] += qa[s] * f23.x; acc[3][s & 3] += qa[s] * f23.y;
+            } else {
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f01.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f01.y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f23.x, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f23.y, acc[3], 0, 0, 0);
+            }
+        }
 
-    for (uint32_t t = t_begin; t < t_end; ++t) {
-        fa += (size_t)64 * KS;
-        // FA carries one extra (NaN) tile at the end, so the prefetch past the last tile is in bounds
+        const uint32_t bin = st * 64 + 4 * c;   // this lane's first bin of the step
 #pragma unroll
-        for (int s = 0; s < KS; ++s) a_nxt[s] = fa[s];
-
-        v4f64 acc[IT];
-#pragma unroll
-        for (int ti = 0; ti < IT; ++ti) acc[ti] = (v4f64){0, 0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int ti = 0; ti < IT; ++ti)
-                acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[s], qb[ti][s], acc[ti], 0, 0, 0);
-
-        const uint32_t bin = t * 16 + 4 * g;          // this lane's first bin in the tile
-        bool hit = false;
-        double d[IT][4];
-#pragma unroll
-        for (int ti = 0; ti < IT; ++ti) {
+        for (int r = 0; r < 4; ++r) {
             float sv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                d[ti][r] = fabs(acc[ti][r]);          // ||G^H a||^2 >= 0; padding bins are NaN (never insert)
-                sv[r] = strength_f32(d[ti][r]);
-                hit |= d[ti][r] < td[ti][NMAX - 1];
+            for (int t = 0; t < 4; ++t) {
+                if constexpr (ABL & 4) sv[t] = __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint64_t, acc[t][r]));
+                else sv[t] = strength_f32(fabs(acc[t][r]));   // ||G^H a||^2 >= 0 in the reference
             }
-            if constexpr (SPEC) {
-                const uint32_t it = item0 + 16 * ti + c;
-                if constexpr (VEC4) {                 // res % 4 == 0: the 4 bins are all in or all out
-                    if (it < batch && bin < res)
-                        *reinterpret_cast<float4*>(&spec[(size_t)it * res + bin]) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+            if constexpr (ABL & 1) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(sv[t]));
+            }
+            if constexpr (SPEC && !(ABL & 1)) {
+                const uint32_t it = item0 + g + 4 * r;
+                if constexpr (VEC4) {      // res % 4 == 0: the 4 bins are all in or all out
+                    if (it < batch && bin < res) {
+                        const v4f32 v = {sv[0], sv[1], sv[2], sv[3]};
+                        *reinterpret_cast<v4f32*>(&spec[(size_t)it * res + bin]) = v;
+                    }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (it < batch && bin + r < res) spec[(size_t)it * res + bin + r] = sv[r];
+                    for (int t = 0; t < 4; ++t)
+                        if (it < batch && bin + t < res) spec[(size_t)it * res + bin + t] = sv[t];
                 }
             }
+            if constexpr (!(ABL & 2)) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) key_insert<NMAX>(key[r], make_key(acc[t][r], bin + t, keep_mask));
+            }
         }
-        if (__any(hit)) {
-#pragma unroll
-            for (int ti = 0; ti < IT; ++ti)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) topn_insert<NMAX>(td[ti], tb[ti], d[ti][r], bin + r);
-        }
-#pragma unroll
-        for (int s = 0; s < KS; ++s) a_cur[s] = a_nxt[s];
     }
 
-    // merge the 4 lanes (g = 0..3) that share an item, then emit
+    // merge the 16 lanes c = 0..15 that share an item row, then emit this range's candidates
 #pragma unroll
-    for (int ti = 0; ti < IT; ++ti) {
-        topn_merge_xor<NMAX>(td[ti], tb[ti], 16);
-        topn_merge_xor<NMAX>(td[ti], tb[ti], 32);
-        const uint32_t it = item0 + 16 * ti + c;
-        if (g == 0 && it < batch) {
-            if (nsplit == 1) {
+    for (int r = 0; r < 4; ++r) {
+        key_merge_xor<NMAX>(key[r], 1);
+        key_merge_xor<NMAX>(key[r], 2);
+        key_merge_xor<NMAX>(key[r], 4);
+        key_merge_xor<NMAX>(key[r], 8);
+        const uint32_t it = item0 + g + 4 * r;
+        if (c == 0 && it < batch) {
 #pragma unroll
-                for (int i = 0; i < NMAX; ++i)
-                    if (i < (int)n) {
-                        ang[(size_t)it * n + i] = (float)((double)tb[ti][i] * 360.0 / (double)res);   // .cc:134,152
-                        if (lvl) lvl[(size_t)it * n + i] = strength_f32(td[ti][i]);                    // .cc:153
-                    }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NMAX; ++i) {
-                    cand_d[((size_t)it * nsplit + split) * NMAX + i] = td[ti][i];
-                    cand_b[((size_t)it * nsplit + split) * NMAX + i] = tb[ti][i];
-                }
-            }
+            for (int i = 0; i < NMAX; ++i) cand[((size_t)it * nsplit + split) * NMAX + i] = key[r][i];
         }
     }
 }
 
-// Final top-n over the per-bin-range candidate lists (one thread per item).
+// Final top-n over the per-range candidate keys (one thread per item), ang / lvl outputs
+// (lib/baz_music_doa.cc:129-155).  lvl[i] is read back from the spectrum this launch sequence just
+// wrote when port 2 is wired, so that lvl[i] == spectrum[bin_i] holds bit for bit as in the reference.
 template <int NMAX>
-__global__ __launch_bounds__(256) void topn_merge_kernel(const double* __restrict__ cand_d,
-                                                          const uint32_t* __restrict__ cand_b,
+__global__ __launch_bounds__(256) void topn_merge_kernel(const double* __restrict__ cand,
+                                                          const float* __restrict__ spec,
                                                           float* __restrict__ ang, float* __restrict__ lvl,
-                                                          uint32_t batch, uint32_t res, uint32_t n, uint32_t nsplit)
+                                                          uint32_t batch, uint32_t res, uint32_t n, uint32_t nsplit,
+                                                          uint32_t keep_mask)
 {
     const uint32_t it = blockIdx.x * 256 + threadIdx.x;
     if (it >= batch) return;
-    double fd[NMAX];
-    uint32_t fb[NMAX];
+    double key[NMAX];
 #pragma unroll
-    for (int i = 0; i < NMAX; ++i) { fd[i] = __builtin_huge_val(); fb[i] = 0; }
+    for (int i = 0; i < NMAX; ++i) key[i] = key_empty();
     const size_t base = (size_t)it * nsplit * NMAX;
-    for (uint32_t k = 0; k < nsplit * NMAX; ++k) {
-        const double d = cand_d[base + k];
-        const uint32_t b = cand_b[base + k];
-        if (d < __builtin_huge_val()) topn_insert_lex<NMAX>(fd, fb, d, b);
-    }
+    for (uint32_t k = 0; k < nsplit * NMAX; ++k) key_insert<NMAX>(key, cand[base + k]);
 #pragma unroll
     for (int i = 0; i < NMAX; ++i)
         if (i < (int)n) {
-            ang[(size_t)it * n + i] = (float)((double)fb[i] * 360.0 / (double)res);   // .cc:134,152
-            if (lvl) lvl[(size_t)it * n + i] = strength_f32(fd[i]);                    // .cc:153
+            const uint64_t b = __builtin_bit_cast(uint64_t, key[i]);
+            const uint32_t bin = (uint32_t)b & ~keep_mask;
+            const bool used = (b < (uint64_t)BAZ_KEY_EMPTY_BITS) && (bin < res);
+            float a = 0.0f, l = 0.0f;                                          // (0, 0): .cc:95
+            if (used) {
+                a = (float)((double)bin * 360.0 / (double)res);                // .cc:134,152
+                if (spec) l = spec[(size_t)it * res + bin];                    // .cc:153 (== spectrum[bin])
+                else l = strength_f32(__builtin_bit_cast(double, b & ~(uint64_t)(~keep_mask)));
+            }
+            ang[(size_t)it * n + i] = a;
+            if (lvl) lvl[(size_t)it * n + i] = l;
         }
 }
 

@@ -54,7 +54,8 @@ enum {
 #define BAZ_MUSIC_MAX_N 16u       /* top-n list length handled on device (n < m anyway) */
 
 /* Stage indices for baz_music_stage_ms / baz_music_stage_name. */
-enum { BAZ_MUSIC_STAGE_COV = 0, BAZ_MUSIC_STAGE_EVD = 1, BAZ_MUSIC_STAGE_SCAN = 2, BAZ_MUSIC_NUM_STAGES = 3 };
+enum { BAZ_MUSIC_STAGE_COV = 0, BAZ_MUSIC_STAGE_EVD = 1, BAZ_MUSIC_STAGE_SCAN = 2, BAZ_MUSIC_STAGE_MERGE = 3,
+       BAZ_MUSIC_NUM_STAGES = 4 };
 
 /* Replaces baz_music_doa::baz_music_doa (lib/baz_music_doa.cc:35-53).  Validates what the
  * reference only assert()s: m>0, 0<n<m (n==m underflows .cc:93), nsamples>0, nsamples%m==0,

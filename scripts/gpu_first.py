@@ -73,7 +73,7 @@ def timing(name, B, iters=10, spec_on=True):
     bpi = ctx.bytes_per_item(spec_on)
     print("%s B=%d spec=%s: %.3f ms/step  %.3e items/s  %.2f TB/s algorithmic (%.1f%% of 8 TB/s)" % (
         name, B, spec_on, dt * 1e3, B / dt, B / dt * bpi / 1e12, B / dt * bpi / 8e12 * 100), flush=True)
-    for s in range(3):
+    for s in range(4):
         ms, cnt = ctx.stage_ms(s)
         print("   stage %d %-32s %.3f ms/launch (%d launches)" % (s, ctx.stage_name(s), ms / max(cnt, 1), cnt), flush=True)
     ctx.close()

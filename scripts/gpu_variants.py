@@ -1,4 +1,5 @@
-"""A/B timing of scan-kernel variants (BAZ_MUSIC_SCAN_VARIANT) on the GPU box + parity spot check."""
+"""Per-stage timing on the GPU box + parity spot check (argv: label list, batch, cfg).  The label used to
+select BAZ_MUSIC_SCAN_VARIANT builds while the scan kernel was being tuned; it is now just a tag."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -37,7 +38,7 @@ for r in range(rounds):   # interleaved rounds
         ctx.profile(True)
         for _ in range(5): ctx.process_device(x.data_ptr(), B, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr())
         ctx.sync()
-        ms = [ctx.stage_ms(s)[0] / 5 for s in range(3)]
+        ms = [ctx.stage_ms(s)[0] / 5 for s in range(4)]
         ctx.profile(False)
         results[v].append(ms)
 for v in variants:
