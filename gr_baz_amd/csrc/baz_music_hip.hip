@@ -48,13 +48,19 @@ struct baz_music_ctx {
     double2* dR = nullptr;
     double* dQ = nullptr;
     uint32_t cap = 0;   // items
-    // host-path staging (device side)
-    float* s_in = nullptr;
-    float* s_ang = nullptr;
-    float* s_lvl = nullptr;
-    float* s_spec = nullptr;
+    // host-fed path (baz_music_process): two device-side slots so that the H2D copy of chunk i+1, the kernels
+    // of chunk i and the D2H copy of chunk i-1 overlap on three streams
+    struct Slot {
+        float* in = nullptr;
+        float* ang = nullptr;
+        float* lvl = nullptr;
+        float* spec = nullptr;
+        hipEvent_t h2d = nullptr, comp = nullptr, d2h = nullptr;
+        bool busy = false;
+    } slot[2];
     uint32_t s_cap = 0;
     bool s_has_spec = false;
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     std::mutex mtx;   // serialises set_table against process*, like d_mutex (.cc:67,101)
     bool profiling = false;
     StageProf prof[BAZ_MUSIC_NUM_STAGES];
@@ -200,28 +206,34 @@ void prof_collect(baz_music_ctx* c)
 template <int M>
 int launch_cov_t(baz_music_ctx* c, const float* d_in, uint32_t batch, double2* dR)
 {
-    constexpr int IPT = 16 / (2 * M);
-    const uint32_t ntiles = (batch + IPT - 1) / IPT;
-    uint32_t blocks = (ntiles + 3) / 4;
-    blocks = std::min<uint32_t>(blocks, 256u * 32u);
-    hipLaunchKernelGGL((cov_mfma_kernel<M>), dim3(blocks), dim3(256), 0, c->stream, d_in, dR, batch, c->K);
+    if constexpr (M <= 8) {    // one 16x16 Gram tile holds 16/(2m) items
+        constexpr int IPT = 16 / (2 * M);
+        const uint32_t ntiles = (batch + IPT - 1) / IPT;
+        const uint32_t blocks = std::min<uint32_t>((ntiles + 3) / 4, 256u * 32u);
+        hipLaunchKernelGGL((cov_mfma_kernel<M>), dim3(blocks), dim3(256), 0, c->stream, d_in, dR, batch, c->K);
+    } else {                   // 2x2 tiles per item
+        const uint32_t blocks = std::min<uint32_t>((batch + 3) / 4, 256u * 32u);
+        hipLaunchKernelGGL((cov_mfma2_kernel<M>), dim3(blocks), dim3(256), 0, c->stream, d_in, dR, batch, c->K);
+    }
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
 }
 
+#define BAZ_M_CASES(CALL)                                                                          \
+    case 2: return CALL(2); case 3: return CALL(3); case 4: return CALL(4); case 5: return CALL(5); \
+    case 6: return CALL(6); case 7: return CALL(7); case 8: return CALL(8); case 9: return CALL(9); \
+    case 10: return CALL(10); case 11: return CALL(11); case 12: return CALL(12); case 13: return CALL(13); \
+    case 14: return CALL(14); case 15: return CALL(15); case 16: return CALL(16);
+
 int launch_cov(baz_music_ctx* c, const float* d_in, uint32_t batch, double2* dR)
 {
     ProfScope ps(c, BAZ_MUSIC_STAGE_COV);
+#define BAZ_CALL(MV) launch_cov_t<MV>(c, d_in, batch, dR)
     switch (c->m) {
-        case 2: return launch_cov_t<2>(c, d_in, batch, dR);
-        case 3: return launch_cov_t<3>(c, d_in, batch, dR);
-        case 4: return launch_cov_t<4>(c, d_in, batch, dR);
-        case 5: return launch_cov_t<5>(c, d_in, batch, dR);
-        case 6: return launch_cov_t<6>(c, d_in, batch, dR);
-        case 7: return launch_cov_t<7>(c, d_in, batch, dR);
-        case 8: return launch_cov_t<8>(c, d_in, batch, dR);
+        BAZ_M_CASES(BAZ_CALL)
         default: return BAZ_MUSIC_E_UNSUPPORTED;
     }
+#undef BAZ_CALL
 }
 
 template <int M>
@@ -242,16 +254,12 @@ int launch_evd_t(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ
 int launch_evd(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ, uint32_t qstride)
 {
     ProfScope ps(c, BAZ_MUSIC_STAGE_EVD);
+#define BAZ_CALL(MV) launch_evd_t<MV>(c, dR, batch, dQ, qstride)
     switch (c->m) {
-        case 2: return launch_evd_t<2>(c, dR, batch, dQ, qstride);
-        case 3: return launch_evd_t<3>(c, dR, batch, dQ, qstride);
-        case 4: return launch_evd_t<4>(c, dR, batch, dQ, qstride);
-        case 5: return launch_evd_t<5>(c, dR, batch, dQ, qstride);
-        case 6: return launch_evd_t<6>(c, dR, batch, dQ, qstride);
-        case 7: return launch_evd_t<7>(c, dR, batch, dQ, qstride);
-        case 8: return launch_evd_t<8>(c, dR, batch, dQ, qstride);
+        BAZ_M_CASES(BAZ_CALL)
         default: return BAZ_MUSIC_E_UNSUPPORTED;
     }
+#undef BAZ_CALL
 }
 
 // Launch geometry of the scan: (16-item groups) x (`nsplit` ranges of 64-bin steps), chosen so that a launch
@@ -318,14 +326,19 @@ int launch_scan_m(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
 {
     if (c->n <= 2) return launch_scan_t<M, 2>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec);
     if (c->n <= 4) return launch_scan_t<M, 4>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec);
-    return launch_scan_t<M, 8>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec);
+    if constexpr (M > 5) {
+        if (c->n <= 8) return launch_scan_t<M, 8>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec);
+    }
+    if constexpr (M > 9) return launch_scan_t<M, 16>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec);
+    return BAZ_MUSIC_E_UNSUPPORTED;   // unreachable: n < m
 }
+
+uint32_t topn_list_len(uint32_t n) { return n <= 2 ? 2u : (n <= 4 ? 4u : (n <= 8 ? 8u : 16u)); }
 
 // candidate keys one scan launch over `nb` items produces (mirrors launch_scan_t's geometry)
 size_t cand_entries(const baz_music_ctx* c, uint32_t nb)
 {
-    const uint32_t nmax = c->n <= 2 ? 2u : (c->n <= 4 ? 4u : 8u);
-    return (size_t)nb * scan_geometry(nb, c->fb_steps).nsplit * nmax;
+    return (size_t)nb * scan_geometry(nb, c->fb_steps).nsplit * topn_list_len(c->n);
 }
 
 int reserve_candidates(baz_music_ctx* c, uint32_t batch)
@@ -336,25 +349,24 @@ int reserve_candidates(baz_music_ctx* c, uint32_t batch)
 int launch_merge(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl, float* d_spec)
 {
     ProfScope ps(c, BAZ_MUSIC_STAGE_MERGE);
-    if (c->n <= 2) return launch_merge_t<2>(c, batch, d_ang, d_lvl, d_spec);
-    if (c->n <= 4) return launch_merge_t<4>(c, batch, d_ang, d_lvl, d_spec);
-    return launch_merge_t<8>(c, batch, d_ang, d_lvl, d_spec);
+    switch (topn_list_len(c->n)) {
+        case 2: return launch_merge_t<2>(c, batch, d_ang, d_lvl, d_spec);
+        case 4: return launch_merge_t<4>(c, batch, d_ang, d_lvl, d_spec);
+        case 8: return launch_merge_t<8>(c, batch, d_ang, d_lvl, d_spec);
+        default: return launch_merge_t<16>(c, batch, d_ang, d_lvl, d_spec);
+    }
 }
 
 int launch_scan(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t batch, float* d_ang,
                 float* d_lvl, float* d_spec)
 {
     ProfScope ps(c, BAZ_MUSIC_STAGE_SCAN);
+#define BAZ_CALL(MV) launch_scan_m<MV>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec)
     switch (c->m) {
-        case 2: return launch_scan_m<2>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec);
-        case 3: return launch_scan_m<3>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec);
-        case 4: return launch_scan_m<4>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec);
-        case 5: return launch_scan_m<5>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec);
-        case 6: return launch_scan_m<6>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec);
-        case 7: return launch_scan_m<7>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec);
-        case 8: return launch_scan_m<8>(c, dQ, qstride, batch, d_ang, d_lvl, d_spec);
+        BAZ_M_CASES(BAZ_CALL)
         default: return BAZ_MUSIC_E_UNSUPPORTED;
     }
+#undef BAZ_CALL
 }
 
 int upload_table(baz_music_ctx* c, const float* table_ri)
@@ -365,6 +377,45 @@ int upload_table(baz_music_ctx* c, const float* table_ri)
     build_FB(F, c->m, c->res, c->fb_steps, FB);
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // no batch in flight reads the old table
     HIP_TRY(c, hipMemcpy(c->dFB, FB.data(), FB.size() * sizeof(double), hipMemcpyHostToDevice));
+    return BAZ_MUSIC_OK;
+}
+
+void free_slots(baz_music_ctx* c)
+{
+    for (auto& sl : c->slot) {
+        if (sl.in) (void)hipFree(sl.in);
+        if (sl.ang) (void)hipFree(sl.ang);
+        if (sl.lvl) (void)hipFree(sl.lvl);
+        if (sl.spec) (void)hipFree(sl.spec);
+        if (sl.h2d) (void)hipEventDestroy(sl.h2d);
+        if (sl.comp) (void)hipEventDestroy(sl.comp);
+        if (sl.d2h) (void)hipEventDestroy(sl.d2h);
+        sl = baz_music_ctx::Slot();
+    }
+    c->s_cap = 0;
+    c->s_has_spec = false;
+}
+
+int ensure_slots(baz_music_ctx* c, uint32_t chunk, bool want_spec)
+{
+    if (chunk <= c->s_cap && (!want_spec || c->s_has_spec)) return BAZ_MUSIC_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const bool spec = want_spec || c->s_has_spec;
+    const uint32_t cap = std::max(chunk, c->s_cap);
+    free_slots(c);
+    if (!c->s_h2d) HIP_TRY(c, hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
+    if (!c->s_d2h) HIP_TRY(c, hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
+    for (auto& sl : c->slot) {
+        HIP_TRY(c, hipMalloc((void**)&sl.in, (size_t)cap * c->nsamples * 8));
+        HIP_TRY(c, hipMalloc((void**)&sl.ang, (size_t)cap * c->n * 4));
+        HIP_TRY(c, hipMalloc((void**)&sl.lvl, (size_t)cap * c->n * 4));
+        if (spec) HIP_TRY(c, hipMalloc((void**)&sl.spec, (size_t)cap * c->res * 4));
+        HIP_TRY(c, hipEventCreateWithFlags(&sl.h2d, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&sl.comp, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&sl.d2h, hipEventDisableTiming));
+    }
+    c->s_cap = cap;
+    c->s_has_spec = spec;
     return BAZ_MUSIC_OK;
 }
 
@@ -437,13 +488,13 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         return r;
     }
     char buf[128];
-    snprintf(buf, sizeof(buf), "bazmusic::cov_mfma_kernel<%u>", m);
+    snprintf(buf, sizeof(buf), m <= 8 ? "bazmusic::cov_mfma_kernel<%u>" : "bazmusic::cov_mfma2_kernel<%u>", m);
     c->stage_name[BAZ_MUSIC_STAGE_COV] = buf;
     snprintf(buf, sizeof(buf), m <= 4 ? "bazmusic::evd_proj_kernel<%u>" : "bazmusic::evd_proj_lds_kernel<%u>", m);
     c->stage_name[BAZ_MUSIC_STAGE_EVD] = buf;
     snprintf(buf, sizeof(buf), "bazmusic::scan_mfma_kernel<%u,", m);
     c->stage_name[BAZ_MUSIC_STAGE_SCAN] = buf;
-    snprintf(buf, sizeof(buf), "bazmusic::topn_merge_kernel<%u>", n <= 2 ? 2u : (n <= 4 ? 4u : 8u));
+    snprintf(buf, sizeof(buf), "bazmusic::topn_merge_kernel<%u>", topn_list_len(n));
     c->stage_name[BAZ_MUSIC_STAGE_MERGE] = buf;
     *out = c;
     return BAZ_MUSIC_OK;
@@ -461,10 +512,9 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->dCand) (void)hipFree(c->dCand);
         if (c->dR) (void)hipFree(c->dR);
         if (c->dQ) (void)hipFree(c->dQ);
-        if (c->s_in) (void)hipFree(c->s_in);
-        if (c->s_ang) (void)hipFree(c->s_ang);
-        if (c->s_lvl) (void)hipFree(c->s_lvl);
-        if (c->s_spec) (void)hipFree(c->s_spec);
+        free_slots(c);
+        if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
+        if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     }
     delete c;
@@ -526,43 +576,49 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
 
-    // chunk so that device staging stays below ~512 MiB
+    // chunks of <= ~64 MiB of traffic each: big enough to amortise launches, small enough to overlap
     const size_t per_item = (size_t)c->nsamples * 8 + (size_t)c->res * 4 + (size_t)c->n * 8;
-    uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(batch, (512u << 20) / per_item));
+    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(batch, (64u << 20) / per_item));
     const bool want_spec = spectrum != nullptr;
-    if (chunk > c->s_cap || (want_spec && !c->s_has_spec)) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->s_in) (void)hipFree(c->s_in);
-        if (c->s_ang) (void)hipFree(c->s_ang);
-        if (c->s_lvl) (void)hipFree(c->s_lvl);
-        if (c->s_spec) (void)hipFree(c->s_spec);
-        c->s_in = c->s_ang = c->s_lvl = c->s_spec = nullptr;
-        c->s_cap = 0;
-        const uint32_t cap = std::max(chunk, c->s_cap);
-        HIP_TRY(c, hipMalloc((void**)&c->s_in, (size_t)cap * c->nsamples * 8));
-        HIP_TRY(c, hipMalloc((void**)&c->s_ang, (size_t)cap * c->n * 4));
-        HIP_TRY(c, hipMalloc((void**)&c->s_lvl, (size_t)cap * c->n * 4));
-        if (want_spec || c->s_has_spec) {
-            HIP_TRY(c, hipMalloc((void**)&c->s_spec, (size_t)cap * c->res * 4));
-            c->s_has_spec = true;
-        }
-        c->s_cap = cap;
-    }
-    for (uint32_t done = 0; done < batch; done += chunk) {
+    int r = ensure_slots(c, chunk, want_spec);
+    if (r) return r;
+    r = ensure_workspace(c, chunk);
+    if (r) return r;
+    r = reserve_candidates(c, chunk);
+    if (r) return r;
+
+    int rc = BAZ_MUSIC_OK;
+    uint32_t idx = 0;
+    for (uint32_t done = 0; done < batch && rc == BAZ_MUSIC_OK; done += chunk, ++idx) {
+        baz_music_ctx::Slot& sl = c->slot[idx & 1];
         const uint32_t nb = std::min(chunk, batch - done);
-        HIP_TRY(c, hipMemcpyAsync(c->s_in, in_ri + (size_t)done * c->nsamples * 2, (size_t)nb * c->nsamples * 8,
-                                  hipMemcpyHostToDevice, c->stream));
-        int r = process_device_locked(c, c->s_in, nb, c->s_ang, c->s_lvl, want_spec ? c->s_spec : nullptr);
-        if (r) return r;
-        HIP_TRY(c, hipMemcpyAsync(ang + (size_t)done * c->n, c->s_ang, (size_t)nb * c->n * 4, hipMemcpyDeviceToHost, c->stream));
+        if (sl.busy) {   // chunk idx-2 used this slot: its outputs must be on the host before we reuse it
+            HIP_TRY(c, hipEventSynchronize(sl.d2h));
+            sl.busy = false;
+        }
+        HIP_TRY(c, hipMemcpyAsync(sl.in, in_ri + (size_t)done * c->nsamples * 2, (size_t)nb * c->nsamples * 8,
+                                  hipMemcpyHostToDevice, c->s_h2d));
+        HIP_TRY(c, hipEventRecord(sl.h2d, c->s_h2d));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.h2d, 0));
+        rc = process_device_locked(c, sl.in, nb, sl.ang, sl.lvl, want_spec ? sl.spec : nullptr);
+        if (rc) break;
+        HIP_TRY(c, hipEventRecord(sl.comp, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->s_d2h, sl.comp, 0));
+        HIP_TRY(c, hipMemcpyAsync(ang + (size_t)done * c->n, sl.ang, (size_t)nb * c->n * 4, hipMemcpyDeviceToHost, c->s_d2h));
         if (lvl)
-            HIP_TRY(c, hipMemcpyAsync(lvl + (size_t)done * c->n, c->s_lvl, (size_t)nb * c->n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(lvl + (size_t)done * c->n, sl.lvl, (size_t)nb * c->n * 4, hipMemcpyDeviceToHost, c->s_d2h));
         if (want_spec)
-            HIP_TRY(c, hipMemcpyAsync(spectrum + (size_t)done * c->res, c->s_spec, (size_t)nb * c->res * 4,
-                                      hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipMemcpyAsync(spectrum + (size_t)done * c->res, sl.spec, (size_t)nb * c->res * 4,
+                                      hipMemcpyDeviceToHost, c->s_d2h));
+        HIP_TRY(c, hipEventRecord(sl.d2h, c->s_d2h));
+        sl.busy = true;
     }
-    return (int)batch;
+    // drain (also on the error path) so that no copy still targets the caller's buffers
+    (void)hipStreamSynchronize(c->s_h2d);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->s_d2h);
+    c->slot[0].busy = c->slot[1].busy = false;
+    return rc ? rc : (int)batch;
 }
 
 int baz_music_profile(baz_music_ctx* c, int enable)

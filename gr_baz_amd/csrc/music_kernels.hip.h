@@ -68,10 +68,12 @@ __global__ __launch_bounds__(256) void cov_mfma_kernel(const float* __restrict__
     double* g = gram[wave];
 
     for (uint32_t tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-        const uint32_t item = tile * IPT + sub;
+        constexpr bool PAD = (16 % ROWS) != 0;       // tile rows beyond IPT*ROWS carry no item (m = 3, 5, 6, 7)
+        const uint32_t item = tile * IPT + (PAD ? ((sub < IPT) ? sub : 0) : sub);
         const bool live = (sub < IPT) && (item < batch);
-        const float* p = in + (size_t)(live ? item : 0) * item_floats + kk * ROWS + row;
-        const float keep = live ? 1.0f : 0.0f;
+        // batch tail: a missing item re-reads the last one; its Gram block is simply not written back
+        const float* p = in + (size_t)((item < batch) ? item : (batch - 1)) * item_floats + kk * ROWS + row;
+        const float keep = (!PAD || sub < IPT) ? 1.0f : 0.0f;
         v4f64 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 
         if (fast) {
@@ -88,7 +90,8 @@ __global__ __launch_bounds__(256) void cov_mfma_kernel(const float* __restrict__
                 }
 #pragma unroll
                 for (int u = 0; u < CH; u += 2) {
-                    const double a0 = (double)(va[u] * keep), a1 = (double)(va[u + 1] * keep);
+                    const double a0 = PAD ? (double)(va[u] * keep) : (double)va[u];
+                    const double a1 = PAD ? (double)(va[u + 1] * keep) : (double)va[u + 1];
                     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
                 }
@@ -99,7 +102,8 @@ __global__ __launch_bounds__(256) void cov_mfma_kernel(const float* __restrict__
                     }
 #pragma unroll
                     for (int u = 0; u < CH; u += 2) {
-                        const double a0 = (double)(vb[u] * keep), a1 = (double)(vb[u + 1] * keep);
+                        const double a0 = PAD ? (double)(vb[u] * keep) : (double)vb[u];
+                        const double a1 = PAD ? (double)(vb[u + 1] * keep) : (double)vb[u + 1];
                         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
                     }
@@ -129,6 +133,84 @@ __global__ __launch_bounds__(256) void cov_mfma_kernel(const float* __restrict__
             const double im = g[(base + 2 * a + 1) * 17 + base + 2 * b] - g[(base + 2 * a) * 17 + base + 2 * b + 1];
             const uint32_t it2 = tile * IPT + s2;
             if (it2 < batch) R[(size_t)it2 * MM + ab] = make_double2(re / dK, im / dK);   // .cc:85 "/ (double)average_over"
+        }
+        wave_lds_fence();
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// 1b. The same covariance for 9 <= m <= 16: the realified item has 2m = 18..32 rows = two 16-row tiles
+//     X0 (rows 0..15) and X1 (rows 16..31, zero beyond 2m).  Gram blocks G00 = X0 X0^T, G11 = X1 X1^T and
+//     G10 = X1 X0^T (G01 is its transpose): three MFMAs per k-step from two fp32 loads per lane.
+// -------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(256) void cov_mfma2_kernel(const float* __restrict__ in,
+                                                         double2* __restrict__ R,
+                                                         uint32_t batch, uint32_t K)
+{
+    constexpr int ROWS = 2 * M;
+    constexpr int MM = M * M;
+    constexpr int CH = 16;
+    static_assert(ROWS > 16 && ROWS <= 32, "two-tile covariance handles 9 <= m <= 16");
+    __shared__ double gram[4][32 * 33];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15;
+    const int kk = lane >> 4;
+    const bool hi_row = (16 + i) < ROWS;          // row 16+i exists
+    const size_t item_floats = (size_t)K * ROWS;
+    const uint32_t steps = (K + 3) >> 2;
+    const bool fast = (K % (4 * CH)) == 0;
+    double* g = gram[wave];
+
+    for (uint32_t item = blockIdx.x * 4 + wave; item < batch; item += gridDim.x * 4) {
+        const float* p0 = in + (size_t)item * item_floats + kk * ROWS + i;
+        const float* p1 = p0 + (hi_row ? 16 : 0);
+        const float keep1 = hi_row ? 1.0f : 0.0f;
+        v4f64 a00 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0};
+        if (fast) {
+            for (uint32_t t = 0; t < steps; t += CH) {
+                float v0[CH], v1[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    v0[u] = p0[(size_t)(t + u) * (4 * ROWS)];
+                    v1[u] = p1[(size_t)(t + u) * (4 * ROWS)];
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const double x0 = (double)v0[u], x1 = (double)(v1[u] * keep1);
+                    a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, a00, 0, 0, 0);
+                    a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, a11, 0, 0, 0);
+                    a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, a10, 0, 0, 0);
+                }
+            }
+        } else {
+            for (uint32_t t = 0; t < steps; ++t) {
+                const bool ok = (4 * t + kk) < K;
+                const double x0 = ok ? (double)p0[(size_t)t * (4 * ROWS)] : 0.0;
+                const double x1 = (ok && hi_row) ? (double)p1[(size_t)t * (4 * ROWS)] : 0.0;
+                a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, a00, 0, 0, 0);
+                a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, a11, 0, 0, 0);
+                a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, a10, 0, 0, 0);
+            }
+        }
+        // D layout: col = lane&15 (i), row = kk + 4r.   G10[row][col] = sum X1[row] X0[col]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = kk + 4 * r;
+            g[row * 33 + i] = a00[r];
+            g[(16 + row) * 33 + 16 + i] = a11[r];
+            g[(16 + row) * 33 + i] = a10[r];
+            g[i * 33 + 16 + row] = a10[r];         // G01 = G10^T
+        }
+        wave_lds_fence();
+        const double dK = (double)K;
+        for (int e = lane; e < MM; e += 64) {
+            const int a = e / M, b = e - a * M;
+            const double re = g[(2 * a) * 33 + 2 * b] + g[(2 * a + 1) * 33 + 2 * b + 1];
+            const double im = g[(2 * a + 1) * 33 + 2 * b] - g[(2 * a) * 33 + 2 * b + 1];
+            R[(size_t)item * MM + e] = make_double2(re / dK, im / dK);   // .cc:85
         }
         wave_lds_fence();
     }
@@ -487,12 +569,13 @@ __device__ __forceinline__ double vmax64(double a, double b)
     return r;
 }
 
+// key of a freshly computed d: only the low word is touched (one v_and_or_b32); the sign of d (rounding noise
+// around 0) is dropped by the |.| source modifier of the first network operation in key_insert_new().
 __device__ __forceinline__ double make_key(const double d, const uint32_t bin, const uint32_t keep_mask)
 {
     const uint64_t b = __builtin_bit_cast(uint64_t, d);
-    const uint32_t hi = (uint32_t)(b >> 32) & 0x7FFFFFFFu;          // |d|
     const uint32_t lo = ((uint32_t)b & keep_mask) | bin;
-    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+    return __builtin_bit_cast(double, (b & 0xFFFFFFFF00000000ull) | lo);
 }
 
 template <int NMAX>
@@ -503,6 +586,25 @@ __device__ __forceinline__ void key_insert(double (&t)[NMAX], double k)
         const double lo = vmin64(k, t[i]);
         if (i + 1 < NMAX) k = vmax64(k, t[i]);
         t[i] = lo;
+    }
+}
+
+// same, for a key that may still carry a sign bit: |k| is applied inside the first min/max pair
+template <int NMAX>
+__device__ __forceinline__ void key_insert_new(double (&t)[NMAX], double k)
+{
+    double lo, hi = 0.0;
+    asm("v_min_f64 %0, |%1|, %2" : "=v"(lo) : "v"(k), "v"(t[0]));
+    if constexpr (NMAX > 1) asm("v_max_f64 %0, |%1|, %2" : "=v"(hi) : "v"(k), "v"(t[0]));
+    t[0] = lo;
+    if constexpr (NMAX > 1) {
+        k = hi;
+#pragma unroll
+        for (int i = 1; i < NMAX; ++i) {
+            const double l2 = vmin64(k, t[i]);
+            if (i + 1 < NMAX) k = vmax64(k, t[i]);
+            t[i] = l2;
+        }
     }
 }
 
@@ -636,7 +738,7 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict
             }
             if constexpr (!(ABL & 2)) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) key_insert<NMAX>(key[r], make_key(acc[t][r], bin + t, keep_mask));
+                for (int t = 0; t < 4; ++t) key_insert_new<NMAX>(key[r], make_key(acc[t][r], bin + t, keep_mask));
             }
         }
     }

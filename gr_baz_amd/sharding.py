@@ -35,20 +35,34 @@ def init_process_group(use_gpu: bool, local_rank: int = 0):
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        global _BACKEND
+        backend = "gloo"
         if use_gpu:
             import torch
             torch.cuda.set_device(local_rank)
+            if os.environ.get("BAZ_BENCH_BACKEND", "nccl") == "nccl":
+                backend = "nccl"      # = RCCL on ROCm; used for the barrier / clock only
+        if backend == "nccl":
+            import torch
             dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        _BACKEND = backend
     return True
+
+
+_BACKEND = "gloo"
+
+
+def _on_gpu(use_gpu: bool) -> bool:
+    return use_gpu and _BACKEND == "nccl"
 
 
 def barrier(active: bool, use_gpu: bool):
     if active:
         import torch.distributed as dist
-        if use_gpu:
+        if _on_gpu(use_gpu):
             import torch
             dist.barrier(device_ids=[torch.cuda.current_device()])
         else:
@@ -60,7 +74,7 @@ def max_over_ranks(value: float, active: bool, use_gpu: bool) -> float:
         return value
     import torch
     import torch.distributed as dist
-    t = torch.tensor([value], dtype=torch.float64, device="cuda" if use_gpu else "cpu")
+    t = torch.tensor([value], dtype=torch.float64, device="cuda" if _on_gpu(use_gpu) else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -70,7 +84,7 @@ def sum_over_ranks(value: float, active: bool, use_gpu: bool) -> float:
         return value
     import torch
     import torch.distributed as dist
-    t = torch.tensor([value], dtype=torch.float64, device="cuda" if use_gpu else "cpu")
+    t = torch.tensor([value], dtype=torch.float64, device="cuda" if _on_gpu(use_gpu) else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 

@@ -50,8 +50,8 @@ enum {
     BAZ_MUSIC_E_NODEVICE = -5     /* no gfx950 device / device_id out of range */
 };
 
-#define BAZ_MUSIC_MAX_M 8u        /* antennas handled by the register-resident kernels */
-#define BAZ_MUSIC_MAX_N 16u       /* top-n list length handled on device (n < m anyway) */
+#define BAZ_MUSIC_MAX_M 16u       /* antennas handled by the gfx950 kernels (config 5 uses 16) */
+#define BAZ_MUSIC_MAX_N 15u       /* expected emitters (n < m) */
 
 /* Stage indices for baz_music_stage_ms / baz_music_stage_name. */
 enum { BAZ_MUSIC_STAGE_COV = 0, BAZ_MUSIC_STAGE_EVD = 1, BAZ_MUSIC_STAGE_SCAN = 2, BAZ_MUSIC_STAGE_MERGE = 3,

@@ -66,6 +66,12 @@ def main():
     fixture("m6_n2_N1536_r1440", 6, 2, 1536, 1440, mo.array_geometry(6), 3, 20.0, 2008)
     fixture("m7_n4_N700_r500", 7, 4, 700, 500, mo.array_geometry(7), 3, 30.0, 2009,
             angles=(33.0, 111.0, 199.0, 287.0))
+    # 9 <= m <= 16: two-tile covariance, LDS EVD, K = m*m up to 256 scan; BASELINE config 5 shape (m16, N4096, res3600)
+    fixture("cfg5_m16_n2_N4096_r3600", 16, 2, 4096, 3600, mo.array_geometry(16), 2, 20.0, 1005)
+    fixture("m12_n9_N1200_r720", 12, 9, 1200, 720, mo.array_geometry(12), 2, 30.0, 2010,
+            angles=(10.0, 50.0, 90.0, 130.0, 170.0, 210.0, 250.0, 290.0, 330.0))
+    fixture("m10_n3_N1000_r1001", 10, 3, 1000, 1001, mo.array_geometry(10), 3, 20.0, 2011, angles=(70.0, 190.0, 300.5))
+    fixture("m9_n1_N630_r250", 9, 1, 630, 250, mo.array_geometry(9), 3, 15.0, 2012, angles=(222.0,))
 
 
 if __name__ == "__main__":

@@ -113,6 +113,10 @@ def test_stage_taps_covariance_and_projector(gpu_device):
     (7, 3, 7 * 37, 77, 48),
     (8, 7, 8 * 20, 1024, 20),   # n = 7 on the 8-antenna path
     (8, 1, 8 * 1000, 90, 5),    # long integration, short table
+    (9, 4, 9 * 50, 333, 21),    # two-tile covariance with padding rows (2m = 18)
+    (13, 12, 13 * 40, 128, 9),  # n = m-1 = 12: 16-entry list
+    (16, 2, 16 * 256, 900, 40), # config-5 antenna count
+    (16, 15, 16 * 64, 64, 6),
 ])
 def test_hip_matches_oracle_on_odd_shapes(m, n, N, res, batch, gpu_device):
     arr = mo.array_geometry(m) if m != 2 else [[0.0, 0.0], [1.0, 0.0]]
