@@ -20,6 +20,7 @@ namespace bazmusic {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef float v4f32 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void wave_lds_fence()
 {
@@ -643,10 +644,17 @@ __device__ __forceinline__ float strength_f32(const double d)
 //    (A first version with rows = bins wrote 64-B pieces scattered over 16 item rows per instruction:
 //    ablation showed the store pattern and a branchy top-n, not the MFMAs, bound it -- DESIGN.md 5.)
 //
-//    FB streams from L2 (452 KiB at cfg2, shared by every wave).  An LDS-stationary slice per block and a
-//    per-row fp32 vote in front of the key network were both measured and dropped (no gain:
-//    profiles/r01_scan_v3_variants.txt, r01_scan_v3_ablation.txt).  ABL is a lab-only ablation mask
-//    (scripts/scan_lab.hip); product launches use ABL = 0.
+//    F delivery: the 4 waves of a workgroup own 4 different 16-item groups but walk the SAME range of bin
+//    steps in lockstep, and share every piece of FB through a double-buffered LDS stage (each wave fetches
+//    a quarter of the next phase from L2 while the current phase's MFMAs run; one s_barrier per phase).
+//    Letting every wave stream FB itself costs 8 KiB of L2 reads per 16 MFMAs = 1.9 GB / 11 TB/s per cfg-2
+//    launch -- the measured floor of that form (0.175 ms with everything but loads + MFMAs removed,
+//    profiles/r01c_scan_ablation.txt).  Ordering inside a phase: stage-loads(next) ... MFMAs ... epilogue
+//    VALU ... s_waitcnt (only the stage loads and the PREVIOUS step's stores are outstanding) ... LDS write
+//    ... this step's stores ... barrier: on gfx9-family ISAs loads and stores share vmcnt and complete out
+//    of order with each other, so a wait must never sit right behind fresh stores.
+//    A phase is up to SCH = 8 k-steps (8 or 16 KiB of LDS per buffer); m = 4 has one phase per step.
+//    ABL is a lab-only ablation mask (scripts/scan_lab.hip); product launches use ABL = 0.
 // =====================================================================================
 template <int M, int NMAX, bool SPEC, bool VEC4, int ABL = 0>
 __global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict__ Qs,
@@ -658,18 +666,22 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict
                                                          uint32_t keep_mask)
 {
     constexpr int MM = M * M;
-    constexpr int KS = (MM + 3) / 4;        // MFMA k-steps
-    constexpr int C2 = 2 * KS;              // double2 chunks per lane per step
+    constexpr int KS = (MM + 3) / 4;                  // MFMA k-steps per bin step
+    constexpr int SCH = (KS <= 8) ? KS : 8;           // k-steps per phase
+    constexpr int PPS = (KS + SCH - 1) / SCH;         // phases per bin step
+    constexpr int CPP = 2 * SCH;                      // 1-KiB chunks (64 x double2) per full phase
+    constexpr int SPW = (CPP + 3) / 4;                // chunks one wave stages per phase
+    __shared__ v2f64 stage[2][CPP * 64];
 
     const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, g = lane >> 4;
 
     // wave task = (16-item group, range of 64-bin steps); the 4 waves of a block take 4 consecutive groups
     const uint32_t split = blockIdx.x % nsplit;
-    const uint32_t igroup = (blockIdx.x / nsplit) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (igroup >= ngroups) return;          // wave-uniform
-    const uint32_t st_begin = (uint32_t)(((uint64_t)nsteps * split) / nsplit);
-    const uint32_t st_end = (uint32_t)(((uint64_t)nsteps * (split + 1)) / nsplit);
+    const uint32_t igroup = (blockIdx.x / nsplit) * 4 + wave;        // may be >= ngroups in the last block:
+    const uint32_t st_begin = (uint32_t)(((uint64_t)nsteps * split) / nsplit);   // such a wave still stages and
+    const uint32_t st_end = (uint32_t)(((uint64_t)nsteps * (split + 1)) / nsplit);   // syncs, but stores nothing
     const uint32_t item0 = igroup * 16;
 
     // A operand: q[item0 + c][e = 4 s + g]   (zero for the K padding e >= MM)
@@ -690,56 +702,142 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict
 #pragma unroll
         for (int i = 0; i < NMAX; ++i) key[r][i] = key_empty();
 
+    // FB is one flat array of chunks: step st, k-step s, tile pair h -> chunk (st*KS + s)*2 + h.
+    // Phase (st, p) covers k-steps [p*SCH, min(KS, (p+1)*SCH)): chunks [ (st*KS + p*SCH)*2, ... ).
+    // Staging registers are four named clang vectors, not an array: an array written under `if (more)` and
+    // read under a later `if (more)` was left in scratch by the compiler (with a full wait after every load).
+    const v2f64* __restrict__ fb = reinterpret_cast<const v2f64*>(FB) + lane;
+    const int wave4 = wave & 3;             // 256-thread blocks: lets the compiler fold `chunk < chunks-per-phase`
+    v2f64 sreg0 = {0, 0}, sreg1 = {0, 0}, sreg2 = {0, 0}, sreg3 = {0, 0};
+    static_assert(SPW <= 4, "a wave stages at most 4 chunks per phase");
+#define BAZ_STAGE_LOAD(ST, P)                                                                    \
+    do {   /* unconditional loads, index clamped into the phase */                               \
+        const int nch__ = 2 * ((KS - (P) * SCH < SCH) ? (KS - (P) * SCH) : SCH);                 \
+        const size_t ch0__ = ((size_t)(ST) * KS + (size_t)(P) * SCH) * 2;                        \
+        sreg0 = fb[(ch0__ + (wave4 < nch__ ? wave4 : nch__ - 1)) * 64];                          \
+        if constexpr (SPW > 1) sreg1 = fb[(ch0__ + (wave4 + 4 < nch__ ? wave4 + 4 : nch__ - 1)) * 64];   \
+        if constexpr (SPW > 2) sreg2 = fb[(ch0__ + (wave4 + 8 < nch__ ? wave4 + 8 : nch__ - 1)) * 64];   \
+        if constexpr (SPW > 3) sreg3 = fb[(ch0__ + (wave4 + 12 < nch__ ? wave4 + 12 : nch__ - 1)) * 64]; \
+    } while (0)
+#define BAZ_STAGE_STORE(BUF, P)                                                                  \
+    do {                                                                                         \
+        const int nch__ = 2 * ((KS - (P) * SCH < SCH) ? (KS - (P) * SCH) : SCH);                 \
+        if (wave4 < nch__) stage[(BUF)][wave4 * 64 + lane] = sreg0;                              \
+        if constexpr (SPW > 1) { if (wave4 + 4 < nch__) stage[(BUF)][(wave4 + 4) * 64 + lane] = sreg1; }   \
+        if constexpr (SPW > 2) { if (wave4 + 8 < nch__) stage[(BUF)][(wave4 + 8) * 64 + lane] = sreg2; }   \
+        if constexpr (SPW > 3) { if (wave4 + 12 < nch__) stage[(BUF)][(wave4 + 12) * 64 + lane] = sreg3; } \
+    } while (0)
+
+    if (st_begin < st_end) {
+        BAZ_STAGE_LOAD(st_begin, 0);
+        BAZ_STAGE_STORE(0, 0);
+    }
+    __syncthreads();
+
+    int buf = 0;
+    v4f32 sv[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // spectrum values of item row r
+    // spectrum addressing: uniform base of this wave's 16 item rows + per-lane 32-bit byte offsets of row r
+    float* __restrict__ spec_base = SPEC ? spec + (size_t)item0 * res : nullptr;
+    uint32_t soff[4];
+    bool row_ok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        soff[r] = ((uint32_t)(g + 4 * r) * res + 4u * (uint32_t)c) * 4u;   // BYTE offset, < 16*res*4
+        row_ok[r] = (item0 + g + 4 * r) < batch;
+    }
     for (uint32_t st = st_begin; st < st_end; ++st) {
-        const double2* __restrict__ fp = FB + (size_t)st * C2 * 64 + lane;
         v4f64 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0, 0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const double2 f01 = fp[(2 * s) * 64];       // tiles (0,1) of k-step s
-            const double2 f23 = fp[(2 * s + 1) * 64];   // tiles (2,3)
-            if constexpr (ABL & 8) {   // lab only
-                acc[0][s & 3] += qa[s] * f01.x; acc[1][s & 3] += qa[s] * f01.y;
-                acc[2][s & 3] += qa[s] * f23.x; acc[3][s & 3] += qa[s] * f23.y;
-            } else {
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f01.x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f01.y, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f23.x, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f23.y, acc[3], 0, 0, 0);
-            }
-        }
-
         const uint32_t bin = st * 64 + 4 * c;   // this lane's first bin of the step
+
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float sv[4];
+        for (int p = 0; p < PPS; ++p) {
+            // 1. fetch this wave's quarter of the NEXT phase from L2 (lands in registers while the MFMAs run)
+            const bool last_p = (p == PPS - 1);
+            const bool more = !last_p || (st + 1 < st_end);                 // wave-uniform
+            if (more) BAZ_STAGE_LOAD(last_p ? st + 1 : st, last_p ? 0 : p + 1);
+
+            // 2. this phase: B operands from LDS, MFMAs
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if constexpr (ABL & 4) sv[t] = __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint64_t, acc[t][r]));
-                else sv[t] = strength_f32(fabs(acc[t][r]));   // ||G^H a||^2 >= 0 in the reference
-            }
-            if constexpr (ABL & 1) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(sv[t]));
-            }
-            if constexpr (SPEC && !(ABL & 1)) {
-                const uint32_t it = item0 + g + 4 * r;
-                if constexpr (VEC4) {      // res % 4 == 0: the 4 bins are all in or all out
-                    if (it < batch && bin < res) {
-                        const v4f32 v = {sv[0], sv[1], sv[2], sv[3]};
-                        *reinterpret_cast<v4f32*>(&spec[(size_t)it * res + bin]) = v;
+            for (int sl = 0; sl < SCH; ++sl) {
+                const int s = p * SCH + sl;
+                if (s < KS) {
+                    const v2f64 f01 = stage[buf][(2 * sl) * 64 + lane];       // tiles (0,1) of k-step s
+                    const v2f64 f23 = stage[buf][(2 * sl + 1) * 64 + lane];   // tiles (2,3)
+                    if constexpr (ABL & 8) {   // lab only
+                        acc[0][s & 3] += qa[s] * f01.x; acc[1][s & 3] += qa[s] * f01.y;
+                        acc[2][s & 3] += qa[s] * f23.x; acc[3][s & 3] += qa[s] * f23.y;
+                    } else {
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f01.x, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f01.y, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f23.x, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f23.y, acc[3], 0, 0, 0);
                     }
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (it < batch && bin + t < res) spec[(size_t)it * res + bin + t] = sv[t];
                 }
             }
-            if constexpr (!(ABL & 2)) {
+
+            // 3. after the last phase of the step: epilogue arithmetic (no memory traffic yet).
+            //    sv (the store data) lives across iterations: the empty asm keeps the PREVIOUS step's values
+            //    allocated until here, so the accumulators above can never be given the registers that still
+            //    feed in-flight stores (the compiler would otherwise guard that WAR hazard with s_waitcnt
+            //    vmcnt(..) in the middle of the MFMA sequence, i.e. wait for fresh stores every step).
+            if (last_p) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) key_insert_new<NMAX>(key[r], make_key(acc[t][r], bin + t, keep_mask));
+                for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(sv[r]));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if constexpr (ABL & 4) sv[r][t] = __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint64_t, acc[t][r]));
+                        else sv[r][t] = strength_f32(fabs(acc[t][r]));   // ||G^H a||^2 >= 0 in the reference
+                    }
+                    if constexpr (!(ABL & 2)) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) key_insert_new<NMAX>(key[r], make_key(acc[t][r], bin + t, keep_mask));
+                    }
+                }
             }
+
+            // 4. publish the next phase (waits only for the stage loads and the previous step's stores) ...
+            if (more) BAZ_STAGE_STORE(buf ^ 1, last_p ? 0 : p + 1);
+
+            // 5. ... then this step's spectrum stores, then the barrier
+            if (last_p) {
+                if constexpr (ABL & 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(sv[r]));
+                }
+                if constexpr (SPEC && !(ABL & 1)) {
+                    // wave-uniform base (SGPR pair) + loop-invariant 32-bit lane offsets: the store operands are
+                    // never recomputed, so no register they occupy is recycled while a store is in flight
+                    char* __restrict__ srow = reinterpret_cast<char*>(spec_base + (size_t)st * 64);
+                    if constexpr (VEC4) {          // res % 4 == 0: a lane's 4 bins are all in or all out
+                        if (st * 64 + 64 <= res) { // wave-uniform: whole step inside the table
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                if constexpr (ABL & 16) {   // lab only: untracked saddr store (no compiler vmcnt bookkeeping)
+                                    if (row_ok[r]) asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(soff[r]), "v"(sv[r]), "s"(srow) : "memory");
+                                } else {
+                                    if (row_ok[r]) *reinterpret_cast<v4f32*>(srow + soff[r]) = sv[r];
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (row_ok[r] && bin < res) *reinterpret_cast<v4f32*>(srow + soff[r]) = sv[r];
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                if (row_ok[r] && bin + t < res) *reinterpret_cast<float*>(srow + soff[r] + 4u * t) = sv[r][t];
+                    }
+                }
+            }
+            __syncthreads();
+            buf ^= 1;
         }
     }
 
@@ -757,6 +855,9 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict
         }
     }
 }
+
+#undef BAZ_STAGE_LOAD
+#undef BAZ_STAGE_STORE
 
 // Final top-n over the per-range candidate keys (one thread per item), ang / lvl outputs
 // (lib/baz_music_doa.cc:129-155).  lvl[i] is read back from the spectrum this launch sequence just

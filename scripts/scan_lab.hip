@@ -47,6 +47,8 @@ int main()
     R(3, "no stores, no top-n", 8);
     R(7, "no stores/top-n/cvt-rcp", 8);
     R(8, "full, no MFMA", 8);
+    R(16, "full, asm saddr stores (untracked)", 8);
+    R(18, "asm saddr stores, no top-n", 8);
     R(0, "full ns=1", 1);
     R(0, "full ns=2", 2);
     R(0, "full ns=4", 4);
