@@ -44,8 +44,19 @@ def init_process_group(use_gpu: bool, local_rank: int = 0):
                 backend = "nccl"      # = RCCL on ROCm; used for the barrier / clock only
         if backend == "nccl":
             import torch
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+                dist.barrier(device_ids=[local_rank])          # first collective: creates the RCCL communicator
+            except Exception as e:   # RCCL unusable on this box: the data path needs no collective anyway
+                import sys
+                print("[gr_baz_amd.sharding] RCCL init failed (%s); using gloo for the barrier/clock" % e,
+                      file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29511")) + 1)
+                backend = "gloo"
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         _BACKEND = backend
