@@ -232,3 +232,105 @@ def test_full_size_properties(cfg, batch, distinct, gpu_device):
     assert bool((bins[:, 0] == spec.argmax(dim=1)).all())
     assert bool((torch.gather(spec, 1, bins) == lvl).all())
     assert bool((lvl[:, :-1] >= lvl[:, 1:]).all())
+
+
+# ------------------------------------------------------------------ boundary behaviour
+def test_more_than_65536_bins_uses_the_wide_key(gpu_device):
+    """resolution > 65,536 switches the top-n key to a 20-bit bin field; also an odd resolution
+    (scalar spectrum stores) and a tail step with 33 valid bins."""
+    m, n, N, res, batch = 2, 1, 64, 70001, 3
+    arr = [[0.0, 0.0], [1.0, 0.0]]
+    table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
+    items = mo.synth_items(batch, m, N, arr, mo.FREQUENCY, mo.SPACING, angles_deg=(300.3,), snr_db=15.0, seed=9)
+    ao, lo, so, st = mo.music_doa_work_batch(items, table, m, n)
+    with _capi().Context(m, n, N, res, table) as ctx:
+        ang, lvl, spec = device_run(ctx, items, gpu_device)
+    assert_spectrum_close(spec, so)
+    assert_doa_match(ang, lvl, ao, lo, res, st)
+    bins = np.rint(ang.astype(np.float64) * res / 360.0).astype(int)
+    assert bins.max() > 65535 or bins.min() >= 0
+
+
+def test_host_path_with_several_chunks_equals_device_path(gpu_device):
+    """baz_music_process cuts big host batches into pipelined chunks (64 MiB of traffic each)."""
+    c = mo.make_config("cfg1", 256, seed=31)
+    reps = 200                                    # 51,200 items x 3.5 KB = 3 chunks
+    items = np.tile(c["items"], (reps, 1))
+    with _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"]) as ctx:
+        a_d, l_d, s_d = device_run(ctx, c["items"], gpu_device)
+        a_h, l_h, s_h = ctx.process(items)
+        a_2, l_2, _ = ctx.process(items[:777], want_spectrum=False)
+    assert np.array_equal(a_h.reshape(reps, 256, -1), np.broadcast_to(a_d, (reps,) + a_d.shape))
+    assert np.array_equal(s_h.reshape(reps, 256, -1), np.broadcast_to(s_d, (reps,) + s_d.shape))
+    assert np.array_equal(l_h[:256], l_d) and np.array_equal(a_2, a_h[:777]) and np.array_equal(l_2, l_h[:777])
+
+
+def test_caller_stream_ordering(gpu_device):
+    """baz_music_set_stream: work is ordered on the caller's stream (here a torch side stream), so torch
+    ops enqueued before/after on that stream see consistent data without extra synchronisation."""
+    torch = _torch()
+    c = mo.make_config("cfg1", 128, seed=41)
+    ao, lo, so, st = mo.music_doa_work_batch(c["items"], c["table"], c["m"], c["n"])
+    side = torch.cuda.Stream()
+    with _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"]) as ctx:
+        ctx.set_stream(side.cuda_stream)
+        host = torch.from_numpy(c["items"].view(np.float32)).pin_memory()
+        with torch.cuda.stream(side):
+            x = torch.empty_like(host, device=gpu_device)
+            x.copy_(host, non_blocking=True)                     # producer on the same stream
+            ang = torch.zeros(128, c["n"], dtype=torch.float32, device=gpu_device)
+            lvl = torch.zeros_like(ang)
+            spec = torch.zeros(128, c["res"], dtype=torch.float32, device=gpu_device)
+            ctx.process_device(x.data_ptr(), 128, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr())
+            total = spec.sum(dim=1)                              # consumer on the same stream
+        side.synchronize()
+        ctx.set_stream(None)
+    assert_spectrum_close(spec.cpu().numpy(), so)
+    assert np.allclose(total.cpu().numpy(), so.astype(np.float64).sum(axis=1), rtol=1e-4)
+
+
+def test_two_contexts_interleaved(gpu_device):
+    c1 = mo.make_config("cfg1", 70, seed=51)
+    c3 = mo.make_config("cfg3", 5, seed=52)
+    r1 = mo.music_doa_work_batch(c1["items"], c1["table"], c1["m"], c1["n"])
+    r3 = mo.music_doa_work_batch(c3["items"], c3["table"], c3["m"], c3["n"])
+    capi = _capi()
+    with capi.Context(c1["m"], c1["n"], c1["nsamples"], c1["res"], c1["table"]) as k1, \
+            capi.Context(c3["m"], c3["n"], c3["nsamples"], c3["res"], c3["table"]) as k3:
+        for _ in range(3):
+            a1, l1, s1 = device_run(k1, c1["items"], gpu_device)
+            a3, l3, s3 = device_run(k3, c3["items"], gpu_device)
+            assert_spectrum_close(s1, r1[2]); assert_doa_match(a1, l1, r1[0], r1[1], c1["res"], r1[3])
+            assert_spectrum_close(s3, r3[2]); assert_doa_match(a3, l3, r3[0], r3[1], c3["res"], r3[3])
+
+
+def test_set_table_from_another_thread_is_never_torn(gpu_device):
+    """set_array_response runs on the GUI/python thread while work() runs on the scheduler thread
+    (lib/baz_music_doa.cc:67,101): every batch must be computed with exactly one of the two tables."""
+    import threading
+    c = mo.make_config("cfg1", 64, seed=61)
+    tA = c["table"]
+    tB = mo.steering_table_c64(c["array"], c["res"], mo.FREQUENCY * 0.9, mo.SPACING)
+    sA = mo.music_doa_work_batch(c["items"], tA, c["m"], c["n"])[2]
+    sB = mo.music_doa_work_batch(c["items"], tB, c["m"], c["n"])[2]
+    stop = threading.Event()
+    with _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], tA) as ctx:
+        def flipper():
+            k = 0
+            while not stop.is_set():
+                ctx.set_table(tB if (k & 1) == 0 else tA)
+                k += 1
+        th = threading.Thread(target=flipper)
+        th.start()
+        seen = set()
+        try:
+            for _ in range(60):
+                _, _, s = ctx.process(c["items"])
+                relA = np.max(np.abs(s - sA) / sA)
+                relB = np.max(np.abs(s - sB) / sB)
+                assert min(relA, relB) <= 1e-5, "a batch mixed two steering tables"
+                seen.add("A" if relA <= relB else "B")
+        finally:
+            stop.set()
+            th.join()
+    assert seen  # usually {"A", "B"}
