@@ -27,7 +27,9 @@ def _load_native():
 _native = _load_native()
 music_doa = _native.music_doa
 baz_music_doa_sptr = _native.baz_music_doa_sptr
+agc_cc = _native.agc_cc                    # GR_SWIG_BLOCK_MAGIC(baz, agc_cc) in the reference
+baz_agc_cc_sptr = _native.baz_agc_cc_sptr
 
 from . import music_doa_helper  # noqa: E402,F401
 
-__all__ = ["music_doa", "baz_music_doa_sptr", "music_doa_helper"]
+__all__ = ["music_doa", "baz_music_doa_sptr", "music_doa_helper", "agc_cc", "baz_agc_cc_sptr"]

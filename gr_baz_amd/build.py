@@ -1,6 +1,7 @@
 """Builds the in-tree native artefacts of gr_baz_amd (gfx950 only, no JIT cache):
 
   csrc/libbaz_music_hip.so   HIP kernels + the C-ABI of include/baz_music_hip.h   (hipcc)
+  csrc/libbaz_agc_hip.so     AGC kernels + the C-ABI of include/baz_agc_hip.h      (hipcc)
   host/libgnuradio_baz_music.so   the gr::sync_block host block on the GNU Radio API shim (g++)
   host/_baz_music*.so        pybind11 module exposing baz.music_doa (SWIG stand-in)
 
@@ -21,6 +22,7 @@ HOST = os.path.join(HERE, "host")
 INCLUDE = os.path.join(ROOT, "include")
 
 HIP_LIB = os.path.join(CSRC, "libbaz_music_hip.so")
+AGC_LIB = os.path.join(CSRC, "libbaz_agc_hip.so")
 HOST_LIB = os.path.join(HOST, "libgnuradio_baz_music.so")
 
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in VGPRs (gfx950 has a unified file): no v_accvgpr_read per result
@@ -50,6 +52,13 @@ def build_hip(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=CSRC)
+    agc_srcs = [os.path.join(CSRC, "baz_agc_hip.hip"), os.path.join(CSRC, "agc_kernels.hip.h"),
+                os.path.join(INCLUDE, "baz_agc_hip.h")]
+    if force or _newer(AGC_LIB, agc_srcs):
+        cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", AGC_LIB, agc_srcs[0]]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
     return HIP_LIB
 
 
@@ -61,14 +70,15 @@ def pybind_module_path():
 def build_host(force=False, verbose=False):
     """C++ host block (gr::sync_block surface) + pybind11 module; both link libbaz_music_hip.so."""
     block_srcs = [os.path.join(HOST, "baz_music_doa.cc"), os.path.join(HOST, "baz_music_doa.h"),
-                  os.path.join(INCLUDE, "baz_music_hip.h")]
+                  os.path.join(INCLUDE, "baz_music_hip.h"), os.path.join(HOST, "baz_agc_cc.cc"),
+                  os.path.join(HOST, "baz_agc_cc.h"), os.path.join(INCLUDE, "baz_agc_hip.h")]
     if not os.path.exists(block_srcs[0]):
         return None
     shim_inc = os.path.join(HOST, "gr_shim")
     common = ["-O2", "-std=c++14", "-fPIC", "-I", INCLUDE, "-I", HOST, "-I", shim_inc]
-    link = ["-L", CSRC, "-lbaz_music_hip", "-Wl,-rpath,$ORIGIN/../csrc"]
-    if force or _newer(HOST_LIB, block_srcs + [HIP_LIB]):
-        cmd = ["g++"] + common + ["-shared", "-o", HOST_LIB, block_srcs[0]] + link
+    link = ["-L", CSRC, "-lbaz_music_hip", "-lbaz_agc_hip", "-Wl,-rpath,$ORIGIN/../csrc"]
+    if force or _newer(HOST_LIB, block_srcs + [HIP_LIB, AGC_LIB]):
+        cmd = ["g++"] + common + ["-shared", "-o", HOST_LIB, block_srcs[0], block_srcs[3]] + link
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=HOST)

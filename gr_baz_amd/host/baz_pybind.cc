@@ -3,6 +3,7 @@
  * handle on the C++ host block with `.set_array_response(list[list[complex]])`.  `.work(items)` is a
  * test/demo convenience that drives the block's virtual work() the way the GNU Radio scheduler
  * does (pointer vectors into numpy buffers). */
+#include <baz_agc_cc.h>
 #include <baz_music_doa.h>
 
 #include <pybind11/complex.h>
@@ -43,6 +44,31 @@ py::tuple drive_work(music_doa_handle& h, py::array_t<std::complex<float>, py::a
     return py::make_tuple(produced, ang, n_outputs > 1 ? py::object(lvl) : none, n_outputs > 2 ? py::object(spec) : none);
 }
 
+struct agc_handle {
+    baz_agc_cc_sptr blk;
+};
+
+py::tuple drive_agc(agc_handle& h, py::array_t<std::complex<float>, py::array::c_style | py::array::forcecast> x, int n_outputs)
+{
+    if (n_outputs < 1 || n_outputs > 3) throw std::invalid_argument("n_outputs must be 1, 2 or 3");
+    py::buffer_info bi = x.request();
+    const int n = (int)bi.size;
+    py::array_t<std::complex<float>> out((size_t)n);
+    py::array_t<float> env((size_t)n), mul((size_t)n);
+    gr_vector_const_void_star in(1, bi.ptr);
+    gr_vector_void_star outs;
+    outs.push_back(out.mutable_data());
+    if (n_outputs > 1) outs.push_back(env.mutable_data());
+    if (n_outputs > 2) outs.push_back(mul.mutable_data());
+    int produced;
+    {
+        py::gil_scoped_release nogil;
+        produced = h.blk->work(n, in, outs);
+    }
+    py::object none = py::none();
+    return py::make_tuple(produced, out, n_outputs > 1 ? py::object(env) : none, n_outputs > 2 ? py::object(mul) : none);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_baz_music, mod)
@@ -65,6 +91,22 @@ PYBIND11_MODULE(_baz_music, mod)
             return py::make_tuple(h.blk->output_signature()->min_streams(), h.blk->output_signature()->max_streams());
         })
         .def("work", &drive_work, py::arg("items"), py::arg("n_outputs") = 3);
+    py::class_<agc_handle>(mod, "baz_agc_cc_sptr")
+        .def("name", [](agc_handle& h) { return h.blk->name(); })
+        .def("input_item_sizes", [](agc_handle& h) { return h.blk->input_signature()->sizeof_stream_items(); })
+        .def("output_item_sizes", [](agc_handle& h) { return h.blk->output_signature()->sizeof_stream_items(); })
+        .def("output_streams", [](agc_handle& h) {
+            return py::make_tuple(h.blk->output_signature()->min_streams(), h.blk->output_signature()->max_streams());
+        })
+        .def("work", &drive_agc, py::arg("items"), py::arg("n_outputs") = 3);
+    // swig/baz_swig.i: GR_SWIG_BLOCK_MAGIC(baz, agc_cc) -> baz.agc_cc(rate, reference, gain, max_gain)
+    mod.def("agc_cc",
+            [](float rate, float reference, float gain, float max_gain) {
+                agc_handle h;
+                h.blk = baz_make_agc_cc(rate, reference, gain, max_gain);
+                return h;
+            },
+            py::arg("rate") = 1e-4f, py::arg("reference") = 1.0f, py::arg("gain") = 1.0f, py::arg("max_gain") = 0.0f);
     mod.def("music_doa",
             [](unsigned int m, unsigned int n, unsigned int nsamples, const array_response_t& table, unsigned int resolution) {
                 music_doa_handle h;

@@ -1,0 +1,58 @@
+/* baz_agc_hip.h -- C-ABI of the MI355X (gfx950) AGC engine (BASELINE config 5 front-end).
+ *
+ * Drop-in boundary for baz_agc_cc (gr-baz):
+ *     baz_agc_cc::baz_agc_cc()   /root/reference/lib/baz_agc_cc.cc:50-62   (rate, reference, gain, max_gain, state)
+ *     baz_agc_cc::work()         /root/reference/lib/baz_agc_cc.cc:64-102  (the live part; :103-149 is dead code
+ *                                                                            behind an unconditional `continue`)
+ * One context holds `nstreams` independent AGC states (one gr-baz block instance each), so a multi-antenna
+ * front-end is one launch sequence.  Plain C types, no exceptions; 0 == OK, negative == error
+ * (codes shared with baz_music_hip.h).  Layout: stream-major, stream s occupies [s*stride, s*stride + n).
+ */
+#ifndef INCLUDED_BAZ_AGC_HIP_H
+#define INCLUDED_BAZ_AGC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define BAZ_AGC_API __attribute__((visibility("default")))
+#else
+#define BAZ_AGC_API
+#endif
+
+typedef struct baz_agc_ctx baz_agc_ctx;
+
+enum { BAZ_AGC_OK = 0, BAZ_AGC_E_INVALID = -1, BAZ_AGC_E_NOMEM = -2, BAZ_AGC_E_HIP = -3, BAZ_AGC_E_NODEVICE = -5 };
+
+/* Replaces baz_make_agc_cc(rate, reference, gain, max_gain) (lib/baz_agc_cc.cc:44-62; defaults 1e-4, 1.0, 1.0,
+ * 0.0 at lib/baz_agc_cc.h:41).  `gain` and `max_gain` only feed the reference's dead code and are kept for
+ * signature compatibility.  device_id < 0 selects the current HIP device. */
+BAZ_AGC_API int baz_agc_create(baz_agc_ctx** out, uint32_t nstreams, float rate, float reference, float gain,
+                               float max_gain, int device_id);
+BAZ_AGC_API void baz_agc_destroy(baz_agc_ctx* ctx);
+
+/* Replaces work() for n samples per stream held in HOST memory (blocks until the outputs are filled).
+ * in_ri/out_ri: complex64 as interleaved floats; env, mul: float per sample or NULL (output ports 1, 2,
+ * lib/baz_agc_cc.cc:68-69).  State (_env, _count) carries over to the next call like the reference's members.
+ * Returns n or <0. */
+BAZ_AGC_API int baz_agc_process(baz_agc_ctx* ctx, const float* in_ri, uint64_t n, uint64_t stride, float* out_ri,
+                                float* env, float* mul);
+/* Same on DEVICE-resident buffers, asynchronous on the context's stream.  Returns 0 or <0. */
+BAZ_AGC_API int baz_agc_process_device(baz_agc_ctx* ctx, const void* d_in, uint64_t n, uint64_t stride, void* d_out,
+                                       void* d_env, void* d_mul);
+/* Restarts every stream (count = 0, env = 0), i.e. a freshly constructed block. */
+BAZ_AGC_API int baz_agc_reset(baz_agc_ctx* ctx);
+BAZ_AGC_API int baz_agc_set_stream(baz_agc_ctx* ctx, void* hip_stream);
+BAZ_AGC_API int baz_agc_sync(baz_agc_ctx* ctx);
+/* Number of samples consumed per stream so far (the reference's _count). */
+BAZ_AGC_API uint64_t baz_agc_count(const baz_agc_ctx* ctx);
+BAZ_AGC_API const char* baz_agc_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INCLUDED_BAZ_AGC_HIP_H */

@@ -28,6 +28,8 @@ public:
     std::vector<int> sizeof_stream_items;
     static sptr make(int mn, int mx, int s0)
     { sptr p(new io_signature); p->min_streams = mn; p->max_streams = mx; p->sizeof_stream_items = {s0}; return p; }
+    static sptr make2(int mn, int mx, int s0, int s1)
+    { sptr p(new io_signature); p->min_streams = mn; p->max_streams = mx; p->sizeof_stream_items = {s0, s1}; return p; }
     static sptr make3(int mn, int mx, int s0, int s1, int s2)
     { sptr p(new io_signature); p->min_streams = mn; p->max_streams = mx; p->sizeof_stream_items = {s0, s1, s2}; return p; }
 };
@@ -51,4 +53,12 @@ private:
 };
 
 }  // namespace gr
+
+// gnuradio::get_initial_sptr (lib/baz_agc_cc.cc:47): plain shared_ptr construction in the shim
+namespace gnuradio {
+template <class T> inline boost::shared_ptr<T> get_initial_sptr(T* p) { return boost::shared_ptr<T>(p); }
+}
+#ifndef BAZ_API
+#define BAZ_API
+#endif
 #endif

@@ -39,6 +39,31 @@ def fixture(name, m, n, nsamples, res, array, batch, snr_db, seed, angles=(40.3,
     print("%-28s items %s  spectrum %s  %6.1f KiB" % (name, items.shape, spec.shape, os.path.getsize(path) / 1024))
 
 
+def agc_signal(n, seed):
+    rng = np.random.default_rng(seed)
+    amp = 0.05 + 2.0 * np.abs(np.sin(np.linspace(0.0, 9.0, n))) + (np.arange(n) > n // 2) * 3.0
+    return ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * amp).astype(np.complex64)
+
+
+def agc_fixture(name, rate, reference, calls, seed):
+    """calls: sample counts of consecutive work() calls on ONE block instance (state carries over).  Outputs
+    come from oracle/_ref/libbaz_agc_ref.so == the reference's own lib/baz_agc_cc.cc::work()."""
+    from oracle import agc_ref as ar
+    x = agc_signal(int(sum(calls)), seed)
+    blk = ar.Agc(rate, reference, use_reference_source=True)
+    outs, envs, muls = [], [], []
+    pos = 0
+    for c in calls:
+        o, e, m = blk.work(x[pos:pos + c])
+        outs.append(o); envs.append(e); muls.append(m)
+        pos += c
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, x=x, out=np.concatenate(outs), env=np.concatenate(envs), mul=np.concatenate(muls),
+                        calls=np.asarray(calls), rate=np.float32(rate), reference=np.float32(reference),
+                        generator="oracle/_ref (reference lib/baz_agc_cc.cc::work on API shim)")
+    print("%-28s calls %s  %6.1f KiB" % (name, list(calls), os.path.getsize(path) / 1024))
+
+
 def main():
     if not mr.have_ref():
         mr.build()
@@ -72,6 +97,11 @@ def main():
             angles=(10.0, 50.0, 90.0, 130.0, 170.0, 210.0, 250.0, 290.0, 330.0))
     fixture("m10_n3_N1000_r1001", 10, 3, 1000, 1001, mo.array_geometry(10), 3, 20.0, 2011, angles=(70.0, 190.0, 300.5))
     fixture("m9_n1_N630_r250", 9, 1, 630, 250, mo.array_geometry(9), 3, 15.0, 2012, angles=(222.0,))
+    # baz_agc_cc: defaults of lib/baz_agc_cc.h:41 and a fast loop; stateful call sequences
+    # that straddle the 4096-sample chunk of the HIP scan
+    agc_fixture("agc_default_rate1e-4", 1e-4, 1.0, (12000,), 3001)
+    agc_fixture("agc_stateful_rate1e-2", 1e-2, 0.5, (1, 4095, 4096, 4097, 3, 5000), 3002)
+    agc_fixture("agc_fast_rate0.5", 0.5, 2.0, (100, 9000), 3003)
 
 
 if __name__ == "__main__":
