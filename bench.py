@@ -108,7 +108,6 @@ def main():
     spec = torch.zeros(batch, RES, dtype=torch.float32, device=dev)
 
     ctx = capi.Context(M, N_EMIT, NSAMPLES, RES, table, device_id=local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.reserve(batch)
 
     def step():

@@ -85,7 +85,8 @@ BAZ_MUSIC_API int baz_music_process_device(baz_music_ctx* ctx, const void* d_in,
                                            void* d_ang, void* d_lvl, void* d_spectrum);
 
 /* Use an externally owned hipStream_t (e.g. the host framework's current stream) for all
- * subsequent launches; NULL restores the context's own stream. */
+ * subsequent launches; NULL restores the context's own stream (so the legacy default stream, whose
+ * handle is NULL, cannot be selected: pass a created stream). */
 BAZ_MUSIC_API int baz_music_set_stream(baz_music_ctx* ctx, void* hip_stream);
 
 /* Blocks until everything submitted on the context's stream has finished. */
