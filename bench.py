@@ -117,7 +117,7 @@ def main():
         step()
     torch.cuda.synchronize()
     sharding.barrier(active, True)
-    ctx.profile(True)
+    ctx.profile(int(os.environ.get("BAZ_BENCH_PROFILE", "2")))   # 2: hipEvents around the dominant kernel only
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):

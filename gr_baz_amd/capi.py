@@ -176,7 +176,8 @@ class Context:
         self._chk(lib().baz_music_reserve(self._h, int(max_batch)), "baz_music_reserve")
 
     def profile(self, enable):
-        self._chk(lib().baz_music_profile(self._h, 1 if enable else 0), "baz_music_profile")
+        """enable: False/0 off, True/1 every stage, 2 only the scan stage (cheapest)."""
+        self._chk(lib().baz_music_profile(self._h, int(enable)), "baz_music_profile")
 
     def stage_ms(self, stage):
         ms = ctypes.c_double(0.0)

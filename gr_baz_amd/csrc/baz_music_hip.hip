@@ -62,7 +62,7 @@ struct baz_music_ctx {
     bool s_has_spec = false;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     std::mutex mtx;   // serialises set_table against process*, like d_mutex (.cc:67,101)
-    bool profiling = false;
+    int profiling = 0;      // 0 off, 1 every stage, 2 only the dominant (scan) stage
     StageProf prof[BAZ_MUSIC_NUM_STAGES];
     std::string stage_name[BAZ_MUSIC_NUM_STAGES];
     char hip_err[256] = {0};
@@ -167,7 +167,7 @@ struct ProfScope {
     hipEvent_t stop = nullptr;
     ProfScope(baz_music_ctx* ctx, int st) : c(ctx), stage(st)
     {
-        if (!c->profiling) return;
+        if (!c->profiling || (c->profiling == 2 && stage != BAZ_MUSIC_STAGE_SCAN)) return;
         StageProf& p = c->prof[stage];
         if (p.used + 2 > p.ev.size()) {
             for (int k = 0; k < 2; ++k) {
@@ -629,10 +629,10 @@ int baz_music_profile(baz_music_ctx* c, int enable)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (enable) {
         for (auto& p : c->prof) { p.used = 0; p.total_ms = 0.0; p.launches = 0; }
-        c->profiling = true;
+        c->profiling = (enable == 2) ? 2 : 1;
     } else {
         prof_collect(c);
-        c->profiling = false;
+        c->profiling = 0;
     }
     return BAZ_MUSIC_OK;
 }

@@ -97,7 +97,8 @@ BAZ_MUSIC_API int baz_music_sync(baz_music_ctx* ctx);
 BAZ_MUSIC_API int baz_music_reserve(baz_music_ctx* ctx, uint32_t max_batch);
 
 /* Per-stage device timing with hipEvents recorded on the launch stream around each
- * kernel of process_device().  enable: 1 = start recording (and reset), 0 = stop. */
+ * kernel of process_device().  enable: 1 = start recording every stage (and reset), 2 = only the dominant
+ * (scan) stage -- each recorded event pair costs ~10 us of launch gap --, 0 = stop. */
 BAZ_MUSIC_API int baz_music_profile(baz_music_ctx* ctx, int enable);
 /* Synchronises, then returns total milliseconds and number of launches recorded for `stage`. */
 BAZ_MUSIC_API int baz_music_stage_ms(baz_music_ctx* ctx, int stage, double* total_ms, uint64_t* launches);
