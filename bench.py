@@ -125,13 +125,20 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     sharding.barrier(active, True)
+    scan_ms, scan_n = ctx.stage_ms(capi.STAGE_SCAN)       # dominant kernel, timed region only
+    ctx.profile(False)
+    # informational per-stage breakdown from a separate short pass (events around every kernel add launch gaps,
+    # so they stay out of the timed region)
+    ctx.profile(1)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
     stage = [ctx.stage_ms(s) for s in range(capi.NUM_STAGES)]
     ctx.profile(False)
 
     value, tmax, total_items = sharding.whole_job_rate(batch * args.steps, elapsed, active, True)
 
     if rank == 0:
-        scan_ms, scan_n = stage[capi.STAGE_SCAN]
         scan_avg_s = scan_ms / max(scan_n, 1) * 1e-3
         scan_bytes = (4 * RES + 8 * N_EMIT) * batch                 # spectrum + ang/lvl-equivalent written per launch
         achieved = scan_bytes / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
@@ -153,7 +160,7 @@ def main():
                        "items_per_gpu_per_step": batch, "parallelism": "independent streams, s mod %d, no collective" % world,
                        "algorithmic_bytes_per_item": ctx.bytes_per_item(True),
                        "pipeline_hbm_fraction_of_8TBs": value / world * ctx.bytes_per_item(True) / 8e12,
-                       "stage_ms_per_launch": {nm: stage[s][0] / max(stage[s][1], 1)
+                       "stage_ms_per_launch_separate_pass": {nm: stage[s][0] / max(stage[s][1], 1)
                                                for s, nm in enumerate(("cov_mfma", "evd_proj", "scan_mfma", "topn_merge"))}},
             "roofline": {"bound": "hbm", "kernel": "scan_mfma_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
