@@ -72,9 +72,10 @@ def cpu_baseline(table, seconds_per_thread=2.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ramp-seconds", type=float, default=0.25, help="untimed steady load before warm-up (clock ramp)")
     args = ap.parse_args()
 
     import numpy as np
@@ -113,6 +114,14 @@ def main():
     def step():
         ctx.process_device(x.data_ptr(), batch, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr())
 
+    # Clock ramp (untimed, before the W warm-up steps): the GPU's power management needs tens of milliseconds of
+    # continuous load to leave its idle clocks -- a 3-step (1 ms) warm-up measures the ramp, not the steady state a
+    # streaming block runs in (0.42 vs 0.36 ms/step on the same box, profiles/r01g_clock_ramp.txt).
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < args.ramp_seconds:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

@@ -63,6 +63,7 @@ struct baz_music_ctx {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     std::mutex mtx;   // serialises set_table against process*, like d_mutex (.cc:67,101)
     int profiling = 0;      // 0 off, 1 every stage, 2 only the dominant (scan) stage
+    int lab_variant = 0;
     StageProf prof[BAZ_MUSIC_NUM_STAGES];
     std::string stage_name[BAZ_MUSIC_NUM_STAGES];
     char hip_err[256] = {0};
@@ -302,6 +303,14 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
 #define BAZ_SCAN_LAUNCH(SPEC, VEC4)                                                                          \
     hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4>), dim3(G.blocks), dim3(256), 0, c->stream, dQ, \
                        c->dFB, d_spec, cand, batch, c->res, qstride, c->fb_steps, G.nsplit, G.groups, c->keep_mask)
+    if constexpr (M == 4 && NMAX == 2) {   // lab (BAZ_MUSIC_SCAN_VARIANT=1): cached spectrum stores, for the A/B in DESIGN.md 5.3
+        if (spec && c->lab_variant == 1) {
+            hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, true, false, 32>), dim3(G.blocks), dim3(256), 0, c->stream, dQ,
+                               c->dFB, d_spec, cand, batch, c->res, qstride, c->fb_steps, G.nsplit, G.groups, c->keep_mask);
+            HIP_TRY(c, hipGetLastError());
+            return BAZ_MUSIC_OK;
+        }
+    }
     if (spec && vec4) BAZ_SCAN_LAUNCH(true, true);
     else if (spec) BAZ_SCAN_LAUNCH(true, false);
     else BAZ_SCAN_LAUNCH(false, false);
@@ -471,6 +480,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     if (!c) return BAZ_MUSIC_E_NOMEM;
     c->m = m; c->n = n; c->nsamples = nsamples; c->res = resolution; c->K = nsamples / m;
     c->device = dev;
+    if (const char* v = getenv("BAZ_MUSIC_SCAN_VARIANT")) c->lab_variant = atoi(v);
     DeviceGuard guard(dev);
     int r = BAZ_MUSIC_OK;
     do {

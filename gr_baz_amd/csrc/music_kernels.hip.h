@@ -20,6 +20,7 @@ namespace bazmusic {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef float v4f32 __attribute__((ext_vector_type(4)));
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void wave_lds_fence()
@@ -739,6 +740,9 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict
     // spectrum addressing: uniform base of this wave's 16 item rows + per-lane 32-bit byte offsets of row r
     float* __restrict__ spec_base = SPEC ? spec + (size_t)item0 * res : nullptr;
     uint32_t soff[4];
+    // raw buffer over this wave's 16 rows: offsets stay < 16*res*4 + res*4 <= 4.25 MiB (res <= 65536)
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t spec_rsrc = __builtin_amdgcn_make_buffer_rsrc(spec_base, 0, 0x7FFFFFFF, 0x00020000);
+    constexpr int SPEC_STORE_AUX = 1 | 2 | 16;   // gfx94x/gfx950 cache-policy bits: sc0 | nt | sc1
     bool row_ok[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -809,30 +813,40 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict
                     for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(sv[r]));
                 }
                 if constexpr (SPEC && !(ABL & 1)) {
-                    // wave-uniform base (SGPR pair) + loop-invariant 32-bit lane offsets: the store operands are
-                    // never recomputed, so no register they occupy is recycled while a store is in flight
-                    char* __restrict__ srow = reinterpret_cast<char*>(spec_base + (size_t)st * 64);
-                    if constexpr (VEC4) {          // res % 4 == 0: a lane's 4 bins are all in or all out
-                        if (st * 64 + 64 <= res) { // wave-uniform: whole step inside the table
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                if constexpr (ABL & 16) {   // lab only: untracked saddr store (no compiler vmcnt bookkeeping)
-                                    if (row_ok[r]) asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(soff[r]), "v"(sv[r]), "s"(srow) : "memory");
-                                } else {
-                                    if (row_ok[r]) *reinterpret_cast<v4f32*>(srow + soff[r]) = sv[r];
-                                }
-                            }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (row_ok[r] && bin < res) *reinterpret_cast<v4f32*>(srow + soff[r]) = sv[r];
-                        }
-                    } else {
+                    // Buffer stores: wave-uniform resource (this wave's 16 item rows) + loop-invariant 32-bit lane
+                    // offsets + the step offset as SGPR soffset: the store operands are never recomputed, so no
+                    // register they occupy is recycled while a store is in flight.  Cache policy sc0|sc1|nt: the
+                    // spectrum is written once and not read by this pipeline (the merge fetches n floats per item),
+                    // so it streams to HBM instead of parking ~290 MB of dirty lines in L2 / Infinity Cache that the
+                    // NEXT kernel (covariance of the following batch) then pays to drain: step 0.434 -> 0.358 ms,
+                    // covariance 0.156 -> 0.108 ms, scan 0.244 -> 0.219 ms (profiles/r01g_store_policy.txt).
+                    const int step_off = (int)(st * 256u);
+                    if constexpr (ABL & 32) {      // lab: the plain cached stores of the measurement above
+                        char* __restrict__ srow = reinterpret_cast<char*>(spec_base + (size_t)st * 64);
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
 #pragma unroll
                             for (int t = 0; t < 4; ++t)
                                 if (row_ok[r] && bin + t < res) *reinterpret_cast<float*>(srow + soff[r] + 4u * t) = sv[r][t];
+                    } else if constexpr (VEC4) {   // res % 4 == 0: a lane's 4 bins are all in or all out
+                        if (st * 64 + 64 <= res) { // wave-uniform: whole step inside the table
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (row_ok[r]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, SPEC_STORE_AUX);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (row_ok[r] && bin < res) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, SPEC_STORE_AUX);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const v4u32 u = __builtin_bit_cast(v4u32, sv[r]);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                if (row_ok[r] && bin + t < res)
+                                    __builtin_amdgcn_raw_buffer_store_b32(u[t], spec_rsrc, (int)(soff[r] + 4u * t), step_off, SPEC_STORE_AUX);
+                        }
                     }
                 }
             }

@@ -41,6 +41,16 @@ for r in range(rounds):   # interleaved rounds
         ms = [ctx.stage_ms(s)[0] / 5 for s in range(4)]
         ctx.profile(False)
         results[v].append(ms)
+wall = {v: [] for v in variants}
+for r in range(rounds):   # un-instrumented wall clock, 20 steps back to back
+    for v in variants:
+        ctx = ctxs[v]
+        for _ in range(3): ctx.process_device(x.data_ptr(), B, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr())
+        ctx.sync(); t0 = time.perf_counter()
+        for _ in range(20): ctx.process_device(x.data_ptr(), B, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr())
+        ctx.sync(); wall[v].append((time.perf_counter() - t0) / 20 * 1e3)
+for v in variants:
+    print("variant %d: wall ms/step %s" % (v, " ".join("%.4f" % w for w in wall[v])), flush=True)
 for v in variants:
     a = np.array(results[v])
     med = np.median(a, axis=0)
