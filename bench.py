@@ -12,9 +12,10 @@ N GPUs   : one process per GPU (torch.distributed.run), streams dealt s mod N, N
 roofline : dominant kernel = the scan (scan_mfma_kernel); achieved = its algorithmic bytes per launch
            (4*resolution + 8*n per item) / its average launch duration, measured with
            hipEvents recorded on the launch stream inside the timed region (baz_music_profile).
-cpu_baseline : rank 0, N=1 only: the plain-C restatement of the reference's work() (oracle/music_ref.c,
-           kind "port"), one work() per item like the GNU Radio scheduler drives the reference, on
-           all host cores (one independent block instance per thread) for a bounded sample.
+cpu_baseline : rank 0, N=1 only: oracle/_ref (the reference's own baz_music_doa.cc compiled in place, kind
+           "reference") when its prebuilt .so is present, else the plain-C restatement (oracle/music_ref.c, kind
+           "port"); one work() per item like the GNU Radio scheduler drives the reference, on all host cores
+           (one independent block instance per thread) for a bounded sample (~2 s per leg).
 """
 import argparse
 import json
@@ -35,26 +36,43 @@ STREAMS_PER_GPU, ITEMS_PER_STREAM = 8, 8192
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(table, seconds_per_thread=2.0):
-    """Oracle leg (the ONLY use of oracle/ in this file): times the C restatement on host cores."""
+def _usable_cpus():
+    """Threads worth starting: the affinity mask, capped by a cgroup CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()            # cgroup v2: "max 100000" | "<quota> <period>"
+        if q[0] != "max":
+            n = min(n, max(1, int(float(q[0]) / float(q[1]) + 0.5)))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
+def _time_cpu(fn, items, table, seconds_per_thread, chunk):
+    """Items/s of `fn` (one work() per item inside) on 1 thread and on all host threads (independent block
+    instances, one per thread -- how T gr-baz blocks would run)."""
     import numpy as np
-    from oracle import music_oracle as mo
-    from oracle import music_ref as mr
-    sample = 512
-    items = mo.synth_items(sample, M, NSAMPLES, mo.array_geometry(M), FREQUENCY, SPACING, seed=1002)
-    mr.work_batch(items[:16], table, M, N_EMIT)            # warm-up / page-in
+    sample = items.shape[0]
+    fn(items[:16], table, M, N_EMIT)                       # warm-up / page-in
     t0 = time.perf_counter()
-    mr.work_batch(items, table, M, N_EMIT)
+    fn(items, table, M, N_EMIT)
     one = sample / (time.perf_counter() - t0)
-    cores = os.cpu_count() or 1
+    cores = _usable_cpus()
     counts = [0] * cores
     stop_at = time.perf_counter() + seconds_per_thread
 
     def worker(i):
-        x = np.ascontiguousarray(items[(i * 37) % sample:] if (i * 37) % sample < sample - 64 else items)
+        o = (i * 37) % (sample - chunk)
+        x = np.ascontiguousarray(items[o:o + chunk])
         while time.perf_counter() < stop_at:
-            mr.work_batch(x[:64], table, M, N_EMIT)        # ctypes releases the GIL
-            counts[i] += 64
+            fn(x, table, M, N_EMIT)                        # ctypes releases the GIL
+            counts[i] += chunk
 
     th = [threading.Thread(target=worker, args=(i,)) for i in range(cores)]
     t0 = time.perf_counter()
@@ -63,10 +81,43 @@ def cpu_baseline(table, seconds_per_thread=2.0):
     for t in th:
         t.join()
     dt = time.perf_counter() - t0
-    return {"value": sum(counts) / dt, "unit": "snapshots/s", "cores": cores, "kind": "port",
-            "value_1thread": one,
-            "sample": "%d items in %.1f s on %d threads (+%d items on 1 thread); oracle/music_ref.c, "
-                      "one work() per item, cfg2 inputs" % (sum(counts), dt, cores, sample)}
+    return sum(counts) / dt, one, cores, sum(counts), dt
+
+
+def cpu_baseline(table, seconds_per_thread=2.0):
+    """Oracle leg (the ONLY use of oracle/ in this file): times the CPU path on the host cores.
+    kind "reference": oracle/_ref = the reference's own lib/baz_music_doa.cc compiled in place (prebuilt .so, travels
+    with the snapshot), arma::eig_sym backed by LAPACK zheev (scipy's OpenBLAS) when loadable, else the shim's Jacobi.
+    kind "port": oracle/music_ref.c, the plain-C restatement (used when oracle/_ref is not there; always reported)."""
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    from oracle import music_oracle as mo
+    from oracle import music_ref as mr
+    sample = 512
+    items = mo.synth_items(sample, M, NSAMPLES, mo.array_geometry(M), FREQUENCY, SPACING, seed=1002)
+    pv, pone, cores, pn, pdt = _time_cpu(mr.work_batch, items, table, seconds_per_thread, 64)
+    out = {"value": pv, "unit": "snapshots/s", "cores": cores, "kind": "port", "value_1thread": pone,
+           "sample": "%d items in %.1f s on %d threads (+%d items on 1 thread); oracle/music_ref.c, "
+                     "one work() per item, cfg2 inputs" % (pn, pdt, cores, sample)}
+    if mr.have_ref():
+        try:
+            lapack = mr.ref_use_lapack(True)
+            saved = os.dup(2)                              # the reference prints a banner per block instance
+            devnull = os.open(os.devnull, os.O_WRONLY)
+            os.dup2(devnull, 2)
+            try:
+                rv, rone, cores, rn, rdt = _time_cpu(mr.ref_work_batch, items, table, seconds_per_thread, 64)
+            finally:
+                os.dup2(saved, 2)
+                os.close(saved)
+                os.close(devnull)
+            out = {"value": rv, "unit": "snapshots/s", "cores": cores, "kind": "reference", "value_1thread": rone,
+                   "eig_backend": "LAPACKE_zheev (scipy OpenBLAS)" if lapack else "Jacobi (oracle/ref_shim)",
+                   "port_value": pv, "port_value_1thread": pone,
+                   "sample": "%d items in %.1f s on %d threads (+%d items on 1 thread); oracle/_ref = the reference's "
+                             "baz_music_doa.cc, one work() per item, cfg2 inputs" % (rn, rdt, cores, sample)}
+        except Exception as e:                             # keep the port figure if _ref cannot run here
+            out["reference_error"] = repr(e)
+    return out
 
 
 def main():

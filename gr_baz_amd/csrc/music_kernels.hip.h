@@ -322,11 +322,13 @@ __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict_
     int ex = 0;
     (void)frexp(dmax, &ex);
     const double scl = (dmax > 0.0 && dmax < __builtin_huge_val()) ? ldexp(1.0, -ex) : 1.0;
+    double psum = 0.0;
 #pragma unroll
     for (int i = 0; i < M; ++i)
 #pragma unroll
         for (int j = 0; j < M; ++j) {
             const double2 v = Rp[i * M + j];
+            psum += v.x + v.y;
             h.Ar[i][j] = v.x * scl;
             h.Ai[i][j] = (i == j) ? 0.0 : v.y * scl;
             h.Vr[i][j] = (i == j) ? 1.0 : 0.0;
@@ -345,6 +347,9 @@ __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict_
         if (__all(done)) break;
         jacobi_sweep<M, UNROLL>(h);
     }
+    // A covariance with NaN/Inf entries has no eigen-decomposition (the reference's eig_sym fails there): poison the
+    // projector so that the item's spectrum is NaN and no bin is ever inserted (.cc:131) -> (0, 0) outputs.
+    const double poison = psum * 0.0;             // NaN iff some entry is NaN or +-Inf, else +-0
 
     // ascending rank of each eigenvalue (ties -> lower column first), noise = rank < m-n
     double wk[M];
@@ -372,10 +377,10 @@ __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict_
             }
             if (valid) {
                 if (i == j) {
-                    Qs[(size_t)(i * M + i) * qstride + item] = re;
+                    Qs[(size_t)(i * M + i) * qstride + item] = re + poison;
                 } else {
-                    Qs[(size_t)(i * M + j) * qstride + item] = 2.0 * re;
-                    Qs[(size_t)(j * M + i) * qstride + item] = -2.0 * im;
+                    Qs[(size_t)(i * M + j) * qstride + item] = 2.0 * re + poison;
+                    Qs[(size_t)(j * M + i) * qstride + item] = -2.0 * im + poison;
                 }
             }
         }
@@ -414,15 +419,22 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
 
     if (lane_used) {
         const double2* Rp = R + (size_t)itc * MM + j * M;
+        double rsum = 0.0;
 #pragma unroll
         for (int k = 0; k < M; ++k) {
             double2 v = Rp[k];
+            rsum += v.x + v.y;
             if (k == j) v.y = 0.0;
             A[j][k] = v;
             V[j][k] = make_double2(k == j ? 1.0 : 0.0, 0.0);
         }
+        sPart[sl][j] = rsum * 0.0;      // NaN iff this row holds a NaN / Inf
     }
     wave_lds_fence();
+    // non-finite covariance -> poisoned projector (see evd_proj_kernel)
+    double poison = 0.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) poison += sPart[sl][k];
     // exact power-of-two normalisation (see evd_proj_kernel)
     double dmax = 0.0;
 #pragma unroll
@@ -532,10 +544,10 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
                 im += msk[k] * (vj[k].y * vl.x - vj[k].x * vl.y);
             }
             if (l == j) {
-                Qs[(size_t)(j * M + j) * qstride + item] = re;
+                Qs[(size_t)(j * M + j) * qstride + item] = re + poison;
             } else {
-                Qs[(size_t)(j * M + l) * qstride + item] = 2.0 * re;
-                Qs[(size_t)(l * M + j) * qstride + item] = -2.0 * im;
+                Qs[(size_t)(j * M + l) * qstride + item] = 2.0 * re + poison;
+                Qs[(size_t)(l * M + j) * qstride + item] = -2.0 * im + poison;
             }
         }
     }

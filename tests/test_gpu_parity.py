@@ -203,6 +203,34 @@ def test_zero_input_and_scaling(gpu_device):
     assert np.all(np.isfinite(sz))
 
 
+@pytest.mark.parametrize("cfg", ["cfg1", "m8_small"])
+def test_non_finite_items_stay_isolated(cfg, gpu_device):
+    """NaN / Inf samples (the reference would throw inside Armadillo's eig_sym or emit garbage): the poisoned items
+    must not hang the Jacobi loop, must not touch their neighbours (same tile, same wave, same item group), and
+    give an all-NaN spectrum plus the (0, 0) initial DoA pairs of .cc:95 (NaN is never inserted, .cc:131)."""
+    if cfg == "cfg1":
+        c = mo.make_config("cfg1", 70, seed=23)
+    else:                                   # m = 8: LDS multi-lane EVD, one item per covariance tile
+        arr = mo.array_geometry(8)
+        c = dict(m=8, n=2, nsamples=256, res=360, table=mo.steering_table_c64(arr, 360, mo.FREQUENCY, mo.SPACING),
+                 items=mo.synth_items(24, 8, 256, arr, mo.FREQUENCY, mo.SPACING, seed=23))
+    m, n, res = c["m"], c["n"], c["res"]
+    clean = c["items"]
+    dirty = clean.copy()
+    dirty[5, :] = np.nan
+    dirty[6, 3] = np.inf
+    dirty[17, 0] = complex(np.nan, 1.0)
+    dirty[18, -1] = complex(-np.inf, np.inf)
+    bad = [5, 6, 17, 18]
+    good = [i for i in range(clean.shape[0]) if i not in bad]
+    with _capi().Context(m, n, c["nsamples"], res, c["table"]) as ctx:
+        a0, l0, s0 = device_run(ctx, clean, gpu_device)
+        a1, l1, s1 = device_run(ctx, dirty, gpu_device)
+    assert np.array_equal(s0[good], s1[good]) and np.array_equal(a0[good], a1[good]) and np.array_equal(l0[good], l1[good])
+    # a covariance with NaN/Inf entries has no EVD: the projector is poisoned, the spectrum is NaN, nothing is inserted
+    assert np.all(np.isnan(s1[bad])) and np.all(a1[bad] == 0.0) and np.all(l1[bad] == 0.0)
+
+
 # ------------------------------------------------------------------ full-size properties
 @pytest.mark.parametrize("cfg,batch,distinct", [("cfg2", 65536, 256), ("cfg3", 4096, 16)])
 def test_full_size_properties(cfg, batch, distinct, gpu_device):
