@@ -140,17 +140,26 @@ class Context:
         self._chk(lib().baz_music_set_table(self._h, t.view(np.float32).ctypes.data_as(_f32p)),
                   "baz_music_set_table")
 
-    def process(self, items, want_lvl=True, want_spectrum=True):
-        """items: (batch, nsamples) complex64 host array -> (ang, lvl|None, spectrum|None)."""
+    def process(self, items, want_lvl=True, want_spectrum=True, out=None):
+        """items: (batch, nsamples) complex64 host array -> (ang, lvl|None, spectrum|None).
+        out: optional (ang, lvl|None, spectrum|None) float32 C-contiguous arrays to write into (a scheduler's
+        persistent buffers; page-locked ones are handed to the DMA engines without staging)."""
         x = np.ascontiguousarray(np.asarray(items, dtype=np.complex64))
         if x.ndim == 1:
             x = x[None, :]
         if x.shape[1] != self.nsamples:
             raise ValueError("items must be (batch, %d) complex64" % self.nsamples)
         B = x.shape[0]
-        ang = np.zeros((B, self.n), np.float32)
-        lvl = np.zeros((B, self.n), np.float32) if want_lvl else None
-        spec = np.zeros((B, self.res), np.float32) if want_spectrum else None
+        if out is not None:
+            ang, lvl, spec = out
+            want_lvl, want_spectrum = lvl is not None, spec is not None
+            for a, cols in ((ang, self.n), (lvl, self.n), (spec, self.res)):
+                if a is not None and (a.dtype != np.float32 or not a.flags["C_CONTIGUOUS"] or a.shape != (B, cols)):
+                    raise ValueError("out arrays must be C-contiguous float32 of shape (batch, n|n|resolution)")
+        else:
+            ang = np.zeros((B, self.n), np.float32)
+            lvl = np.zeros((B, self.n), np.float32) if want_lvl else None
+            spec = np.zeros((B, self.res), np.float32) if want_spectrum else None
         r = lib().baz_music_process(
             self._h, x.view(np.float32).ctypes.data_as(_f32p), B, ang.ctypes.data_as(_f32p),
             lvl.ctypes.data_as(_f32p) if want_lvl else None,

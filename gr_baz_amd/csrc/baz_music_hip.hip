@@ -64,6 +64,7 @@ struct baz_music_ctx {
     std::mutex mtx;   // serialises set_table against process*, like d_mutex (.cc:67,101)
     int profiling = 0;      // 0 off, 1 every stage, 2 only the dominant (scan) stage
     int lab_variant = 0;
+    size_t chunk_bytes = 0;   // host-fed path: traffic per pipelined chunk (BAZ_MUSIC_CHUNK_MIB); 0 = by buffer kind
     StageProf prof[BAZ_MUSIC_NUM_STAGES];
     std::string stage_name[BAZ_MUSIC_NUM_STAGES];
     char hip_err[256] = {0};
@@ -428,6 +429,18 @@ int ensure_slots(baz_music_ctx* c, uint32_t chunk, bool want_spec)
     return BAZ_MUSIC_OK;
 }
 
+// Is this caller pointer page-locked (hipHostMalloc / hipHostRegister / torch pinned memory)?
+bool is_pinned_host(const void* p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();     // plain pageable memory: not an error for us
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
 // One pass of the hot path over `batch` device-resident items: three launches (+ the tiny top-n merge) back
 // to back on the context's stream.  (Cutting the batch into sub-batches and overlapping covariance/EVD of
 // sub-batch i+1 with the scan of sub-batch i on two extra streams was measured and is SLOWER -- 0.53 ms ->
@@ -481,6 +494,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     c->m = m; c->n = n; c->nsamples = nsamples; c->res = resolution; c->K = nsamples / m;
     c->device = dev;
     if (const char* v = getenv("BAZ_MUSIC_SCAN_VARIANT")) c->lab_variant = atoi(v);
+    if (const char* v = getenv("BAZ_MUSIC_CHUNK_MIB")) c->chunk_bytes = (size_t)std::max(1, std::min(1024, atoi(v))) << 20;
     DeviceGuard guard(dev);
     int r = BAZ_MUSIC_OK;
     do {
@@ -586,9 +600,14 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
 
-    // chunks of <= ~64 MiB of traffic each: big enough to amortise launches, small enough to overlap
+    // chunks of ~BAZ_MUSIC_CHUNK_MIB of traffic each (>= 64 items): a GNU Radio work() call of a few thousand items
+    // still becomes several chunks, so that H2D of chunk i+1, the kernels of chunk i and D2H of chunk i-1 overlap
+    // (measured, profiles/r01h_hostfed_chunk_sweep.txt: pageable buffers want big chunks -- the runtime's pageable copy
+    // has a large fixed cost --, page-locked ones overlap best at 16-32 MiB)
     const size_t per_item = (size_t)c->nsamples * 8 + (size_t)c->res * 4 + (size_t)c->n * 8;
-    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(batch, (64u << 20) / per_item));
+    size_t chunk_bytes = c->chunk_bytes;
+    if (!chunk_bytes) chunk_bytes = (is_pinned_host(in_ri) && (!spectrum || is_pinned_host(spectrum))) ? (32u << 20) : (64u << 20);
+    const uint32_t chunk = (uint32_t)std::min<size_t>(batch, std::max<size_t>(64, chunk_bytes / per_item));
     const bool want_spec = spectrum != nullptr;
     int r = ensure_slots(c, chunk, want_spec);
     if (r) return r;
