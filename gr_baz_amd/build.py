@@ -2,6 +2,7 @@
 
   csrc/libbaz_music_hip.so   HIP kernels + the C-ABI of include/baz_music_hip.h   (hipcc)
   csrc/libbaz_agc_hip.so     AGC kernels + the C-ABI of include/baz_agc_hip.h      (hipcc)
+  csrc/libbaz_resamp_hip.so  fractional resampler kernel + the C-ABI of include/baz_resamp_hip.h (hipcc)
   host/libgnuradio_baz_music.so   the gr::sync_block host block on the GNU Radio API shim (g++)
   host/_baz_music*.so        pybind11 module exposing baz.music_doa (SWIG stand-in)
 
@@ -23,6 +24,7 @@ INCLUDE = os.path.join(ROOT, "include")
 
 HIP_LIB = os.path.join(CSRC, "libbaz_music_hip.so")
 AGC_LIB = os.path.join(CSRC, "libbaz_agc_hip.so")
+RESAMP_LIB = os.path.join(CSRC, "libbaz_resamp_hip.so")
 HOST_LIB = os.path.join(HOST, "libgnuradio_baz_music.so")
 
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in VGPRs (gfx950 has a unified file): no v_accvgpr_read per result
@@ -56,6 +58,13 @@ def build_hip(force=False, verbose=False):
                 os.path.join(INCLUDE, "baz_agc_hip.h")]
     if force or _newer(AGC_LIB, agc_srcs):
         cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", AGC_LIB, agc_srcs[0]]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
+    rs_srcs = [os.path.join(CSRC, "baz_resamp_hip.hip"), os.path.join(CSRC, "resamp_kernels.hip.h"),
+               os.path.join(INCLUDE, "baz_resamp_hip.h")]
+    if force or _newer(RESAMP_LIB, rs_srcs):
+        cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", RESAMP_LIB, rs_srcs[0]]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=CSRC)

@@ -1,0 +1,73 @@
+// resamp_kernels.hip.h -- gfx950 kernel for gr-baz's fractional resampler (config 5 front-end).
+//
+// Replaces the one-input loop of fractional_resampler_cc_impl::general_work
+// (/root/reference/lib/baz_fractional_resampler_cc.cc:162-203):
+//     out[oo++] = d_resamp->interpolate(&in[ii], d_mu);            (.cc:172; gnuradio-filter MMSE interpolator)
+//     s = d_mu + d_mu_inc (+ d_mu_adj once); f = floor(s); ii += (int)f; d_mu = s - f;        (.cc:183-193)
+// The phase recurrence is a sum, so output o is evaluated independently: P_o = base + o * inc in 64.64-bit fixed
+// point (ii_o = integer part, mu_o = fraction), exactly the reference's x87 sequence whenever that one is exact
+// (include/baz_resamp_hip.h).  One thread per (output, stream); a block's input window is contiguous
+// (256 outputs span <= 256*ratio + 8 samples) and is read through L1/L2 -- 8 overlapping float2 loads per output,
+// HBM sees every input once.  The 129 x 8 tap table (4 KiB) sits in LDS.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bazresamp {
+
+constexpr int RS_NTAPS = 8;
+constexpr int RS_NSTEPS = 128;
+constexpr int RS_BLOCK = 256;
+
+struct PhaseParams {
+    uint64_t first_lo, first_hi;   // P_0 = mu of the first output (64.64): hi = integer part, lo = fraction
+    uint64_t base_lo, base_hi;     // P_o = base + (o - 1) * inc for o >= 1 (base = P_0 + inc + adjustment)
+    uint64_t inc_lo, inc_hi;
+};
+
+__device__ __forceinline__ void phase_of(const PhaseParams& p, uint32_t o, uint64_t& ipart, uint64_t& frac)
+{
+    if (o == 0) { ipart = p.first_hi; frac = p.first_lo; return; }
+    const uint64_t j = (uint64_t)o - 1u;
+    const uint64_t plo = j * p.inc_lo;                        // low 64 bits of j * inc_lo
+    const uint64_t phi = __umul64hi(j, p.inc_lo);             // its carry into the integer part
+    const uint64_t lo = p.base_lo + plo;
+    const uint64_t carry = lo < plo ? 1u : 0u;
+    frac = lo;
+    ipart = p.base_hi + j * p.inc_hi + phi + carry;
+}
+
+__global__ __launch_bounds__(RS_BLOCK) void resamp_kernel(const float2* __restrict__ in, uint64_t in_stride,
+                                                           float2* __restrict__ out, uint64_t out_stride,
+                                                           uint32_t noutput, PhaseParams p,
+                                                           const float* __restrict__ taps)
+{
+    __shared__ float st[(RS_NSTEPS + 1) * RS_NTAPS];
+    for (int i = threadIdx.x; i < (RS_NSTEPS + 1) * RS_NTAPS; i += RS_BLOCK) st[i] = taps[i];
+    __syncthreads();
+    const uint32_t o = blockIdx.x * RS_BLOCK + threadIdx.x;
+    if (o >= noutput) return;
+    const uint32_t stream = blockIdx.y;
+    uint64_t ii, frac;
+    phase_of(p, o, ii, frac);
+    // (float)d_mu: round-to-nearest-even of the 64-bit fraction, like the x87 -> float conversion at .cc:172
+    const float mu = __ull2float_rn(frac) * 5.42101086242752217e-20f;   // * 2^-64 (exact)
+    const int imu = __float2int_rn(mu * (float)RS_NSTEPS);              // rint(mu * NSTEPS), ties to even
+    const float* t = st + imu * RS_NTAPS;
+    const float2* x = in + (size_t)stream * in_stride + ii;
+    float re = 0.0f, im = 0.0f;
+    {
+#pragma clang fp contract(off)   // float multiply, then float add, like the reference's FIR kernel (no fma)
+#pragma unroll
+        for (int k = 0; k < RS_NTAPS; ++k) {
+            const float2 v = x[k];
+            const float w = t[RS_NTAPS - 1 - k];                        // the FIR kernel stores its taps reversed
+            re = re + v.x * w;
+            im = im + v.y * w;
+        }
+    }
+    out[(size_t)stream * out_stride + o] = make_float2(re, im);
+}
+
+}  // namespace bazresamp

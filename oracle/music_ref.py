@@ -21,7 +21,7 @@ def build(force=False):
     """Compile the oracle libraries (gcc/g++ only).  Building the checker is not using it."""
     if force or not os.path.exists(_LIB) or \
             os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "music_ref.c")):
-        subprocess.check_call(["make", "-C", _HERE, "libmusic_ref.so", "libagc_ref.so"])
+        subprocess.check_call(["make", "-C", _HERE, "libmusic_ref.so", "libagc_ref.so", "libresamp_ref.so"])
     if os.path.isdir("/root/reference") and os.path.isdir(os.path.join(_HERE, "ref_shim")):
         subprocess.check_call(["make", "-C", _HERE, "ref"])
 

@@ -17,9 +17,9 @@ def pytest_configure(config):
 
 
 def golden_names():
-    """MUSIC-DoA fixtures (the agc_* fixtures belong to tests/test_agc.py)."""
+    """MUSIC-DoA fixtures (agc_* and resamp_* fixtures belong to tests/test_agc.py, tests/test_resamp.py)."""
     return sorted(n for n in (os.path.splitext(os.path.basename(p))[0]
-                              for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))) if not n.startswith("agc_"))
+                              for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))) if not n.startswith(("agc_", "resamp_")))
 
 
 def load_golden(name):

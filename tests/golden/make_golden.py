@@ -64,7 +64,62 @@ def agc_fixture(name, rate, reference, calls, seed):
     print("%-28s calls %s  %6.1f KiB" % (name, list(calls), os.path.getsize(path) / 1024))
 
 
+def resamp_signal(n, seed):
+    """complex baseband occupying about a quarter of the band (the MMSE table is designed for |f| <= 1/4)"""
+    rng = np.random.default_rng(seed)
+    w = rng.standard_normal(n + 64) + 1j * rng.standard_normal(n + 64)
+    h = np.sinc(0.25 * (np.arange(65) - 32)) * np.hamming(65) * 0.25
+    return np.convolve(w, h, mode="valid")[:n].astype(np.complex64)
+
+
+RESAMP_EVENTS = {"set_mu": 1, "set_ratio": 2, "adjust": 3, "set_rational": 4}
+
+
+def resamp_apply_event(blk, kind, a, b):
+    if kind == 1: blk.set_mu(float(a))
+    elif kind == 2: blk.set_resamp_ratio(float(a))
+    elif kind == 3: blk.adjust(float(a))
+    elif kind == 4: blk.set_resamp_ratio_rational(int(a), int(b))
+
+
+def resamp_fixture(name, phase, ratio, num, denom, calls, events, seed, nin=18000):
+    """calls: noutput of consecutive general_work() calls on ONE block instance; events: (before_call, kind, a, b).
+    Outputs come from oracle/_ref/libbaz_resamp_ref.so == the reference's own
+    lib/baz_fractional_resampler_cc.cc::general_work() (its MMSE interpolator is the shim, see oracle/resamp_ref.c:
+    PARITY UNPINNED with respect to a real gnuradio-filter)."""
+    from oracle import resamp_ref as rr
+    x = resamp_signal(nin, seed)
+    blk = rr.RefResampler(phase, ratio, num, denom)
+    outs, cons, mus = [], [], []
+    pos = 0
+    for i, c in enumerate(calls):
+        for (ci, kind, a, b) in events:
+            if ci == i:
+                resamp_apply_event(blk, kind, a, b)
+        o, k = blk.work(x[pos:], c)
+        outs.append(o); cons.append(k); mus.append(blk.mu())
+        pos += k
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, x=x, out=np.concatenate(outs), calls=np.asarray(calls), consumed=np.asarray(cons),
+                        mu_after=np.asarray(mus), events=np.asarray(events, dtype=np.float64).reshape(-1, 4),
+                        phase=np.float64(phase), ratio=np.float64(ratio), num=np.uint64(num), denom=np.uint64(denom),
+                        generator="oracle/_ref (reference lib/baz_fractional_resampler_cc.cc::general_work on API shim; "
+                                  "MMSE interpolator = closed-form table, parity unpinned)")
+    print("%-28s calls %s consumed %s  %6.1f KiB" % (name, list(calls), cons, os.path.getsize(path) / 1024))
+
+
+def resamp_fixtures():
+    resamp_fixture("resamp_ratio1.25", 0.0, 1.25, 0, 0, (4000, 1, 255, 256, 257, 9000), [], 4001)
+    resamp_fixture("resamp_interp0.73_phase0.3", 0.3, 0.73, 0, 0, (5000, 7000), [], 4002)
+    resamp_fixture("resamp_48k_to_44k1", 0.0, 0.0, 48000, 44100, (3000, 3000, 3000), [], 4003)
+    resamp_fixture("resamp_setters", 0.5, 1.0000123, 0, 0, (2000, 2000, 2000, 2000, 2000),
+                   [(1, 2, 1.5, 0), (2, 1, 0.125, 0), (3, 3, 0.75, 0), (4, 4, 3, 2), (4, 3, -0.25, 0)], 4004)
+
+
 def main():
+    if "--resamp-only" in sys.argv:
+        resamp_fixtures()
+        return
     if not mr.have_ref():
         mr.build()
     if not mr.have_ref():
@@ -102,6 +157,8 @@ def main():
     agc_fixture("agc_default_rate1e-4", 1e-4, 1.0, (12000,), 3001)
     agc_fixture("agc_stateful_rate1e-2", 1e-2, 0.5, (1, 4095, 4096, 4097, 3, 5000), 3002)
     agc_fixture("agc_fast_rate0.5", 0.5, 2.0, (100, 9000), 3003)
+    # fractional_resampler_cc
+    resamp_fixtures()
 
 
 if __name__ == "__main__":
