@@ -29,7 +29,8 @@ music_doa = _native.music_doa
 baz_music_doa_sptr = _native.baz_music_doa_sptr
 agc_cc = _native.agc_cc                    # GR_SWIG_BLOCK_MAGIC(baz, agc_cc) in the reference
 baz_agc_cc_sptr = _native.baz_agc_cc_sptr
+fractional_resampler_cc = _native.fractional_resampler_cc   # GR_SWIG_BLOCK_MAGIC2(baz, fractional_resampler_cc)
 
 from . import music_doa_helper  # noqa: E402,F401
 
-__all__ = ["music_doa", "baz_music_doa_sptr", "music_doa_helper", "agc_cc", "baz_agc_cc_sptr"]
+__all__ = ["music_doa", "baz_music_doa_sptr", "music_doa_helper", "agc_cc", "baz_agc_cc_sptr", "fractional_resampler_cc"]

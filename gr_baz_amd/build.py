@@ -80,14 +80,16 @@ def build_host(force=False, verbose=False):
     """C++ host block (gr::sync_block surface) + pybind11 module; both link libbaz_music_hip.so."""
     block_srcs = [os.path.join(HOST, "baz_music_doa.cc"), os.path.join(HOST, "baz_music_doa.h"),
                   os.path.join(INCLUDE, "baz_music_hip.h"), os.path.join(HOST, "baz_agc_cc.cc"),
-                  os.path.join(HOST, "baz_agc_cc.h"), os.path.join(INCLUDE, "baz_agc_hip.h")]
+                  os.path.join(HOST, "baz_agc_cc.h"), os.path.join(INCLUDE, "baz_agc_hip.h"),
+                  os.path.join(HOST, "baz_fractional_resampler_cc.cc"), os.path.join(HOST, "baz_fractional_resampler_cc.h"),
+                  os.path.join(INCLUDE, "baz_resamp_hip.h")]
     if not os.path.exists(block_srcs[0]):
         return None
     shim_inc = os.path.join(HOST, "gr_shim")
     common = ["-O2", "-std=c++14", "-fPIC", "-I", INCLUDE, "-I", HOST, "-I", shim_inc]
-    link = ["-L", CSRC, "-lbaz_music_hip", "-lbaz_agc_hip", "-Wl,-rpath,$ORIGIN/../csrc"]
-    if force or _newer(HOST_LIB, block_srcs + [HIP_LIB, AGC_LIB]):
-        cmd = ["g++"] + common + ["-shared", "-o", HOST_LIB, block_srcs[0], block_srcs[3]] + link
+    link = ["-L", CSRC, "-lbaz_music_hip", "-lbaz_agc_hip", "-lbaz_resamp_hip", "-Wl,-rpath,$ORIGIN/../csrc"]
+    if force or _newer(HOST_LIB, block_srcs + [HIP_LIB, AGC_LIB, RESAMP_LIB]):
+        cmd = ["g++"] + common + ["-shared", "-o", HOST_LIB, block_srcs[0], block_srcs[3], block_srcs[6]] + link
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=HOST)

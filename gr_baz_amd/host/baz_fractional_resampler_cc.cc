@@ -1,0 +1,86 @@
+/* -*- c++ -*- */
+/* Host side of the MI355X fractional resampler: buffer marshalling across include/baz_resamp_hip.h.  Mirrors
+ * /root/reference/lib/baz_fractional_resampler_cc.cc:73-101 (make, constructor: block name, ports, ratio rules,
+ * banner, relative rate), :141-149 (forecast), :152-203 (general_work, one-input branch; the arithmetic runs in the
+ * HIP kernel) and :220-254 (accessors, deferred setters). */
+#include <baz_fractional_resampler_cc.h>
+#include <baz_resamp_hip.h>
+
+#include <gnuradio/io_signature.h>
+
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace gr {
+namespace baz {
+
+class fractional_resampler_cc_impl : public fractional_resampler_cc
+{
+    baz_resamp_ctx* d_ctx;
+
+public:
+    fractional_resampler_cc_impl(double phase_shift, double resamp_ratio, unsigned long long num, unsigned long long denom)
+        : block("fractional_resampler_cc", io_signature::make(1, 1, sizeof(gr_complex)),
+                io_signature::make(1, 1, sizeof(gr_complex))),
+          d_ctx(NULL)
+    {
+        const int rc = baz_resamp_create(&d_ctx, 1, phase_shift, resamp_ratio, num, denom, -1);
+        if (rc == BAZ_RESAMP_E_INVALID)   /* .cc:94-97 */
+            throw std::out_of_range("resampling ratio must be > 0 and phase shift ratio must be >= 0 and <= 1");
+        if (rc != BAZ_RESAMP_OK)
+            throw std::runtime_error(std::string("fractional_resampler_cc: cannot open the gfx950 engine: ") +
+                                     baz_resamp_strerror(rc));
+        set_relative_rate(1.0 / baz_resamp_ratio(d_ctx));   /* .cc:99 */
+    }
+    ~fractional_resampler_cc_impl() { baz_resamp_destroy(d_ctx); }
+
+    void forecast(int noutput_items, gr_vector_int& ninput_items_required)   /* .cc:141-149 */
+    {
+        const int need = (int)baz_resamp_forecast(d_ctx, (uint32_t)(noutput_items > 0 ? noutput_items : 0));
+        for (size_t i = 0; i < ninput_items_required.size(); ++i) ninput_items_required[i] = need;
+    }
+
+    int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
+                     gr_vector_void_star& output_items)
+    {
+        if (noutput_items <= 0) return 0;
+        uint64_t consumed = 0;
+        const int64_t produced = baz_resamp_process(d_ctx, static_cast<const float*>(input_items[0]),
+                                                    (uint64_t)ninput_items[0], (uint64_t)ninput_items[0],
+                                                    static_cast<float*>(output_items[0]), (uint64_t)noutput_items,
+                                                    (uint32_t)noutput_items, &consumed);
+        if (produced < 0) {
+            fprintf(stderr, "[%s<%li>] device error: %s\n", name().c_str(), unique_id(), baz_resamp_strerror((int)produced));
+            return -1;
+        }
+        set_relative_rate(1.0 / baz_resamp_ratio(d_ctx));   /* .cc:178 (after a ratio update) */
+        consume_each((int)consumed);                         /* .cc:201 */
+        return (int)produced;
+    }
+
+    long double mu() const { return baz_resamp_mu(d_ctx); }                 /* .cc:220-224 */
+    long double resamp_ratio() const { return baz_resamp_ratio(d_ctx); }    /* .cc:226-230 */
+    void set_mu(long double mu) { check(baz_resamp_set_mu(d_ctx, (double)mu)); }
+    void set_resamp_ratio(long double r) { check(baz_resamp_set_ratio(d_ctx, (double)r)); }
+    void set_resamp_ratio(double r) { set_resamp_ratio((long double)r); }
+    void set_resamp_ratio(unsigned long long num, unsigned long long denom) { check(baz_resamp_set_ratio_rational(d_ctx, num, denom)); }
+    void handle_ppb(long whole, double frac) { check(baz_resamp_set_ratio_ppb(d_ctx, whole, frac)); }
+    void handle_adjust(double d) { check(baz_resamp_adjust(d_ctx, d)); }
+
+private:
+    static void check(int rc)
+    {
+        if (rc != BAZ_RESAMP_OK) throw std::out_of_range(std::string("fractional_resampler_cc: ") + baz_resamp_strerror(rc));
+    }
+};
+
+fractional_resampler_cc::sptr fractional_resampler_cc::make(double phase_shift, double resamp_ratio,
+                                                            unsigned long long resamp_ratio_num,
+                                                            unsigned long long resamp_ratio_denom)
+{
+    return gnuradio::get_initial_sptr(new fractional_resampler_cc_impl(phase_shift, resamp_ratio, resamp_ratio_num, resamp_ratio_denom));
+}
+
+}  // namespace baz
+}  // namespace gr

@@ -4,6 +4,7 @@
  * test/demo convenience that drives the block's virtual work() the way the GNU Radio scheduler
  * does (pointer vectors into numpy buffers). */
 #include <baz_agc_cc.h>
+#include <baz_fractional_resampler_cc.h>
 #include <baz_music_doa.h>
 
 #include <pybind11/complex.h>
@@ -69,6 +70,29 @@ py::tuple drive_agc(agc_handle& h, py::array_t<std::complex<float>, py::array::c
     return py::make_tuple(produced, out, n_outputs > 1 ? py::object(env) : none, n_outputs > 2 ? py::object(mul) : none);
 }
 
+struct resamp_handle {
+    gr::baz::fractional_resampler_cc::sptr blk;
+};
+
+// one general_work() call the way the scheduler issues it: forecast()-sized input window, consume_each() reported
+py::tuple drive_resamp(resamp_handle& h, py::array_t<std::complex<float>, py::array::c_style | py::array::forcecast> x, int noutput)
+{
+    py::buffer_info bi = x.request();
+    gr_vector_int nin(1, (int)bi.size);
+    gr_vector_int need(1, 0);
+    h.blk->forecast(noutput, need);
+    if ((int)bi.size < need[0]) throw std::invalid_argument("general_work needs forecast(noutput) input items");
+    py::array_t<std::complex<float>> out((size_t)(noutput > 0 ? noutput : 0));
+    gr_vector_const_void_star in(1, bi.ptr);
+    gr_vector_void_star outs(1, out.mutable_data());
+    int produced;
+    {
+        py::gil_scoped_release nogil;
+        produced = h.blk->general_work(noutput, nin, in, outs);
+    }
+    return py::make_tuple(produced, out, h.blk->last_consumed());
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_baz_music, mod)
@@ -99,6 +123,28 @@ PYBIND11_MODULE(_baz_music, mod)
             return py::make_tuple(h.blk->output_signature()->min_streams(), h.blk->output_signature()->max_streams());
         })
         .def("work", &drive_agc, py::arg("items"), py::arg("n_outputs") = 3);
+    py::class_<resamp_handle>(mod, "fractional_resampler_cc_sptr")
+        .def("name", [](resamp_handle& h) { return h.blk->name(); })
+        .def("input_item_sizes", [](resamp_handle& h) { return h.blk->input_signature()->sizeof_stream_items(); })
+        .def("output_item_sizes", [](resamp_handle& h) { return h.blk->output_signature()->sizeof_stream_items(); })
+        .def("relative_rate", [](resamp_handle& h) { return h.blk->relative_rate(); })
+        .def("forecast", [](resamp_handle& h, int n) { gr_vector_int r(1, 0); h.blk->forecast(n, r); return r[0]; })
+        .def("mu", [](resamp_handle& h) { return (double)h.blk->mu(); })
+        .def("resamp_ratio", [](resamp_handle& h) { return (double)h.blk->resamp_ratio(); })
+        .def("set_mu", [](resamp_handle& h, double mu) { h.blk->set_mu((long double)mu); })
+        .def("set_resamp_ratio", [](resamp_handle& h, double r) { h.blk->set_resamp_ratio(r); })
+        .def("set_resamp_ratio", [](resamp_handle& h, unsigned long long n, unsigned long long d) { h.blk->set_resamp_ratio(n, d); })
+        .def("handle_ppb", [](resamp_handle& h, long w, double f) { h.blk->handle_ppb(w, f); })
+        .def("handle_adjust", [](resamp_handle& h, double d) { h.blk->handle_adjust(d); })
+        .def("general_work", &drive_resamp, py::arg("items"), py::arg("noutput_items"));
+    // swig/baz_swig.i:964-966: GR_SWIG_BLOCK_MAGIC2(baz, fractional_resampler_cc) -> baz.fractional_resampler_cc(...)
+    mod.def("fractional_resampler_cc",
+            [](double phase_shift, double resamp_ratio, unsigned long long num, unsigned long long denom) {
+                resamp_handle h;
+                h.blk = gr::baz::fractional_resampler_cc::make(phase_shift, resamp_ratio, num, denom);
+                return h;
+            },
+            py::arg("phase_shift"), py::arg("resamp_ratio"), py::arg("resamp_ratio_num") = 0ull, py::arg("resamp_ratio_denom") = 0ull);
     // swig/baz_swig.i: GR_SWIG_BLOCK_MAGIC(baz, agc_cc) -> baz.agc_cc(rate, reference, gain, max_gain)
     mod.def("agc_cc",
             [](float rate, float reference, float gain, float max_gain) {

@@ -193,3 +193,42 @@ def test_hip_rejects_what_the_reference_rejects(gpu_device):
             resamp.Resampler(*args)
     with pytest.raises(resamp.ResampError):
         resamp.Resampler(0.0, 1e-5)               # below 2^-11: not representable on the 64.64 grid
+
+
+# ------------------------------------------------------------------ host block (gr::block surface, pybind = SWIG stand-in)
+def test_host_block_surface_and_constructor_rules():
+    from gr_baz_amd import baz
+    assert callable(baz.fractional_resampler_cc)          # swig/baz_swig.i:966
+    with pytest.raises((IndexError, ValueError, RuntimeError)):
+        baz.fractional_resampler_cc(0.0, 0.0)             # std::out_of_range (.cc:94-95) wins over "no device"
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="gfx950"):
+            baz.fractional_resampler_cc(0.0, 1.25)        # no CPU fallback
+
+
+@pytest.mark.gpu
+def test_host_block_general_work_like_the_scheduler(gpu_device, capfd):
+    from gr_baz_amd import baz
+    g = load("resamp_setters")
+    blk = baz.fractional_resampler_cc(float(g["phase"]), float(g["ratio"]))
+    assert blk.name() == "fractional_resampler_cc" and blk.input_item_sizes() == [8] and blk.output_item_sizes() == [8]
+    ref = rr.Resampler(float(g["phase"]), float(g["ratio"]))
+    assert blk.forecast(1000) == ref.forecast(1000) and abs(blk.relative_rate() - 1.0 / float(g["ratio"])) < 1e-12
+    pos = 0
+    for i, c in enumerate(g["calls"]):
+        for (ci, kind, a, b) in g["events"]:
+            if int(ci) == i:
+                k = int(kind)
+                if k == 1: blk.set_mu(float(a))
+                elif k == 2: blk.set_resamp_ratio(float(a))
+                elif k == 3: blk.handle_adjust(float(a))
+                elif k == 4: blk.set_resamp_ratio(int(a), int(b))
+        need = blk.forecast(int(c))
+        produced, out, consumed = blk.general_work(g["x"][pos:pos + need + 4], int(c))
+        lo = int(np.sum(g["calls"][:i]))
+        assert produced == int(c) and consumed == int(g["consumed"][i])
+        assert np.array_equal(out.view(np.uint32), g["out"][lo:lo + int(c)].view(np.uint32))
+        pos += consumed
+    assert abs(blk.mu() - float(g["mu_after"][-1])) < 1e-15 and abs(blk.relative_rate() - 1.0 / 1.5) < 1e-12
+    assert "Ratio" in capfd.readouterr().err      # the constructor banner of .cc:92
