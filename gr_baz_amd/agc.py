@@ -9,7 +9,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbaz_agc_hip.so")
 
-SYMBOLS = ["baz_agc_create", "baz_agc_destroy", "baz_agc_process", "baz_agc_process_device", "baz_agc_reset",
+SYMBOLS = ["baz_agc_create", "baz_agc_destroy", "baz_agc_process", "baz_agc_process_device", "baz_agc_process_device_interleaved", "baz_agc_reset",
            "baz_agc_set_stream", "baz_agc_sync", "baz_agc_count", "baz_agc_strerror"]
 
 _vp = ctypes.c_void_p
@@ -40,6 +40,8 @@ def lib():
     L.baz_agc_process.argtypes = [_vp, _f32p, _u64, _u64, _f32p, _f32p, _f32p]
     L.baz_agc_process_device.restype = ctypes.c_int
     L.baz_agc_process_device.argtypes = [_vp, _vp, _u64, _u64, _vp, _vp, _vp]
+    L.baz_agc_process_device_interleaved.restype = ctypes.c_int
+    L.baz_agc_process_device_interleaved.argtypes = [_vp, _vp, _u64, _u64, _vp]
     L.baz_agc_reset.restype = ctypes.c_int
     L.baz_agc_reset.argtypes = [_vp]
     L.baz_agc_set_stream.restype = ctypes.c_int
@@ -104,6 +106,12 @@ class Agc:
                                          _vp(d_env) if d_env else None, _vp(d_mul) if d_mul else None)
         if r < 0:
             raise AgcError(r, "baz_agc_process_device")
+
+    def process_device_interleaved(self, d_in, n, stride, d_items):
+        """AGC + interleave: d_items[t * nstreams + s] (MUSIC item layout)."""
+        r = lib().baz_agc_process_device_interleaved(self._h, _vp(d_in), n, stride, _vp(d_items))
+        if r < 0:
+            raise AgcError(r, "baz_agc_process_device_interleaved")
 
     def set_stream(self, s):
         lib().baz_agc_set_stream(self._h, _vp(s) if s else None)

@@ -206,4 +206,96 @@ __global__ __launch_bounds__(64) void agc_carry_kernel(const float2* __restrict_
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// Interleaved-output form (config 5: the AGC sits right in front of MUSIC-DoA): the S per-antenna streams leave
+// the AGC already as MUSIC items, out[t*S + s] = agc_s(x_s[t]) -- x(r,c) = in[c*m + r] of lib/baz_music_doa.cc:82-84
+// -- so GNU Radio's interleave / streams_to_vector hop between the two blocks costs no extra pass over HBM.
+// Workgroup = S waves (one per stream), tile = AGC_IT samples per stream: lane l owns AGC_IE consecutive samples
+// (32 B contiguous per lane, 2 KiB contiguous per wave: no LDS needed on the way in).  The tile is transposed in
+// LDS and written as one contiguous block of AGC_IT*S samples (32 KiB at S = 16), 16 B per thread.
+//   agc_tile_kernel<0>  per (tile, stream): the map (A, S) of the tile  -> chunk_pair[stream][tile]
+//   agc_carry_kernel    (shared with the planar form)                   -> carry_in[stream][tile]
+//   agc_tile_kernel<1>  apply + interleave
+// -------------------------------------------------------------------------------------------------------------
+constexpr int AGC_IE = 4;                  // consecutive samples per lane
+constexpr int AGC_IT = 64 * AGC_IE;        // 256 samples per stream per workgroup
+constexpr int AGC_IMAX = 16;               // streams per context in this form
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void agc_tile_kernel(const float2* __restrict__ in, uint64_t n, uint64_t stride,
+                                                         AgcParams P, double2* __restrict__ chunk_pair,
+                                                         const double* __restrict__ carry_in, uint32_t ntiles,
+                                                         float2* __restrict__ out, double* __restrict__ env_state,
+                                                         uint32_t nstreams)
+{
+    extern __shared__ float2 tile[];       // MODE 1: [nstreams][AGC_IT + 1]
+    const int lane = threadIdx.x & 63;
+    const uint32_t stream = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x;
+    const uint64_t base = (uint64_t)t * AGC_IT;
+    const uint32_t valid = (uint32_t)((n - base < (uint64_t)AGC_IT) ? (n - base) : AGC_IT);
+    const int i0 = lane * AGC_IE;
+    const int cnt = ((int)valid - i0) < 0 ? 0 : (((int)valid - i0) > AGC_IE ? AGC_IE : ((int)valid - i0));
+    const float2* __restrict__ xin = in + (size_t)stream * stride + base + i0;
+    float2 x[AGC_IE];
+    double mag[AGC_IE];
+    if (cnt == AGC_IE && (reinterpret_cast<uintptr_t>(xin) & 15u) == 0) {
+#pragma unroll
+        for (int j = 0; j < AGC_IE; j += 2) {
+            const float4 v = *reinterpret_cast<const float4*>(xin + j);
+            x[j] = make_float2(v.x, v.y);
+            x[j + 1] = make_float2(v.z, v.w);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < AGC_IE; ++j) x[j] = (j < cnt) ? xin[j] : make_float2(0.f, 0.f);
+    }
+    double A = 1.0, S = 0.0;
+#pragma unroll
+    for (int j = 0; j < AGC_IE; ++j) {
+        const double d0 = x[j].x, d1 = x[j].y;
+        mag[j] = sqrt(d0 * d0 + d1 * d1);                    // .cc:74-77
+        if (j < cnt) { S = fma(P.a, S, P.b * mag[j]); A *= P.a; }
+    }
+    double Ai = A, Si = S;                                   // inclusive wave scan of the lane maps
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double Ap = __shfl_up(Ai, d, 64), Sp = __shfl_up(Si, d, 64);
+        if (lane >= d) compose(Ai, Si, Ap, Sp);
+    }
+    if (MODE == 0) {
+        if (lane == 63) chunk_pair[(size_t)stream * ntiles + t] = make_double2(Ai, Si);
+        return;
+    }
+    double Ae = __shfl_up(Ai, 1, 64), Se = __shfl_up(Si, 1, 64);
+    if (lane == 0) { Ae = 1.0; Se = 0.0; }
+    double e = fma(Ae, carry_in[(size_t)stream * ntiles + t], Se);   // state entering this lane's run
+    float2* __restrict__ row = tile + (size_t)stream * (AGC_IT + 1);
+#pragma unroll
+    for (int j = 0; j < AGC_IE; ++j) {
+        if (j < cnt) {
+            e = (e * P.a) + (mag[j] * P.b);                   // .cc:82
+            const double gain = P.reference / e;              // .cc:89
+            row[i0 + j] = make_float2((float)((double)x[j].x * gain), (float)((double)x[j].y * gain));   // .cc:97-100
+        }
+    }
+    if (env_state && base + i0 + cnt == n && cnt > 0) env_state[stream] = e;
+    __syncthreads();
+    // contiguous write-out: element p of the tile block is (time p / S, stream p % S)
+    float2* __restrict__ ob = out + (size_t)base * nstreams;
+    const uint32_t total = valid * nstreams;
+    if ((nstreams & 1u) == 0 && (reinterpret_cast<uintptr_t>(ob) & 15u) == 0) {
+        for (uint32_t p = threadIdx.x * 2; p < total; p += blockDim.x * 2) {     // two streams of one time step
+            const uint32_t tt = p / nstreams, ss = p - tt * nstreams;
+            const float2 a = tile[(size_t)ss * (AGC_IT + 1) + tt], b = tile[(size_t)(ss + 1) * (AGC_IT + 1) + tt];
+            *reinterpret_cast<float4*>(ob + p) = make_float4(a.x, a.y, b.x, b.y);
+        }
+    } else {
+        for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) {
+            const uint32_t tt = p / nstreams, ss = p - tt * nstreams;
+            ob[p] = tile[(size_t)ss * (AGC_IT + 1) + tt];
+        }
+    }
+}
+
 }  // namespace bazagc

@@ -80,6 +80,29 @@ int process_device_locked(baz_agc_ctx* c, const void* d_in, uint64_t n, uint64_t
     return BAZ_AGC_OK;
 }
 
+// Interleaved-output form: out[t * nstreams + s] (MUSIC item layout), tiles of AGC_IT samples, nstreams <= 16.
+int process_device_interleaved_locked(baz_agc_ctx* c, const void* d_in, uint64_t n, uint64_t stride, void* d_items)
+{
+    if (c->nstreams > (uint32_t)AGC_IMAX) return BAZ_AGC_E_INVALID;
+    const uint64_t ntiles64 = (n + AGC_IT - 1) / AGC_IT;
+    if (ntiles64 > 0x7FFFFFFFull) return BAZ_AGC_E_INVALID;
+    const uint32_t ntiles = (uint32_t)ntiles64;
+    int r = ensure_chunks(c, ntiles);
+    if (r) return r;
+    const float2* in = static_cast<const float2*>(d_in);
+    const dim3 block(64 * c->nstreams);
+    const size_t lds = (size_t)c->nstreams * (AGC_IT + 1) * sizeof(float2);
+    hipLaunchKernelGGL((agc_tile_kernel<0>), dim3(ntiles), block, 0, c->stream, in, n, stride, c->P, c->d_pair,
+                       (const double*)nullptr, ntiles, (float2*)nullptr, (double*)nullptr, c->nstreams);
+    hipLaunchKernelGGL(agc_carry_kernel, dim3(c->nstreams), dim3(64), 0, c->stream, in, stride, c->d_pair, c->d_carry,
+                       ntiles, c->d_env, c->count == 0 ? 1 : 0);
+    hipLaunchKernelGGL((agc_tile_kernel<1>), dim3(ntiles), block, lds, c->stream, in, n, stride, c->P, c->d_pair,
+                       c->d_carry, ntiles, static_cast<float2*>(d_items), c->d_env, c->nstreams);
+    AGC_TRY(hipGetLastError());
+    c->count += n;
+    return BAZ_AGC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -144,6 +167,15 @@ int baz_agc_process_device(baz_agc_ctx* c, const void* d_in, uint64_t n, uint64_
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
     return process_device_locked(c, d_in, n, stride, d_out, d_env, d_mul);
+}
+
+int baz_agc_process_device_interleaved(baz_agc_ctx* c, const void* d_in, uint64_t n, uint64_t stride, void* d_items)
+{
+    if (!c || !d_in || !d_items || (c->nstreams > 1 && stride < n)) return BAZ_AGC_E_INVALID;
+    if (n == 0) return BAZ_AGC_OK;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    DeviceGuard guard(c->device);
+    return process_device_interleaved_locked(c, d_in, n, stride, d_items);
 }
 
 int baz_agc_process(baz_agc_ctx* c, const float* in_ri, uint64_t n, uint64_t stride, float* out_ri, float* env, float* mul)

@@ -44,6 +44,13 @@ BAZ_AGC_API int baz_agc_process(baz_agc_ctx* ctx, const float* in_ri, uint64_t n
 /* Same on DEVICE-resident buffers, asynchronous on the context's stream.  Returns 0 or <0. */
 BAZ_AGC_API int baz_agc_process_device(baz_agc_ctx* ctx, const void* d_in, uint64_t n, uint64_t stride, void* d_out,
                                        void* d_env, void* d_mul);
+/* Config-5 form (the AGC sits right in front of MUSIC-DoA): same arithmetic and state as baz_agc_process_device, but
+ * the nstreams (<= 16) per-antenna outputs are written already INTERLEAVED, d_items[t * nstreams + s] = out_s[t] --
+ * i.e. as baz_music_doa items of nsamples = nstreams * K (x(r,c) = in[c*m + r], lib/baz_music_doa.cc:82-84) -- which is
+ * what GNU Radio's stock interleave / streams_to_vector blocks would produce between the two gr-baz blocks.  No env /
+ * gain ports in this form.  Returns 0 or <0. */
+BAZ_AGC_API int baz_agc_process_device_interleaved(baz_agc_ctx* ctx, const void* d_in, uint64_t n, uint64_t stride,
+                                                   void* d_items);
 /* Restarts every stream (count = 0, env = 0), i.e. a freshly constructed block. */
 BAZ_AGC_API int baz_agc_reset(baz_agc_ctx* ctx);
 BAZ_AGC_API int baz_agc_set_stream(baz_agc_ctx* ctx, void* hip_stream);

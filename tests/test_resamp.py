@@ -224,11 +224,17 @@ def test_host_block_general_work_like_the_scheduler(gpu_device, capfd):
                 elif k == 2: blk.set_resamp_ratio(float(a))
                 elif k == 3: blk.handle_adjust(float(a))
                 elif k == 4: blk.set_resamp_ratio(int(a), int(b))
-        need = blk.forecast(int(c))
-        produced, out, consumed = blk.general_work(g["x"][pos:pos + need + 4], int(c))
+        # (the window is not cut to forecast(): a pending ratio increase needs more input than the old ratio forecast;
+        # the reference then reads past ninput_items, this block returns fewer items -- checked below)
+        produced, out, consumed = blk.general_work(g["x"][pos:], int(c))
         lo = int(np.sum(g["calls"][:i]))
         assert produced == int(c) and consumed == int(g["consumed"][i])
         assert np.array_equal(out.view(np.uint32), g["out"][lo:lo + int(c)].view(np.uint32))
         pos += consumed
     assert abs(blk.mu() - float(g["mu_after"][-1])) < 1e-15 and abs(blk.relative_rate() - 1.0 / 1.5) < 1e-12
     assert "Ratio" in capfd.readouterr().err      # the constructor banner of .cc:92
+    blk = baz.fractional_resampler_cc(0.0, 1.0)
+    blk.set_resamp_ratio(2.0)
+    need = blk.forecast(1000)                      # 1008: still the old ratio, like the reference's forecast
+    produced, out, consumed = blk.general_work(g["x"][:need], 1000)
+    assert produced == (need - 8) // 2 + 1 and consumed == 2 * produced   # never reads past the window it was given
