@@ -387,13 +387,39 @@ __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict_
 }
 
 // -------------------------------------------------------------------------------------
-// 2b. The same EVD for m >= 5: M lanes per item, A and V live in LDS (complex128, 2*M*M*16 B per item).
-//     A rotation (p,q) is two lane-parallel phases: lane j applies the column operation to ITS ROW of
-//     A and V (A J, V J), then -- after a wave-level LDS hand-over -- the row operation to ITS COLUMN
-//     of A (J^H (A J)).  Rotation parameters are recomputed by every lane of the item (SIMD: free).
-//     Compact code (runtime p,q loops) instead of a >64 KiB fully unrolled register kernel or the
-//     private-array (scratch) form, which took 1.17 ms per 4,096 8x8 items.
+// 2b. The same EVD for m >= 5: M lanes per item, A lives in LDS (complex128), V in registers (one row per lane).
+//     A rotation is two lane-parallel phases: lane j applies the column operation to ITS ROW of A and V
+//     (A J, V J), then -- after a wave-level LDS hand-over -- the row operation to ITS COLUMN of A (J^H (A J)).
+//     Rotations run in tournament rounds of ME/2 disjoint pairs.  Compact code (runtime rounds) instead of a
+//     >64 KiB fully unrolled register kernel or the private-array (scratch) form, which took 1.17 ms per 4,096
+//     8x8 items.
 // -------------------------------------------------------------------------------------
+// position -> position map of the tournament movement between two rounds (Brent-Luk "musical chairs"): the pairs of
+// a round are always the positions (2k, 2k+1); position 0 stays, the even positions move up, the odd ones down.
+// new[pos] = old[tour_src(pos)].
+template <int ME>
+__device__ __host__ constexpr int tour_src(int pos)
+{
+    if (ME <= 2 || pos == 0) return pos;
+    if (pos == 2) return 1;
+    if (pos == ME - 1) return ME - 2;
+    return (pos & 1) ? pos + 2 : pos - 2;
+}
+
+// original index sitting at position pos in round r (closed form of the movement above; r is wave-uniform and pos a
+// compile-time constant at every use, so this is scalar-ALU work): the positions 1,2,4,..,ME-2,ME-1,ME-3,..,3 form one
+// cycle along which the contents advance by one step per round.
+template <int ME>
+__device__ __forceinline__ int tour_idx(int r, int pos)
+{
+    if (ME <= 2 || pos == 0) return pos;
+    constexpr int P = ME - 1;
+    const int t0 = (pos == 1) ? 0 : ((pos & 1) ? P - (pos - 1) / 2 : pos / 2);
+    int t = t0 - r;
+    t += (t < 0) ? P : 0;
+    return t == 0 ? 1 : (t <= ME / 2 - 1 ? 2 * t : 2 * (P - t) + 1);
+}
+
 template <int M>
 __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restrict__ R,
                                                            double* __restrict__ Qs,
@@ -402,10 +428,13 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
     constexpr int MM = M * M;
     constexpr int IPW = 64 / M;           // items per wave
     constexpr int MAX_SWEEPS = 24;
+    constexpr int ME = M + (M & 1);       // even size of the round-robin schedule (odd M: one phantom index)
+    // A lives in LDS (index space, dynamically addressed); V stays in REGISTERS: lane j holds row j of V with its
+    // columns kept in tournament-position order, so the column pair of round-pair k is always registers 2k, 2k+1
+    // (static), and is re-ordered between rounds by register moves.  V enters LDS only for the final projector
+    // (it reuses A's storage).  Halving the LDS footprint doubles the resident waves at m >= 9.
     __shared__ double2 sA[IPW][M][M + 1]; // +1: rows of different lanes start on different banks
-    __shared__ double2 sV[IPW][M][M + 1];
     __shared__ double sPart[IPW][M];
-    constexpr int ME = M + (M & 1);     // even size of the round-robin schedule (odd M: one phantom index)
     __shared__ double sPar[IPW][ME / 2][6];
 
     const int lane = threadIdx.x;
@@ -417,8 +446,10 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
     const bool valid = lane_used && item < batch;
     const uint32_t itc = (item < batch) ? item : (batch - 1);
     double2(*A)[M + 1] = sA[sl];
-    double2(*V)[M + 1] = sV[sl];
 
+    double2 Vrow[ME];
+#pragma unroll
+    for (int k = 0; k < ME; ++k) Vrow[k] = make_double2(k == j ? 1.0 : 0.0, 0.0);
     if (lane_used) {
         const double2* Rp = R + (size_t)itc * MM + j * M;
         double rsum = 0.0;
@@ -428,7 +459,6 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
             rsum += v.x + v.y;
             if (k == j) v.y = 0.0;
             A[j][k] = v;
-            V[j][k] = make_double2(k == j ? 1.0 : 0.0, 0.0);
         }
         sPart[sl][j] = rsum * 0.0;      // NaN iff this row holds a NaN / Inf
     }
@@ -456,12 +486,12 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
     wave_lds_fence();
 
     for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
-        double off = 0.0, dj = 0.0;
+        double off = 0.0;
         if (lane_used) {
 #pragma unroll
             for (int k = 0; k < M; ++k) {
                 const double2 v = A[j][k];
-                if (k == j) dj = v.x * v.x; else off += v.x * v.x + v.y * v.y;
+                if (k != j) off += v.x * v.x + v.y * v.y;
             }
             sPart[sl][j] = off;
         }
@@ -469,22 +499,20 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
         double offsum = 0.0, dia = 0.0;
 #pragma unroll
         for (int k = 0; k < M; ++k) { offsum += sPart[sl][k]; const double a = A[k][k].x; dia += a * a; }
-        (void)dj;
         const bool done = !(offsum > 2e-33 * dia);   // offsum counts every off-diagonal twice
         wave_lds_fence();
         if (__all(done || !lane_used)) break;
 
-        // One sweep = ME-1 rounds of the round-robin (circle) ordering; the <= ME/2 pairs of a round are disjoint, so
-        // their rotations commute and read only their own 2x2 block: parameters of all pairs are computed at once
+        // One sweep = ME-1 rounds of the round-robin (tournament) ordering; the <= ME/2 pairs of a round are disjoint,
+        // so their rotations commute and read only their own 2x2 block: parameters of all pairs are computed at once
         // (lane k of the item takes pair k), then every lane applies ALL column operations of the round to its row
-        // of A and V, then ALL row operations to its column of A.  3 LDS hand-overs per round instead of 2 per
-        // rotation, one parameter evaluation per lane per round instead of one per lane per rotation: the row-cyclic
-        // form took 2.05 ms per 16,384 16x16 items (57 % of the config-5 step).
+        // of A (LDS) and V (registers), then ALL row operations to its column of A.  3 LDS hand-overs per round
+        // instead of 2 per rotation, one parameter evaluation per lane per round instead of one per lane per
+        // rotation.  (Row-cyclic form: 2.05 ms per 16,384 16x16 items, 57 % of the config-5 step.)
         for (int r = 0; r < ME - 1; ++r) {
             if (lane_used && j < ME / 2) {
                 const int k = j;
-                const int pp = (k == 0) ? r : (r + k) % (ME - 1);
-                const int qq = (k == 0) ? (ME - 1) : (r - k + (ME - 1)) % (ME - 1);
+                const int pp = tour_idx<ME>(r, 2 * k), qq = tour_idx<ME>(r, 2 * k + 1);
                 double c = 1.0, sn = 0.0, ur = 1.0, ui = 0.0;
                 if (pp < M && qq < M) {                  // (a pair with the phantom index of an odd M idles)
                     const double2 apq = A[pp][qq];
@@ -509,25 +537,32 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
             // the round are fetched before the first result is stored (the pairs touch disjoint columns, which the
             // compiler cannot know): one LDS round trip per phase instead of one per pair.
             if (lane_used) {
-                double2 ax[ME / 2], ay[ME / 2], vx[ME / 2], vy[ME / 2];
+                constexpr int HB = (ME / 2 + 1) / 2;          // two operand batches: bounds the live registers
 #pragma unroll
-                for (int k = 0; k < ME / 2; ++k) {
-                    const int pp = (k == 0) ? r : (r + k) % (ME - 1);
-                    const int qq = (k == 0) ? (ME - 1) : (r - k + (ME - 1)) % (ME - 1);
-                    if (pp < M && qq < M) { ax[k] = A[j][pp]; ay[k] = A[j][qq]; vx[k] = V[j][pp]; vy[k] = V[j][qq]; }
-                }
+                for (int h = 0; h < ME / 2; h += HB) {
+                    double2 ax[HB], ay[HB];
 #pragma unroll
-                for (int k = 0; k < ME / 2; ++k) {
-                    const int pp = (k == 0) ? r : (r + k) % (ME - 1);
-                    const int qq = (k == 0) ? (ME - 1) : (r - k + (ME - 1)) % (ME - 1);
-                    if (pp >= M || qq >= M) continue;
-                    const double* par = sPar[sl][k];
-                    const double c = par[0], s = par[1], sur = par[2], sui = par[3], cur = par[4], cui = par[5];
-                    const double2 x = ax[k], y = ay[k], vxk = vx[k], vyk = vy[k];
-                    A[j][pp] = make_double2(c * x.x - (sur * y.x + sui * y.y), c * x.y - (sur * y.y - sui * y.x));
-                    A[j][qq] = make_double2(s * x.x + (cur * y.x + cui * y.y), s * x.y + (cur * y.y - cui * y.x));
-                    V[j][pp] = make_double2(c * vxk.x - (sur * vyk.x + sui * vyk.y), c * vxk.y - (sur * vyk.y - sui * vyk.x));
-                    V[j][qq] = make_double2(s * vxk.x + (cur * vyk.x + cui * vyk.y), s * vxk.y + (cur * vyk.y - cui * vyk.x));
+                    for (int kk = 0; kk < HB; ++kk) {
+                        const int k = h + kk;
+                        if (k < ME / 2) {
+                            const int pp = tour_idx<ME>(r, 2 * k), qq = tour_idx<ME>(r, 2 * k + 1);
+                            if (pp < M && qq < M) { ax[kk] = A[j][pp]; ay[kk] = A[j][qq]; }
+                        }
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < HB; ++kk) {
+                        const int k = h + kk;
+                        if (k >= ME / 2) continue;
+                        const int pp = tour_idx<ME>(r, 2 * k), qq = tour_idx<ME>(r, 2 * k + 1);
+                        if (pp >= M || qq >= M) continue;
+                        const double* par = sPar[sl][k];
+                        const double c = par[0], s = par[1], sur = par[2], sui = par[3], cur = par[4], cui = par[5];
+                        const double2 x = ax[kk], y = ay[kk], vx = Vrow[2 * k], vy = Vrow[2 * k + 1];
+                        A[j][pp] = make_double2(c * x.x - (sur * y.x + sui * y.y), c * x.y - (sur * y.y - sui * y.x));
+                        A[j][qq] = make_double2(s * x.x + (cur * y.x + cui * y.y), s * x.y + (cur * y.y - cui * y.x));
+                        Vrow[2 * k] = make_double2(c * vx.x - (sur * vy.x + sui * vy.y), c * vx.y - (sur * vy.y - sui * vy.x));
+                        Vrow[2 * k + 1] = make_double2(s * vx.x + (cur * vy.x + cui * vy.y), s * vx.y + (cur * vy.y - cui * vy.x));
+                    }
                 }
             }
             wave_lds_fence();
@@ -536,14 +571,12 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
                 double2 ax[ME / 2], ay[ME / 2];
 #pragma unroll
                 for (int k = 0; k < ME / 2; ++k) {
-                    const int pp = (k == 0) ? r : (r + k) % (ME - 1);
-                    const int qq = (k == 0) ? (ME - 1) : (r - k + (ME - 1)) % (ME - 1);
+                    const int pp = tour_idx<ME>(r, 2 * k), qq = tour_idx<ME>(r, 2 * k + 1);
                     if (pp < M && qq < M) { ax[k] = A[pp][j]; ay[k] = A[qq][j]; }
                 }
 #pragma unroll
                 for (int k = 0; k < ME / 2; ++k) {
-                    const int pp = (k == 0) ? r : (r + k) % (ME - 1);
-                    const int qq = (k == 0) ? (ME - 1) : (r - k + (ME - 1)) % (ME - 1);
+                    const int pp = tour_idx<ME>(r, 2 * k), qq = tour_idx<ME>(r, 2 * k + 1);
                     if (pp >= M || qq >= M) continue;
                     const double* par = sPar[sl][k];
                     const double c = par[0], s = par[1], sur = par[2], sui = par[3], cur = par[4], cui = par[5];
@@ -558,8 +591,17 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
                 }
             }
             wave_lds_fence();
+            // tournament movement of V's columns (registers): position pos now holds what tour_src(pos) held
+            {
+                double2 t[ME];
+#pragma unroll
+                for (int k = 0; k < ME; ++k) t[k] = Vrow[tour_src<ME>(k)];
+#pragma unroll
+                for (int k = 0; k < ME; ++k) Vrow[k] = t[k];
+            }
         }
     }
+    // (sweeps are whole periods of the tournament: position == original index again)
 
     // ascending rank of each eigenvalue (ties -> lower column first), noise = rank < m-n
     double wk[M];
@@ -574,18 +616,23 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
         for (int l = 0; l < M; ++l) rank += (wk[l] < wk[k] || (wk[l] == wk[k] && l < k)) ? 1 : 0;
         msk[k] = (rank < nnoise) ? 1.0 : 0.0;
     }
+    // V rows go to LDS (A's storage) for the cross-lane projector
+    wave_lds_fence();
+    double2(*V)[M + 1] = sA[sl];
+    if (lane_used) {
+#pragma unroll
+        for (int k = 0; k < M; ++k) V[j][k] = Vrow[k];
+    }
+    wave_lds_fence();
     // lane j emits row j of Q (upper part): Q_jl = sum_k msk_k V[j][k] conj(V[l][k])
     if (valid) {
-        double2 vj[M];
-#pragma unroll
-        for (int k = 0; k < M; ++k) vj[k] = V[j][k];
         for (int l = j; l < M; ++l) {
             double re = 0.0, im = 0.0;
 #pragma unroll
             for (int k = 0; k < M; ++k) {
                 const double2 vl = V[l][k];
-                re += msk[k] * (vj[k].x * vl.x + vj[k].y * vl.y);
-                im += msk[k] * (vj[k].y * vl.x - vj[k].x * vl.y);
+                re += msk[k] * (Vrow[k].x * vl.x + Vrow[k].y * vl.y);
+                im += msk[k] * (Vrow[k].y * vl.x - Vrow[k].x * vl.y);
             }
             if (l == j) {
                 Qs[(size_t)(j * M + j) * qstride + item] = re + poison;
