@@ -1,6 +1,6 @@
 """AGC throughput on the GPU box: 16 streams (config 5's antenna count), device resident."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from gr_baz_amd import agc
 from oracle import agc_ref as ar

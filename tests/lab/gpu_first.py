@@ -1,6 +1,6 @@
 """Ad-hoc first-light script (GPU box): stage-by-stage parity vs the numpy oracle + quick timing."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from gr_baz_amd import capi

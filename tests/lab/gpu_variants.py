@@ -1,7 +1,7 @@
 """Per-stage timing on the GPU box + parity spot check (argv: label list, batch, cfg).  The label used to
 select BAZ_MUSIC_SCAN_VARIANT builds while the scan kernel was being tuned; it is now just a tag."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from gr_baz_amd import capi

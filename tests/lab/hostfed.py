@@ -2,7 +2,7 @@
 PCIe-inclusive: NOT the headline metric.  Output buffers are allocated once and reused, like a
 scheduler's; argv: batch [chunk MiB list for BAZ_MUSIC_CHUNK_MIB, e.g. 4,16,64]."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from gr_baz_amd import capi
 from oracle import music_oracle as mo

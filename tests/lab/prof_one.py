@@ -1,6 +1,6 @@
 """Small fixed workload for rocprofv3 runs: cfg, batch, iters from argv."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from gr_baz_amd import capi
 from oracle import music_oracle as mo

@@ -1,7 +1,7 @@
 """Experiment: the GPU's 8 streams handled by NCTX contexts (own HIP stream each) issued round-robin, vs one context.
 argv: nctx list (e.g. 1,2,4), items per GPU."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from gr_baz_amd import capi
