@@ -140,7 +140,7 @@ int64_t process_device_locked(baz_resamp_ctx* c, const void* d_in, uint64_t in_s
     p.first_lo = (uint64_t)first; p.first_hi = (uint64_t)(first >> 64);
     p.base_lo = (uint64_t)step1;  p.base_hi = (uint64_t)(step1 >> 64);
     p.inc_lo = (uint64_t)inc;     p.inc_hi = (uint64_t)(inc >> 64);
-    const dim3 grid((uint32_t)((n + RS_BLOCK - 1) / RS_BLOCK), c->nstreams);
+    const dim3 grid((uint32_t)((n + RS_BLOCK * RS_PER_THREAD - 1) / (RS_BLOCK * RS_PER_THREAD)), c->nstreams);
     hipLaunchKernelGGL(resamp_kernel, grid, dim3(RS_BLOCK), 0, c->stream, static_cast<const float2*>(d_in), in_stride,
                        static_cast<float2*>(d_out), out_stride, (uint32_t)n, p, c->d_taps);
     RS_TRY(hipGetLastError());

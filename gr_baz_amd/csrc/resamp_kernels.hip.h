@@ -19,6 +19,7 @@ namespace bazresamp {
 constexpr int RS_NTAPS = 8;
 constexpr int RS_NSTEPS = 128;
 constexpr int RS_BLOCK = 256;
+constexpr int RS_PER_THREAD = 4;
 
 struct PhaseParams {
     uint64_t first_lo, first_hi;   // P_0 = mu of the first output (64.64): hi = integer part, lo = fraction
@@ -46,28 +47,35 @@ __global__ __launch_bounds__(RS_BLOCK) void resamp_kernel(const float2* __restri
     __shared__ float st[(RS_NSTEPS + 1) * RS_NTAPS];
     for (int i = threadIdx.x; i < (RS_NSTEPS + 1) * RS_NTAPS; i += RS_BLOCK) st[i] = taps[i];
     __syncthreads();
-    const uint32_t o = blockIdx.x * RS_BLOCK + threadIdx.x;
-    if (o >= noutput) return;
     const uint32_t stream = blockIdx.y;
-    uint64_t ii, frac;
-    phase_of(p, o, ii, frac);
-    // (float)d_mu: round-to-nearest-even of the 64-bit fraction, like the x87 -> float conversion at .cc:172
-    const float mu = __ull2float_rn(frac) * 5.42101086242752217e-20f;   // * 2^-64 (exact)
-    const int imu = __float2int_rn(mu * (float)RS_NSTEPS);              // rint(mu * NSTEPS), ties to even
-    const float* t = st + imu * RS_NTAPS;
-    const float2* x = in + (size_t)stream * in_stride + ii;
-    float re = 0.0f, im = 0.0f;
-    {
+    const float2* __restrict__ xs = in + (size_t)stream * in_stride;
+    float2* __restrict__ ys = out + (size_t)stream * out_stride;
+    // RS_PER_THREAD outputs per thread, RS_BLOCK apart (coalesced stores), so the 4 KiB tap table is staged once per
+    // 1,024 outputs instead of once per 256 (it was as much traffic as the samples themselves)
+#pragma unroll
+    for (int it = 0; it < RS_PER_THREAD; ++it) {
+        const uint32_t o = (blockIdx.x * RS_PER_THREAD + it) * RS_BLOCK + threadIdx.x;
+        if (o >= noutput) break;
+        uint64_t ii, frac;
+        phase_of(p, o, ii, frac);
+        // (float)d_mu: round-to-nearest-even of the 64-bit fraction, like the x87 -> float conversion at .cc:172
+        const float mu = __ull2float_rn(frac) * 5.42101086242752217e-20f;   // * 2^-64 (exact)
+        const int imu = __float2int_rn(mu * (float)RS_NSTEPS);              // rint(mu * NSTEPS), ties to even
+        const float* t = st + imu * RS_NTAPS;
+        const float2* x = xs + ii;
+        float re = 0.0f, im = 0.0f;
+        {
 #pragma clang fp contract(off)   // float multiply, then float add, like the reference's FIR kernel (no fma)
 #pragma unroll
-        for (int k = 0; k < RS_NTAPS; ++k) {
-            const float2 v = x[k];
-            const float w = t[RS_NTAPS - 1 - k];                        // the FIR kernel stores its taps reversed
-            re = re + v.x * w;
-            im = im + v.y * w;
+            for (int k = 0; k < RS_NTAPS; ++k) {
+                const float2 v = x[k];
+                const float w = t[RS_NTAPS - 1 - k];                        // the FIR kernel stores its taps reversed
+                re = re + v.x * w;
+                im = im + v.y * w;
+            }
         }
+        ys[o] = make_float2(re, im);
     }
-    out[(size_t)stream * out_stride + o] = make_float2(re, im);
 }
 
 }  // namespace bazresamp
