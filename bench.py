@@ -34,6 +34,7 @@ M, N_EMIT, NSAMPLES, RES = 4, 2, 1024, 3600
 FREQUENCY, SPACING = 299792458.0, 0.5
 STREAMS_PER_GPU, ITEMS_PER_STREAM = 8, 8192
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_MFMA_PEAK_TF = 78.6   # AMD datasheet; ubench: v_mfma_f64_16x16x4_f64 = 65 cycles/SIMD -> 77 TF (profiles/r01_ubench_fp64_rates.txt)
 
 
 def _usable_cpus():
@@ -209,6 +210,13 @@ def main():
                 traffic = json.load(open(tj)).get("scan_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        cov_s = stage[capi.STAGE_COV][0] / max(stage[capi.STAGE_COV][1], 1) * 1e-3
+        cov_tf = 8.0 * M * NSAMPLES * batch / cov_s / 1e12 if cov_s > 0 else 0.0
+        cov_mfma = {"useful_tflops": cov_tf, "fp64_matrix_peak_tflops": FP64_MFMA_PEAK_TF,
+                    "frac_of_peak": cov_tf / FP64_MFMA_PEAK_TF, "issued_over_useful": 2.0,
+                    "hbm_read_GBs": 8.0 * NSAMPLES * batch / cov_s / 1e9 if cov_s > 0 else 0.0,
+                    "note": "16x16x4 fp64 MFMA tiles hold 2 items block-diagonally at m=4 (half the issued flops are "
+                            "structural zeros); the kernel is HBM-read bound"}
         line = {
             "metric": "MUSIC-DoA snapshots/s (4 ant, 1024 samp, 3600 bins)",
             "value": value, "unit": "snapshots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -221,7 +229,10 @@ def main():
                        "algorithmic_bytes_per_item": ctx.bytes_per_item(True),
                        "pipeline_hbm_fraction_of_8TBs": value / world * ctx.bytes_per_item(True) / 8e12,
                        "stage_ms_per_launch_separate_pass": {nm: stage[s][0] / max(stage[s][1], 1)
-                                               for s, nm in enumerate(("cov_mfma", "evd_proj", "scan_mfma", "topn_merge"))}},
+                                               for s, nm in enumerate(("cov_mfma", "evd_proj", "scan_mfma", "topn_merge"))},
+                       # the one dense contraction (north_star): useful fp64 flops 8*m*N per item against the fp64
+                       # matrix peak; rocprofv3 MFMA-busy for the same kernel is in profiles/r01g_bench_pmc_summary.txt
+                       "covariance_mfma": cov_mfma},
             "roofline": {"bound": "hbm", "kernel": "scan_mfma_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_avg_s * 1e3,
