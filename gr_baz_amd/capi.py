@@ -26,7 +26,7 @@ SYMBOLS = [
     "baz_music_process_device", "baz_music_set_stream", "baz_music_sync", "baz_music_reserve",
     "baz_music_profile", "baz_music_stage_ms", "baz_music_stage_name", "baz_music_debug_cov",
     "baz_music_debug_evd", "baz_music_q_stride", "baz_music_bytes_per_item", "baz_music_strerror",
-    "baz_music_last_hip_error", "baz_music_version",
+    "baz_music_last_hip_error", "baz_music_version", "baz_music_device_count", "baz_music_device",
 ]
 
 _vp = ctypes.c_void_p
@@ -91,6 +91,10 @@ def lib():
     L.baz_music_last_hip_error.argtypes = [_vp]
     L.baz_music_version.restype = ctypes.c_char_p
     L.baz_music_version.argtypes = []
+    L.baz_music_device_count.restype = ctypes.c_int
+    L.baz_music_device_count.argtypes = []
+    L.baz_music_device.restype = ctypes.c_int
+    L.baz_music_device.argtypes = [_vp]
     _lib = L
     return L
 
@@ -210,6 +214,11 @@ class Context:
 
 def q_stride(batch):
     return int(lib().baz_music_q_stride(int(batch)))
+
+
+def device_count():
+    """Usable gfx950 devices (0 on a CPU-only box)."""
+    return int(lib().baz_music_device_count())
 
 
 def version():

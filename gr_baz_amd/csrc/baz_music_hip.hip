@@ -723,4 +723,19 @@ const char* baz_music_last_hip_error(const baz_music_ctx* c) { return c ? c->hip
 
 const char* baz_music_version(void) { return "gr_baz_amd/baz_music_hip 0.1 (gfx950)"; }
 
+int baz_music_device_count(void)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int usable = 0;
+    for (int d = 0; d < ndev; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++usable;
+        else break;   // device ids must stay dense: stop at the first foreign device
+    }
+    return usable;
+}
+
+int baz_music_device(const baz_music_ctx* c) { return c ? c->device : BAZ_MUSIC_E_INVALID; }
+
 }  // extern "C"

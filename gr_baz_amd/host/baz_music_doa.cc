@@ -12,7 +12,9 @@
 
 #include <gnuradio/io_signature.h>
 
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -46,6 +48,17 @@ void check_config(unsigned int m, unsigned int n, unsigned int nsamples, unsigne
 
 }  // namespace
 
+/* Independent block instances (BASELINE config 4: 64 streams in one flowgraph) are dealt over the node's GPUs
+ * round-robin -- instance i -> device i mod G -- unless BAZ_MUSIC_DEVICE pins one; -1 = the current
+ * HIP device when no gfx950 device is visible (create() then reports the error). */
+static int next_device()
+{
+    if (const char* v = getenv("BAZ_MUSIC_DEVICE")) return atoi(v);
+    static std::atomic<unsigned> s_instances(0);
+    const int g = baz_music_device_count();
+    return g > 0 ? (int)(s_instances.fetch_add(1) % (unsigned)g) : -1;
+}
+
 baz_music_doa_sptr baz_make_music_doa(unsigned int m, unsigned int n, unsigned int nsamples,
                                       const array_response_t& array_response, unsigned int resolution)
 {
@@ -63,7 +76,7 @@ baz_music_doa::baz_music_doa(unsigned int m, unsigned int n, unsigned int nsampl
       d_array_response(array_response), d_ctx(NULL)
 {
     const std::vector<float> flat = flatten_response(array_response, m, resolution);
-    const int rc = baz_music_create(&d_ctx, m, n, nsamples, resolution, flat.data(), -1);
+    const int rc = baz_music_create(&d_ctx, m, n, nsamples, resolution, flat.data(), next_device());
     if (rc == BAZ_MUSIC_E_INVALID || rc == BAZ_MUSIC_E_UNSUPPORTED)
         throw std::invalid_argument(std::string("music_doa: ") + baz_music_strerror(rc));
     if (rc != BAZ_MUSIC_OK)

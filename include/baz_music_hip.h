@@ -122,6 +122,11 @@ BAZ_MUSIC_API const char* baz_music_strerror(int code);
 /* hipGetErrorString of the last failing HIP call in this context ("" if none). */
 BAZ_MUSIC_API const char* baz_music_last_hip_error(const baz_music_ctx* ctx);
 BAZ_MUSIC_API const char* baz_music_version(void);
+/* Number of usable gfx950 devices (0 when none) and the device a context lives on.  The host block deals its
+ * instances over the devices round-robin (instance i -> device i mod count, SURVEY.md 8e: stream s -> GPU s mod G)
+ * unless BAZ_MUSIC_DEVICE pins one. */
+BAZ_MUSIC_API int baz_music_device_count(void);
+BAZ_MUSIC_API int baz_music_device(const baz_music_ctx* ctx);
 
 #ifdef __cplusplus
 }

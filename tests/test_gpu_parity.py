@@ -263,6 +263,17 @@ def test_full_size_properties(cfg, batch, distinct, gpu_device):
 
 
 # ------------------------------------------------------------------ boundary behaviour
+def test_device_dealing_of_block_instances(gpu_device):
+    """Host-block instances are dealt over the visible gfx950 devices (instance i -> device i mod G)."""
+    capi = _capi()
+    g = capi.device_count()
+    assert g >= 1
+    c = mo.make_config("cfg1", 4)
+    with capi.Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"], device_id=g - 1) as ctx:
+        assert capi.lib().baz_music_device(ctx._h) == g - 1
+        a, l, s = device_run(ctx, c["items"], gpu_device) if g == 1 else (None, None, None)
+
+
 def test_more_than_65536_bins_uses_the_wide_key(gpu_device):
     """resolution > 65,536 switches the top-n key to a 20-bit bin field; also an odd resolution
     (scalar spectrum stores) and a tail step with 33 valid bins."""
