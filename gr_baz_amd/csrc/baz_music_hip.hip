@@ -64,6 +64,9 @@ struct baz_music_ctx {
     std::mutex mtx;   // serialises set_table against process*, like d_mutex (.cc:67,101)
     int profiling = 0;      // 0 off, 1 every stage, 2 only the dominant (scan) stage
     int lab_variant = 0;
+    int peak_mode = 0;      // 0: the reference's n strongest bins; 1 (opt-in extension): n strongest local maxima
+    float* dPeakSpec = nullptr;   // internal spectrum when peak mode runs without the spectrum port
+    size_t peak_spec_cap = 0;     // floats
     size_t chunk_bytes = 0;   // host-fed path: traffic per pipelined chunk (BAZ_MUSIC_CHUNK_MIB); 0 = by buffer kind
     StageProf prof[BAZ_MUSIC_NUM_STAGES];
     std::string stage_name[BAZ_MUSIC_NUM_STAGES];
@@ -367,6 +370,26 @@ int launch_merge(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl, f
     }
 }
 
+template <int NMAX>
+int launch_peaks_t(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl, const float* d_spec)
+{
+    hipLaunchKernelGGL((peak_pick_kernel<NMAX>), dim3((batch + 3) / 4), dim3(256), 0, c->stream, d_spec, d_ang, d_lvl,
+                       batch, c->res, c->n);
+    HIP_TRY(c, hipGetLastError());
+    return BAZ_MUSIC_OK;
+}
+
+int launch_peaks(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl, const float* d_spec)
+{
+    ProfScope ps(c, BAZ_MUSIC_STAGE_MERGE);
+    switch (topn_list_len(c->n)) {
+        case 2: return launch_peaks_t<2>(c, batch, d_ang, d_lvl, d_spec);
+        case 4: return launch_peaks_t<4>(c, batch, d_ang, d_lvl, d_spec);
+        case 8: return launch_peaks_t<8>(c, batch, d_ang, d_lvl, d_spec);
+        default: return launch_peaks_t<16>(c, batch, d_ang, d_lvl, d_spec);
+    }
+}
+
 int launch_scan(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t batch, float* d_ang,
                 float* d_lvl, float* d_spec)
 {
@@ -458,10 +481,22 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
     if (r) return r;
     r = launch_evd(c, c->dR, batch, c->dQ, qstride);
     if (r) return r;
-    r = launch_scan(c, c->dQ, qstride, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl),
-                    static_cast<float*>(d_spec));
+    float* spec = static_cast<float*>(d_spec);
+    if (c->peak_mode && !spec) {   // the peak picker reads the spectrum: keep a private one when port 2 is not wired
+        const size_t need = (size_t)batch * c->res;
+        if (need > c->peak_spec_cap) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->dPeakSpec) (void)hipFree(c->dPeakSpec);
+            c->dPeakSpec = nullptr; c->peak_spec_cap = 0;
+            HIP_TRY(c, hipMalloc((void**)&c->dPeakSpec, need * sizeof(float)));
+            c->peak_spec_cap = need;
+        }
+        spec = c->dPeakSpec;
+    }
+    r = launch_scan(c, c->dQ, qstride, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), spec);
     if (r) return r;
-    return launch_merge(c, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), static_cast<float*>(d_spec));
+    if (c->peak_mode) return launch_peaks(c, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), spec);
+    return launch_merge(c, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), spec);
 }
 
 }  // namespace
@@ -536,6 +571,7 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->dCand) (void)hipFree(c->dCand);
         if (c->dR) (void)hipFree(c->dR);
         if (c->dQ) (void)hipFree(c->dQ);
+        if (c->dPeakSpec) (void)hipFree(c->dPeakSpec);
         free_slots(c);
         if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
         if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
@@ -734,6 +770,14 @@ int baz_music_device_count(void)
         else break;   // device ids must stay dense: stop at the first foreign device
     }
     return usable;
+}
+
+int baz_music_set_peak_mode(baz_music_ctx* c, int mode)
+{
+    if (!c || (mode != 0 && mode != 1)) return BAZ_MUSIC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    c->peak_mode = mode;
+    return BAZ_MUSIC_OK;
 }
 
 int baz_music_device(const baz_music_ctx* c) { return c ? c->device : BAZ_MUSIC_E_INVALID; }

@@ -1010,4 +1010,49 @@ __global__ __launch_bounds__(256) void topn_merge_kernel(const double* __restric
         }
 }
 
+// -------------------------------------------------------------------------------------
+// 6. OPT-IN extension (not reference behaviour): the n strongest LOCAL MAXIMA of the
+//    pseudo-spectrum instead of the n strongest bins (the reference's top-n, .cc:129-141, typically returns adjacent
+//    bins of one lobe).  Bin b is a peak when s[b] > s[b-1] and s[b] >= s[b+1] on the circle (a plateau counts once,
+//    at its first bin; NaN never qualifies).  Output format, ordering (descending strength, earlier bin first on
+//    ties) and the (0, 0) fill for missing peaks are those of the reference path.  One wave per item, reads the
+//    spectrum row the scan has just written.
+// -------------------------------------------------------------------------------------
+template <int NMAX>
+__global__ __launch_bounds__(256) void peak_pick_kernel(const float* __restrict__ spec, float* __restrict__ ang,
+                                                         float* __restrict__ lvl, uint32_t batch, uint32_t res,
+                                                         uint32_t n)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t it = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (it >= batch) return;
+    const float* __restrict__ s = spec + (size_t)it * res;
+    double key[NMAX];
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) key[i] = key_empty();
+    for (uint32_t b = lane; b < res; b += 64) {
+        const float v = s[b];
+        const float vp = s[b == 0 ? res - 1 : b - 1];
+        const float vn = s[b + 1 == res ? 0 : b + 1];
+        if (v > vp && v >= vn && v > 0.0f) {
+            // smaller key = stronger peak, then earlier bin: high word 0x7F800000 - bits(v) (v > 0: bits <= 0x7F800000)
+            const uint64_t k = ((uint64_t)(0x7F800000u - __float_as_uint(v)) << 32) | (uint64_t)b;
+            key_insert<NMAX>(key, __builtin_bit_cast(double, k));
+        }
+    }
+#pragma unroll
+    for (int mask = 1; mask < 64; mask <<= 1) key_merge_xor<NMAX>(key, mask);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i)
+            if (i < (int)n) {
+                const uint64_t k = __builtin_bit_cast(uint64_t, key[i]);
+                const bool used = k < (uint64_t)BAZ_KEY_EMPTY_BITS;
+                const uint32_t bin = (uint32_t)k;
+                ang[(size_t)it * n + i] = used ? (float)((double)bin * 360.0 / (double)res) : 0.0f;
+                if (lvl) lvl[(size_t)it * n + i] = used ? __uint_as_float(0x7F800000u - (uint32_t)(k >> 32)) : 0.0f;
+            }
+    }
+}
+
 }  // namespace bazmusic

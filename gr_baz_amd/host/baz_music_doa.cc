@@ -94,6 +94,12 @@ baz_music_doa::~baz_music_doa()
     baz_music_destroy(d_ctx);
 }
 
+void baz_music_doa::set_peak_mode(bool local_maxima)
+{
+    const int rc = baz_music_set_peak_mode(d_ctx, local_maxima ? 1 : 0);
+    if (rc != BAZ_MUSIC_OK) throw std::runtime_error(std::string("music_doa: set_peak_mode: ") + baz_music_strerror(rc));
+}
+
 void baz_music_doa::set_array_response(const array_response_t& array_response)
 {
     const std::vector<float> flat = flatten_response(array_response, d_m, d_resolution);

@@ -57,6 +57,9 @@ public:
 
     /* Thread-safe table replacement (python: music_doa_helper.set_frequency). */
     void set_array_response(const array_response_t& array_response);
+    /* Extension, off by default (not in the reference): emit the n strongest local maxima of the pseudo-spectrum
+     * instead of the n strongest bins (baz_music_set_peak_mode, include/baz_music_hip.h). */
+    void set_peak_mode(bool local_maxima);
 
     unsigned int m() const { return d_m; }
     unsigned int n() const { return d_n; }

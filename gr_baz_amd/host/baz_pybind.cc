@@ -102,6 +102,7 @@ PYBIND11_MODULE(_baz_music, mod)
         .def("set_array_response",
              [](music_doa_handle& h, const array_response_t& t) { h.blk->set_array_response(t); },
              py::arg("array_response"))
+        .def("set_peak_mode", [](music_doa_handle& h, bool on) { h.blk->set_peak_mode(on); }, py::arg("local_maxima"))
         .def("array_response", [](music_doa_handle& h) { return h.blk->array_response(); })
         .def("name", [](music_doa_handle& h) { return h.blk->name(); })
         .def("unique_id", [](music_doa_handle& h) { return h.blk->unique_id(); })

@@ -125,6 +125,11 @@ BAZ_MUSIC_API const char* baz_music_version(void);
 /* Number of usable gfx950 devices (0 when none) and the device a context lives on.  The host block deals its
  * instances over the devices round-robin (instance i -> device i mod count, SURVEY.md 8e: stream s -> GPU s mod G)
  * unless BAZ_MUSIC_DEVICE pins one. */
+/* OPT-IN extension, not reference behaviour: mode 1 makes ang/lvl the n strongest LOCAL MAXIMA
+ * of the pseudo-spectrum (bin b with s[b] > s[b-1] and s[b] >= s[b+1] on the circle) instead of the reference's n
+ * strongest bins (lib/baz_music_doa.cc:129-141, which usually are neighbours on one lobe).  Same output format,
+ * descending strength, (0, 0) for missing peaks.  Mode 0 (default) is the reference. */
+BAZ_MUSIC_API int baz_music_set_peak_mode(baz_music_ctx* ctx, int mode);
 BAZ_MUSIC_API int baz_music_device_count(void);
 BAZ_MUSIC_API int baz_music_device(const baz_music_ctx* ctx);
 

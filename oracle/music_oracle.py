@@ -238,3 +238,23 @@ def make_config(name, batch, snr_db=20.0, seed=None, angles_deg=(40.3, 121.7)):
                         seed=cfg["seed"] if seed is None else seed)
     cfg.update(array=arr, table=table, items=items)
     return cfg
+
+
+def peak_pick(spectrum, n, res=None):
+    """EXTENSION, no reference counterpart: the n strongest circular local maxima of one float32
+    spectrum row -- b is a peak when s[b] > s[b-1] and s[b] >= s[b+1] -- as (angle_deg, strength) float32 arrays in
+    descending strength (earlier bin first on ties), (0, 0) where fewer than n peaks exist.  Definition used by
+    tests/test_gpu_parity.py for baz_music_set_peak_mode(ctx, 1)."""
+    s = np.asarray(spectrum, dtype=np.float32)
+    res = s.shape[0] if res is None else res
+    prev, nxt = np.roll(s, 1), np.roll(s, -1)
+    with np.errstate(invalid="ignore"):
+        is_peak = (s > prev) & (s >= nxt) & (s > 0)
+    bins = np.nonzero(is_peak)[0]
+    order = sorted(bins.tolist(), key=lambda b: (-float(s[b]), b))[:n]
+    ang = np.zeros(n, np.float32)
+    lvl = np.zeros(n, np.float32)
+    for i, b in enumerate(order):
+        ang[i] = np.float32(b * 360.0 / res)
+        lvl[i] = s[b]
+    return ang, lvl

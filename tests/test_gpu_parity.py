@@ -262,6 +262,33 @@ def test_full_size_properties(cfg, batch, distinct, gpu_device):
     assert bool((lvl[:, :-1] >= lvl[:, 1:]).all())
 
 
+# ------------------------------------------------------------------ opt-in extension: local-maximum picker
+@pytest.mark.parametrize("cfg,n_items", [("cfg2", 200), ("cfg1", 64)])
+def test_peak_mode_is_opt_in_and_matches_its_definition(cfg, n_items, gpu_device):
+    """baz_music_set_peak_mode(ctx, 1): the n strongest circular local maxima of the spectrum the device itself wrote
+    (definition: oracle/music_oracle.py::peak_pick; NOT reference behaviour, default stays the reference's top-n)."""
+    c = mo.make_config(cfg, n_items, snr_db=20.0, seed=91)
+    m, n, res = c["m"], c["n"], c["res"]
+    with _capi().Context(m, n, c["nsamples"], res, c["table"]) as ctx:
+        a0, l0, s0 = device_run(ctx, c["items"], gpu_device)                      # default: reference semantics
+        ctx.set_peak_mode(1)
+        a1, l1, s1 = device_run(ctx, c["items"], gpu_device)
+        a2, l2, _ = device_run(ctx, c["items"], gpu_device, want_spec=False)      # private spectrum buffer
+        ctx.set_peak_mode(0)
+        a3, l3, s3 = device_run(ctx, c["items"], gpu_device)
+    ao, lo, so, st = mo.music_doa_work_batch(c["items"], c["table"], m, n)
+    assert_doa_match(a0, l0, ao, lo, res, st) and np.array_equal(a0, a3) and np.array_equal(l0, l3)
+    assert np.array_equal(s0, s1) and np.array_equal(s0, s3)
+    for b in range(n_items):
+        ea, el = mo.peak_pick(s1[b], n)
+        assert np.array_equal(a1[b], ea) and np.array_equal(l1[b], el)
+    assert np.array_equal(a1, a2) and np.array_equal(l1, l2)
+    # two emitters at 40.3 and 121.7 degrees: the peak picker separates them, the reference's top-n usually does not
+    found = np.sort(a1, axis=1)
+    step = 360.0 / res
+    assert np.mean(np.abs(found[:, 0] - 40.3) <= 2 * step + 1.0) > 0.9 and np.mean(np.abs(found[:, 1] - 121.7) <= 2 * step + 1.0) > 0.9
+
+
 # ------------------------------------------------------------------ boundary behaviour
 def test_device_dealing_of_block_instances(gpu_device):
     """Host-block instances are dealt over the visible gfx950 devices (instance i -> device i mod G)."""
