@@ -88,10 +88,25 @@ def test_no_gpu_means_loud_failure():
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under gr_baz_amd/ may import, link or load it."""
     bad = []
-    for dp, _, fns in os.walk(os.path.join(ROOT, "gr_baz_amd")):
-        for fn in fns:
-            if fn.endswith((".py", ".cc", ".h", ".hip", ".cpp")):
-                txt = open(os.path.join(dp, fn), errors="ignore").read()
-                if re.search(r"^\s*(from|import)\s+oracle\b|libmusic_ref|music_ref\.|oracle/_ref|libbaz_music_ref", txt, re.M):
-                    bad.append(os.path.join(dp, fn))
+    for top in ("gr_baz_amd", "scripts", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, top)):
+            for fn in fns:
+                if fn.endswith((".py", ".cc", ".h", ".hip", ".cpp", ".sh")):
+                    txt = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b|lib(music|agc|resamp)_ref|(music|agc|resamp)_ref\.|oracle/_ref|libbaz_\w+_ref",
+                                 txt, re.M):
+                        bad.append(os.path.join(dp, fn))
     assert not bad, bad
+    # bench.py may use the oracle only inside its cpu_baseline leg
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body_outside = src[:src.index("def cpu_baseline(")] + src[src.index("def main():"):]
+    assert not re.search(r"^\s*(from|import)\s+oracle\b", body_outside, re.M)
+
+
+def test_headers_are_plain_c():
+    """include/*.h are the FFI surface: they must compile as C (no C++ or HIP types in the signatures)."""
+    import subprocess
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if h.endswith(".h"):
+            subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c",
+                                   os.path.join(ROOT, "include", h)])
