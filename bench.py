@@ -3,8 +3,8 @@
 
 metric   : BASELINE.json's "MUSIC-DoA snapshots/s (4 ant, 1024 samp, 3600 bins)".
 workload : BASELINE.json configs[1] = SURVEY.md 8d cfg2: m=4, n=2, nsamples=1024 (K=256 columns),
-           resolution=3600, spectrum port wired; per GPU 8 independent synthetic streams of 8,192
-           items (65,536 items = one "step" = one pass of the hot path: covariance -> EVD -> scan),
+           resolution=3600, spectrum port wired; per GPU 8 independent synthetic streams of 32,768
+           items (262,144 items = one "step" = one pass of the hot path: covariance -> EVD -> scan),
            device-resident in HBM before the timed region.
 N GPUs   : one process per GPU (torch.distributed.run), streams dealt s mod N, NO data-path
            collective; torch.distributed (RCCL) only provides the barrier and the max-over-ranks
@@ -32,7 +32,7 @@ if ROOT not in sys.path:
 
 M, N_EMIT, NSAMPLES, RES = 4, 2, 1024, 3600
 FREQUENCY, SPACING = 299792458.0, 0.5
-STREAMS_PER_GPU, ITEMS_PER_STREAM = 8, 8192
+STREAMS_PER_GPU, ITEMS_PER_STREAM = 8, 32768
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_MFMA_PEAK_TF = 78.6   # AMD datasheet; ubench: v_mfma_f64_16x16x4_f64 = 65 cycles/SIMD -> 77 TF (profiles/r01_ubench_fp64_rates.txt)
 
@@ -207,7 +207,10 @@ def main():
         tj = os.path.join(ROOT, "profiles", "r01_scan_pmc_traffic.json")
         if os.path.exists(tj):
             try:
-                traffic = json.load(open(tj)).get("scan_hbm_bytes_per_launch")
+                tinfo = json.load(open(tj))
+                traffic = tinfo.get("scan_hbm_bytes_per_launch")
+                if traffic and tinfo.get("items_per_launch") and tinfo["items_per_launch"] != batch:
+                    traffic = int(traffic * batch / tinfo["items_per_launch"])   # the profile used another launch size
             except Exception:
                 traffic = None
         cov_s = stage[capi.STAGE_COV][0] / max(stage[capi.STAGE_COV][1], 1) * 1e-3
