@@ -110,3 +110,37 @@ def test_headers_are_plain_c():
         if h.endswith(".h"):
             subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c",
                                    os.path.join(ROOT, "include", h)])
+
+
+def _build_c_consumer(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "music_c_smoke")
+    csrc = os.path.join(ROOT, "gr_baz_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi", "music_c_smoke.c"), "-L", csrc, "-lbaz_music_hip", "-lm",
+                           "-Wl,-rpath," + csrc, "-o", exe])
+    return exe
+
+
+def test_plain_c_consumer_links_and_fails_loudly_without_a_gpu(tmp_path):
+    """The boundary is usable from plain C (what a cgo / JNI / ctypes host binds): compile + link with gcc only."""
+    import subprocess
+    import torch
+    exe = _build_c_consumer(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked run")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "gfx950" in r.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_consumer_finds_the_emitter(tmp_path, gpu_device):
+    import subprocess
+    exe = _build_c_consumer(tmp_path)
+    r = subprocess.run([exe, "137.0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("item")]
+    assert len(lines) == 40
+    for l in lines:
+        f = l.split()
+        assert abs(float(f[3]) - 137.0) <= 1.0 and f[-1] == "1"
