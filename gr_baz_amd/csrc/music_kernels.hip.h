@@ -436,6 +436,7 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
     __shared__ double2 sA[IPW][M][M + 1]; // +1: rows of different lanes start on different banks
     __shared__ double sPart[IPW][M];
     __shared__ double sPar[IPW][ME / 2][6];
+    __shared__ int sSel[IPW][M];          // eigenvalue index by ascending rank
 
     const int lane = threadIdx.x;
     const int slot = lane / M;            // item within the wave
@@ -603,19 +604,26 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
     }
     // (sweeps are whole periods of the tournament: position == original index again)
 
-    // ascending rank of each eigenvalue (ties -> lower column first), noise = rank < m-n
-    double wk[M];
-#pragma unroll
-    for (int k = 0; k < M; ++k) wk[k] = A[k][k].x;
-    double msk[M];
-    const int nnoise = (int)M - (int)n;
-#pragma unroll
-    for (int k = 0; k < M; ++k) {
+    // Ascending rank of the eigenvalues (ties -> lower column first; the noise space is rank < m-n, .cc:93): lane j
+    // ranks eigenvalue j and publishes sSel[rank] = j.  The projector is then summed over the SMALLER of the two sets:
+    // Q = sum_noise v v^H  or  Q = I - sum_signal v v^H  (V is unitary) -- n = 2 of 16 columns at config 5, which
+    // takes the epilogue from ~m^3/2 to ~m^2 n complex MACs per item.
+    if (lane_used) sSel[sl][j] = j;
+    wave_lds_fence();
+    if (lane_used) {
+        const double wj = A[j][j].x;
         int rank = 0;
 #pragma unroll
-        for (int l = 0; l < M; ++l) rank += (wk[l] < wk[k] || (wk[l] == wk[k] && l < k)) ? 1 : 0;
-        msk[k] = (rank < nnoise) ? 1.0 : 0.0;
+        for (int l = 0; l < M; ++l) {
+            const double wl = A[l][l].x;
+            rank += (wl < wj || (wl == wj && l < j)) ? 1 : 0;
+        }
+        sSel[sl][rank] = j;                    // (NaN eigenvalues: every rank is 0; the projector is poisoned anyway)
     }
+    const int nnoise = (int)M - (int)n;
+    const bool use_noise = nnoise <= (int)n;
+    const int cnt = use_noise ? nnoise : (int)n;
+    const int base = use_noise ? 0 : nnoise;
     // V rows go to LDS (A's storage) for the cross-lane projector
     wave_lds_fence();
     double2(*V)[M + 1] = sA[sl];
@@ -624,16 +632,17 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
         for (int k = 0; k < M; ++k) V[j][k] = Vrow[k];
     }
     wave_lds_fence();
-    // lane j emits row j of Q (upper part): Q_jl = sum_k msk_k V[j][k] conj(V[l][k])
+    // lane j emits row j of Q (upper part): Q_jl = sum_{k in set} V[j][k] conj(V[l][k])
     if (valid) {
         for (int l = j; l < M; ++l) {
             double re = 0.0, im = 0.0;
-#pragma unroll
-            for (int k = 0; k < M; ++k) {
-                const double2 vl = V[l][k];
-                re += msk[k] * (Vrow[k].x * vl.x + Vrow[k].y * vl.y);
-                im += msk[k] * (Vrow[k].y * vl.x - Vrow[k].x * vl.y);
+            for (int i = 0; i < cnt; ++i) {
+                const int k = sSel[sl][base + i] & 15;
+                const double2 vj = V[j][k], vl = V[l][k];
+                re += vj.x * vl.x + vj.y * vl.y;
+                im += vj.y * vl.x - vj.x * vl.y;
             }
+            if (!use_noise) { re = ((l == j) ? 1.0 : 0.0) - re; im = -im; }
             if (l == j) {
                 Qs[(size_t)(j * M + j) * qstride + item] = re + poison;
             } else {
