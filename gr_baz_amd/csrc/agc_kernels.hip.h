@@ -160,17 +160,22 @@ __global__ __launch_bounds__(AGC_BLOCK) void agc_chunk_kernel(const float2* __re
     }
 }
 
-// One wave per stream: carry-in of every chunk.  first != 0 means this call starts the stream (count == 0,
-// .cc:79-80): the state "before sample 0" is |x_0| itself, which makes e_0 = |x_0| (a + b) = |x_0|.
-// Lane l composes the maps of its contiguous slice of chunks, a wave scan gives the state entering each slice,
-// and the lane walks its slice again writing the per-chunk carry-ins (64x shorter dependent chain than a
-// single-lane loop, which took 21 % of the AGC time at 4096 chunks per stream).
-__global__ __launch_bounds__(64) void agc_carry_kernel(const float2* __restrict__ in, uint64_t stride,
-                                                        const double2* __restrict__ chunk_pair, double* __restrict__ carry_in,
-                                                        uint32_t nchunks, const double* __restrict__ env_state, int first)
+// One workgroup (AGC_CARRY_THREADS lanes) per stream: carry-in of every chunk.  first != 0 means this call starts the
+// stream (count == 0, .cc:79-80): the state "before sample 0" is |x_0| itself, which makes e_0 = |x_0| (a + b) = |x_0|.
+// Thread t composes the maps of its contiguous slice of chunks, a wave scan + a scan over the wave totals give the
+// state entering each slice, and the thread walks its slice again writing the per-chunk carry-ins.  (A single-lane
+// loop took 21 % of the AGC time at 4,096 chunks per stream; one wave per stream still 3 % of the config-5 step at
+// 16,384 tiles: the walk is a chain of dependent L2 loads.)
+constexpr int AGC_CARRY_THREADS = 1024;
+
+__global__ __launch_bounds__(AGC_CARRY_THREADS) void agc_carry_kernel(const float2* __restrict__ in, uint64_t stride,
+                                                                       const double2* __restrict__ chunk_pair,
+                                                                       double* __restrict__ carry_in, uint32_t nchunks,
+                                                                       const double* __restrict__ env_state, int first)
 {
+    __shared__ double wA[AGC_CARRY_THREADS / 64], wS[AGC_CARRY_THREADS / 64];
     const uint32_t stream = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double e0;
     if (first) {
         const float2 x0 = in[(size_t)stream * stride];
@@ -181,8 +186,8 @@ __global__ __launch_bounds__(64) void agc_carry_kernel(const float2* __restrict_
     }
     const double2* __restrict__ cp = chunk_pair + (size_t)stream * nchunks;
     double* __restrict__ ci = carry_in + (size_t)stream * nchunks;
-    const uint32_t per = (nchunks + 63) / 64;
-    const uint32_t c0 = (uint32_t)lane * per;
+    const uint32_t per = (nchunks + AGC_CARRY_THREADS - 1) / AGC_CARRY_THREADS;
+    const uint32_t c0 = ((uint64_t)tid * per < nchunks) ? (uint32_t)tid * per : nchunks;
     const uint32_t c1 = (c0 + per < nchunks) ? (c0 + per) : nchunks;
     double A = 1.0, S = 0.0;
     for (uint32_t c = c0; c < c1; ++c) {
@@ -196,9 +201,14 @@ __global__ __launch_bounds__(64) void agc_carry_kernel(const float2* __restrict_
         const double Ap = __shfl_up(Ai, d, 64), Sp = __shfl_up(Si, d, 64);
         if (lane >= d) compose(Ai, Si, Ap, Sp);
     }
+    if (lane == 63) { wA[wave] = Ai; wS[wave] = Si; }
+    __syncthreads();
     double Ae = __shfl_up(Ai, 1, 64), Se = __shfl_up(Si, 1, 64);
     if (lane == 0) { Ae = 1.0; Se = 0.0; }
-    double e = fma(Ae, e0, Se);           // state entering this lane's slice
+    double Aw = 1.0, Sw = 0.0;              // map of all earlier waves
+    for (int w = 0; w < wave; ++w) { const double a2 = wA[w], s2 = wS[w]; Sw = fma(a2, Sw, s2); Aw *= a2; }
+    compose(Ae, Se, Aw, Sw);                // thread-exclusive map of the whole block prefix
+    double e = fma(Ae, e0, Se);             // state entering this thread's slice
     for (uint32_t c = c0; c < c1; ++c) {
         ci[c] = e;
         const double2 p = cp[c];

@@ -70,7 +70,7 @@ int process_device_locked(baz_agc_ctx* c, const void* d_in, uint64_t n, uint64_t
     const dim3 grid(nchunks, c->nstreams);
     hipLaunchKernelGGL((agc_chunk_kernel<0>), grid, dim3(AGC_BLOCK), 0, c->stream, in, n, stride, c->P, c->d_pair,
                        (const double*)nullptr, nchunks, (float2*)nullptr, (float*)nullptr, (float*)nullptr, (double*)nullptr);
-    hipLaunchKernelGGL(agc_carry_kernel, dim3(c->nstreams), dim3(64), 0, c->stream, in, stride, c->d_pair, c->d_carry,
+    hipLaunchKernelGGL(agc_carry_kernel, dim3(c->nstreams), dim3(AGC_CARRY_THREADS), 0, c->stream, in, stride, c->d_pair, c->d_carry,
                        nchunks, c->d_env, c->count == 0 ? 1 : 0);
     hipLaunchKernelGGL((agc_chunk_kernel<1>), grid, dim3(AGC_BLOCK), 0, c->stream, in, n, stride, c->P, c->d_pair,
                        c->d_carry, nchunks, static_cast<float2*>(d_out), static_cast<float*>(d_env),
@@ -94,7 +94,7 @@ int process_device_interleaved_locked(baz_agc_ctx* c, const void* d_in, uint64_t
     const size_t lds = (size_t)c->nstreams * (AGC_IT + 1) * sizeof(float2);
     hipLaunchKernelGGL((agc_tile_kernel<0>), dim3(ntiles), block, 0, c->stream, in, n, stride, c->P, c->d_pair,
                        (const double*)nullptr, ntiles, (float2*)nullptr, (double*)nullptr, c->nstreams);
-    hipLaunchKernelGGL(agc_carry_kernel, dim3(c->nstreams), dim3(64), 0, c->stream, in, stride, c->d_pair, c->d_carry,
+    hipLaunchKernelGGL(agc_carry_kernel, dim3(c->nstreams), dim3(AGC_CARRY_THREADS), 0, c->stream, in, stride, c->d_pair, c->d_carry,
                        ntiles, c->d_env, c->count == 0 ? 1 : 0);
     hipLaunchKernelGGL((agc_tile_kernel<1>), dim3(ntiles), block, lds, c->stream, in, n, stride, c->P, c->d_pair,
                        c->d_carry, ntiles, static_cast<float2*>(d_items), c->d_env, c->nstreams);
