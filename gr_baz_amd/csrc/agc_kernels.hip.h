@@ -7,13 +7,14 @@
 //     out  = (float)(re*gain), (float)(im*gain)                  (.cc:97-100);  env[i], mul[i] optional ports
 // The envelope is a first-order linear recurrence e_i = a e_{i-1} + b m_i (a = 1 - rate, b = rate, fp64): its
 // composition is associative ((A2,S2) o (A1,S1) = (A1 A2, A2 S1 + S2)), so it is evaluated as a three-pass
-// chunked scan instead of the reference's one-sample-at-a-time loop:
-//   agc_chunk_kernel  (MODE 0)  per 4096-sample chunk: the pair (A_c, S_c) that maps the carry-in to the carry-out
-//   agc_carry_kernel            per stream: carry-in of every chunk (incl. the count == 0 rule: e_{-1} := |x_0|)
-//   agc_chunk_kernel  (MODE 1)  per chunk: recompute the local recurrence from its carry-in, emit out / env / mul
-// Each thread runs 16 consecutive samples in registers; global traffic is fully coalesced (16 B per lane) and
-// transposed through LDS.  The result differs from the sequential loop only by fp64 re-association (~1e-15),
-// far inside the 1e-5 tolerance of the float32 outputs.
+// tiled scan instead of the reference's one-sample-at-a-time loop:
+//   agc_tile_kernel<0>  per 256-sample tile (one wave): the pair (A_c, S_c) that maps the carry-in to the carry-out
+//   agc_carry_kernel    per stream: carry-in of every tile (incl. the count == 0 rule: e_{-1} := |x_0|)
+//   agc_tile_kernel<2>  per tile: recompute the local recurrence from its carry-in, emit out / env / mul (planar), or
+//   agc_tile_kernel<1>  the same with the S streams of a tile written interleaved as MUSIC items (config 5)
+// Each lane runs 4 consecutive samples in registers (32 contiguous bytes per lane, 2 KiB per wave: coalesced without
+// an LDS transpose).  The result differs from the sequential loop only by fp64 re-association (~1e-15), far inside
+// the 1e-5 tolerance of the float32 outputs.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -21,17 +22,11 @@
 
 namespace bazagc {
 
-constexpr int AGC_T = 16;                 // consecutive samples per thread
-constexpr int AGC_BLOCK = 256;
-constexpr int AGC_CHUNK = AGC_T * AGC_BLOCK;   // 4096 samples per workgroup
-
 struct AgcParams {
     double a;          // 1.0 - (double)rate
     double b;          // (double)rate
     double reference;
 };
-
-__device__ __forceinline__ int lds_idx(int i) { return i + (i >> 4); }   // 1 pad slot per 16 samples (8-B units)
 
 // (A2,S2) o (A1,S1): apply 1 first, then 2
 __device__ __forceinline__ void compose(double& A, double& S, const double A1, const double S1)
@@ -39,125 +34,6 @@ __device__ __forceinline__ void compose(double& A, double& S, const double A1, c
     // (A,S) := (A,S) o (A1,S1)
     S = fma(A, S1, S);
     A = A * A1;
-}
-
-// MODE 0: write (A_c, S_c) of each chunk.  MODE 1: apply, given carry_in[stream][chunk].
-template <int MODE>
-__global__ __launch_bounds__(AGC_BLOCK) void agc_chunk_kernel(const float2* __restrict__ in, uint64_t n, uint64_t stride,
-                                                               AgcParams P, double2* __restrict__ chunk_pair,
-                                                               const double* __restrict__ carry_in, uint32_t nchunks,
-                                                               float2* __restrict__ out, float* __restrict__ env_out,
-                                                               float* __restrict__ mul_out, double* __restrict__ env_state)
-{
-    __shared__ float2 sx[AGC_CHUNK + AGC_CHUNK / 16];
-    __shared__ float se[MODE ? (AGC_CHUNK + AGC_CHUNK / 16) : 1];
-    __shared__ float sm[MODE ? (AGC_CHUNK + AGC_CHUNK / 16) : 1];
-    __shared__ double wA[4], wS[4];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t chunk = blockIdx.x;
-    const uint32_t stream = blockIdx.y;
-    const uint64_t base = (uint64_t)chunk * AGC_CHUNK;
-    const float2* __restrict__ xin = in + (size_t)stream * stride + base;
-    const uint32_t valid = (uint32_t)((n - base < (uint64_t)AGC_CHUNK) ? (n - base) : AGC_CHUNK);
-    const bool al16 = (reinterpret_cast<uintptr_t>(xin) & 15u) == 0;   // wave-uniform
-
-    // coalesced load: 2 samples (16 B) per lane per instruction
-#pragma unroll
-    for (int j = 0; j < AGC_T / 2; ++j) {
-        const int i = (j * AGC_BLOCK + tid) * 2;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((uint32_t)i + 1 < valid) {
-            if (al16) v = *reinterpret_cast<const float4*>(xin + i);
-            else { const float2 s0 = xin[i], s1 = xin[i + 1]; v = make_float4(s0.x, s0.y, s1.x, s1.y); }
-        } else if ((uint32_t)i < valid) { const float2 s0 = xin[i]; v.x = s0.x; v.y = s0.y; }
-        sx[lds_idx(i)] = make_float2(v.x, v.y);
-        sx[lds_idx(i + 1)] = make_float2(v.z, v.w);
-    }
-    __syncthreads();
-
-    // this thread's run: samples [tid*16, tid*16+16) of the chunk
-    const int i0 = tid * AGC_T;
-    const int cnt = ((int)valid - i0) < 0 ? 0 : (((int)valid - i0) > AGC_T ? AGC_T : ((int)valid - i0));
-    double mag[AGC_T];
-    float2 x[AGC_T];
-    double A = 1.0, S = 0.0;     // local map e_out = A e_in + S
-#pragma unroll
-    for (int j = 0; j < AGC_T; ++j) {
-        x[j] = sx[lds_idx(i0 + j)];
-        const double d0 = x[j].x, d1 = x[j].y;
-        mag[j] = sqrt(d0 * d0 + d1 * d1);                    // .cc:74-77
-        if (j < cnt) { S = fma(P.a, S, P.b * mag[j]); A *= P.a; }
-    }
-
-    // inclusive scan of the (A,S) maps over the 256 threads: wave shuffles, then 4 wave totals through LDS
-    double Ai = A, Si = S;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double Ap = __shfl_up(Ai, d, 64), Sp = __shfl_up(Si, d, 64);
-        if (lane >= d) compose(Ai, Si, Ap, Sp);
-    }
-    if (lane == 63) { wA[wave] = Ai; wS[wave] = Si; }
-    __syncthreads();
-    // exclusive prefix of this thread = (previous lanes in the wave) o (previous waves)
-    double Ae = __shfl_up(Ai, 1, 64), Se = __shfl_up(Si, 1, 64);
-    if (lane == 0) { Ae = 1.0; Se = 0.0; }
-    double Aw = 1.0, Sw = 0.0;              // map of all earlier waves
-    for (int w = 0; w < wave; ++w) { const double a2 = wA[w], s2 = wS[w]; Sw = fma(a2, Sw, s2); Aw *= a2; }
-    compose(Ae, Se, Aw, Sw);                // thread-exclusive map of the whole block prefix
-
-    if (MODE == 0) {
-        if (tid == AGC_BLOCK - 1) {
-            double At = Ai, St = Si;        // inclusive of this (last) thread within its wave
-            compose(At, St, Aw, Sw);
-            chunk_pair[(size_t)stream * nchunks + chunk] = make_double2(At, St);
-        }
-        return;
-    }
-
-    // MODE 1: state entering this thread's run, then the reference's per-sample arithmetic
-    double e = fma(Ae, carry_in[(size_t)stream * nchunks + chunk], Se);
-    const double one_minus_rate = P.a, rate = P.b;
-#pragma unroll
-    for (int j = 0; j < AGC_T; ++j) {
-        if (j < cnt) {
-            e = (e * one_minus_rate) + (mag[j] * rate);       // .cc:82
-            const double gain = P.reference / e;              // .cc:89
-            const double d0 = (double)x[j].x * gain, d1 = (double)x[j].y * gain;   // .cc:97-98
-            sx[lds_idx(i0 + j)] = make_float2((float)d0, (float)d1);               // .cc:100
-            se[lds_idx(i0 + j)] = (float)e;                   // .cc:85
-            sm[lds_idx(i0 + j)] = (float)gain;                // .cc:92
-        }
-    }
-    if (env_state && base + i0 + cnt == n && cnt > 0) env_state[stream] = e;   // the thread holding the last sample
-    __syncthreads();
-
-    float2* __restrict__ xo = out + (size_t)stream * stride + base;
-    const bool ao16 = (reinterpret_cast<uintptr_t>(xo) & 15u) == 0;
-#pragma unroll
-    for (int j = 0; j < AGC_T / 2; ++j) {
-        const int i = (j * AGC_BLOCK + tid) * 2;
-        if ((uint32_t)i + 1 < valid) {
-            const float2 s0 = sx[lds_idx(i)], s1 = sx[lds_idx(i + 1)];
-            if (ao16) *reinterpret_cast<float4*>(xo + i) = make_float4(s0.x, s0.y, s1.x, s1.y);
-            else { xo[i] = s0; xo[i + 1] = s1; }
-        } else if ((uint32_t)i < valid) {
-            xo[i] = sx[lds_idx(i)];
-        }
-    }
-    if (env_out || mul_out) {
-        float* __restrict__ eo = env_out ? env_out + (size_t)stream * stride + base : nullptr;
-        float* __restrict__ mo = mul_out ? mul_out + (size_t)stream * stride + base : nullptr;
-#pragma unroll
-        for (int j = 0; j < AGC_T; ++j) {
-            const int i = j * AGC_BLOCK + tid;
-            if ((uint32_t)i < valid) {
-                if (eo) eo[i] = se[lds_idx(i)];
-                if (mo) mo[i] = sm[lds_idx(i)];
-            }
-        }
-    }
 }
 
 // One workgroup (AGC_CARRY_THREADS lanes) per stream: carry-in of every chunk.  first != 0 means this call starts the
@@ -231,17 +107,29 @@ constexpr int AGC_IE = 4;                  // consecutive samples per lane
 constexpr int AGC_IT = 64 * AGC_IE;        // 256 samples per stream per workgroup
 constexpr int AGC_IMAX = 16;               // streams per context in this form
 
-template <int MODE>
+// MODE 0: tile maps; MODE 1: apply + interleave (workgroup = the S streams of one tile); MODE 2: apply, planar output
+// with the optional env / gain ports (waves are dealt over (stream, tile) pairs, consecutive waves = consecutive tiles
+// of one stream).  PLANAR_GRID selects the MODE-2 wave -> (stream, tile) mapping for MODE 0 as well.
+template <int MODE, bool PLANAR_GRID = (MODE == 2)>
 __global__ __launch_bounds__(1024) void agc_tile_kernel(const float2* __restrict__ in, uint64_t n, uint64_t stride,
                                                          AgcParams P, double2* __restrict__ chunk_pair,
                                                          const double* __restrict__ carry_in, uint32_t ntiles,
                                                          float2* __restrict__ out, double* __restrict__ env_state,
-                                                         uint32_t nstreams)
+                                                         uint32_t nstreams, float* __restrict__ env_out = nullptr,
+                                                         float* __restrict__ mul_out = nullptr)
 {
     extern __shared__ float2 tile[];       // MODE 1: [nstreams][AGC_IT + 1]
     const int lane = threadIdx.x & 63;
-    const uint32_t stream = threadIdx.x >> 6;
-    const uint32_t t = blockIdx.x;
+    uint32_t stream, t;
+    if constexpr (PLANAR_GRID) {
+        const uint64_t gw = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (gw >= (uint64_t)ntiles * nstreams) return;
+        stream = (uint32_t)(gw / ntiles);
+        t = (uint32_t)(gw - (uint64_t)stream * ntiles);
+    } else {
+        stream = threadIdx.x >> 6;
+        t = blockIdx.x;
+    }
     const uint64_t base = (uint64_t)t * AGC_IT;
     const uint32_t valid = (uint32_t)((n - base < (uint64_t)AGC_IT) ? (n - base) : AGC_IT);
     const int i0 = lane * AGC_IE;
@@ -280,6 +168,48 @@ __global__ __launch_bounds__(1024) void agc_tile_kernel(const float2* __restrict
     double Ae = __shfl_up(Ai, 1, 64), Se = __shfl_up(Si, 1, 64);
     if (lane == 0) { Ae = 1.0; Se = 0.0; }
     double e = fma(Ae, carry_in[(size_t)stream * ntiles + t], Se);   // state entering this lane's run
+    if constexpr (MODE == 2) {     // planar: the lane's AGC_IE outputs are 32 contiguous bytes of its stream
+        float2 y[AGC_IE];
+        float ev[AGC_IE], gv[AGC_IE];
+#pragma unroll
+        for (int j = 0; j < AGC_IE; ++j) {
+            y[j] = make_float2(0.f, 0.f); ev[j] = 0.f; gv[j] = 0.f;
+            if (j < cnt) {
+                e = (e * P.a) + (mag[j] * P.b);                   // .cc:82
+                const double gain = P.reference / e;              // .cc:89
+                y[j] = make_float2((float)((double)x[j].x * gain), (float)((double)x[j].y * gain));   // .cc:97-100
+                ev[j] = (float)e;                                 // .cc:85
+                gv[j] = (float)gain;                              // .cc:92
+            }
+        }
+        if (env_state && base + i0 + cnt == n && cnt > 0) env_state[stream] = e;
+        const size_t o = (size_t)stream * stride + base + i0;
+        float2* __restrict__ yo = out + o;
+        if (cnt == AGC_IE && (reinterpret_cast<uintptr_t>(yo) & 15u) == 0) {
+            *reinterpret_cast<float4*>(yo) = make_float4(y[0].x, y[0].y, y[1].x, y[1].y);
+            *reinterpret_cast<float4*>(yo + 2) = make_float4(y[2].x, y[2].y, y[3].x, y[3].y);
+        } else {
+#pragma unroll
+            for (int j = 0; j < AGC_IE; ++j) if (j < cnt) yo[j] = y[j];
+        }
+        if (env_out) {
+            float* __restrict__ eo = env_out + o;
+            if (cnt == AGC_IE && (reinterpret_cast<uintptr_t>(eo) & 15u) == 0) *reinterpret_cast<float4*>(eo) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+            else {
+#pragma unroll
+                for (int j = 0; j < AGC_IE; ++j) if (j < cnt) eo[j] = ev[j];
+            }
+        }
+        if (mul_out) {
+            float* __restrict__ mo = mul_out + o;
+            if (cnt == AGC_IE && (reinterpret_cast<uintptr_t>(mo) & 15u) == 0) *reinterpret_cast<float4*>(mo) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+            else {
+#pragma unroll
+                for (int j = 0; j < AGC_IE; ++j) if (j < cnt) mo[j] = gv[j];
+            }
+        }
+        return;
+    }
     float2* __restrict__ row = tile + (size_t)stream * (AGC_IT + 1);
 #pragma unroll
     for (int j = 0; j < AGC_IE; ++j) {

@@ -61,20 +61,25 @@ int ensure_chunks(baz_agc_ctx* c, size_t nchunks)
 int process_device_locked(baz_agc_ctx* c, const void* d_in, uint64_t n, uint64_t stride, void* d_out, void* d_env,
                           void* d_mul)
 {
-    const uint64_t nchunks64 = (n + AGC_CHUNK - 1) / AGC_CHUNK;
-    if (nchunks64 > 0xFFFFFFFFull) return BAZ_AGC_E_INVALID;
-    const uint32_t nchunks = (uint32_t)nchunks64;
-    int r = ensure_chunks(c, nchunks);
+    // planar form: waves dealt over (stream, tile) pairs, 16 waves per workgroup
+    const uint64_t ntiles64 = (n + AGC_IT - 1) / AGC_IT;
+    if (ntiles64 > 0x7FFFFFFFull) return BAZ_AGC_E_INVALID;
+    const uint32_t ntiles = (uint32_t)ntiles64;
+    int r = ensure_chunks(c, ntiles);
     if (r) return r;
     const float2* in = static_cast<const float2*>(d_in);
-    const dim3 grid(nchunks, c->nstreams);
-    hipLaunchKernelGGL((agc_chunk_kernel<0>), grid, dim3(AGC_BLOCK), 0, c->stream, in, n, stride, c->P, c->d_pair,
-                       (const double*)nullptr, nchunks, (float2*)nullptr, (float*)nullptr, (float*)nullptr, (double*)nullptr);
-    hipLaunchKernelGGL(agc_carry_kernel, dim3(c->nstreams), dim3(AGC_CARRY_THREADS), 0, c->stream, in, stride, c->d_pair, c->d_carry,
-                       nchunks, c->d_env, c->count == 0 ? 1 : 0);
-    hipLaunchKernelGGL((agc_chunk_kernel<1>), grid, dim3(AGC_BLOCK), 0, c->stream, in, n, stride, c->P, c->d_pair,
-                       c->d_carry, nchunks, static_cast<float2*>(d_out), static_cast<float*>(d_env),
-                       static_cast<float*>(d_mul), c->d_env);
+    const uint64_t nwaves = (uint64_t)ntiles * c->nstreams;
+    const uint64_t nblocks = (nwaves + 15) / 16;
+    if (nblocks > 0x7FFFFFFFull) return BAZ_AGC_E_INVALID;
+    const dim3 grid((uint32_t)nblocks), block(1024);
+    hipLaunchKernelGGL((agc_tile_kernel<0, true>), grid, block, 0, c->stream, in, n, stride, c->P, c->d_pair,
+                       (const double*)nullptr, ntiles, (float2*)nullptr, (double*)nullptr, c->nstreams, (float*)nullptr,
+                       (float*)nullptr);
+    hipLaunchKernelGGL(agc_carry_kernel, dim3(c->nstreams), dim3(AGC_CARRY_THREADS), 0, c->stream, in, stride, c->d_pair,
+                       c->d_carry, ntiles, c->d_env, c->count == 0 ? 1 : 0);
+    hipLaunchKernelGGL((agc_tile_kernel<2, true>), grid, block, 0, c->stream, in, n, stride, c->P, c->d_pair,
+                       c->d_carry, ntiles, static_cast<float2*>(d_out), c->d_env, c->nstreams, static_cast<float*>(d_env),
+                       static_cast<float*>(d_mul));
     AGC_TRY(hipGetLastError());
     c->count += n;
     return BAZ_AGC_OK;
