@@ -64,6 +64,11 @@ struct baz_music_ctx {
     std::mutex mtx;   // serialises set_table against process*, like d_mutex (.cc:67,101)
     int profiling = 0;      // 0 off, 1 every stage, 2 only the dominant (scan) stage
     int lab_variant = 0;
+    // literal-form refinement of near-null items (refine_literal_kernel)
+    double* dG = nullptr;          // noise eigenvectors, item-minor like dQ (cap * m*m * 2 doubles)
+    float2* dTable = nullptr;      // raw steering table [res][m] (complex64)
+    uint32_t* dRefine = nullptr;   // [0] = count, [1..cap] = flagged items
+    double refine_below = 0.0;     // threshold on d = a^H Q a
     int peak_mode = 0;      // 0: the reference's n strongest bins; 1 (opt-in extension): n strongest local maxima
     float* dPeakSpec = nullptr;   // internal spectrum when peak mode runs without the spectrum port
     size_t peak_spec_cap = 0;     // floats
@@ -159,9 +164,13 @@ int ensure_workspace(baz_music_ctx* c, uint32_t batch)
     const size_t mm = (size_t)c->m * c->m;
     if (c->dR) { (void)hipFree(c->dR); c->dR = nullptr; }
     if (c->dQ) { (void)hipFree(c->dQ); c->dQ = nullptr; }
+    if (c->dG) { (void)hipFree(c->dG); c->dG = nullptr; }
+    if (c->dRefine) { (void)hipFree(c->dRefine); c->dRefine = nullptr; }
     c->cap = 0;
     HIP_TRY(c, hipMalloc((void**)&c->dR, (size_t)cap * mm * sizeof(double2)));
     HIP_TRY(c, hipMalloc((void**)&c->dQ, (size_t)cap * mm * sizeof(double)));
+    HIP_TRY(c, hipMalloc((void**)&c->dG, (size_t)cap * mm * 2 * sizeof(double)));
+    HIP_TRY(c, hipMalloc((void**)&c->dRefine, ((size_t)cap + 1) * sizeof(uint32_t)));
     c->cap = cap;
     return BAZ_MUSIC_OK;
 }
@@ -242,24 +251,24 @@ int launch_cov(baz_music_ctx* c, const float* d_in, uint32_t batch, double2* dR)
 }
 
 template <int M>
-int launch_evd_t(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ, uint32_t qstride)
+int launch_evd_t(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ, uint32_t qstride, double* dG)
 {
     if constexpr (M <= 4) {   // one item per lane, register resident
         const uint32_t blocks = (batch + 63) / 64;
-        hipLaunchKernelGGL((evd_proj_kernel<M>), dim3(blocks), dim3(64), 0, c->stream, dR, dQ, batch, c->n, qstride);
+        hipLaunchKernelGGL((evd_proj_kernel<M>), dim3(blocks), dim3(64), 0, c->stream, dR, dQ, batch, c->n, qstride, dG);
     } else {                  // M lanes per item, matrices in LDS
         constexpr uint32_t IPW = 64 / M;
         const uint32_t blocks = (batch + IPW - 1) / IPW;
-        hipLaunchKernelGGL((evd_proj_lds_kernel<M>), dim3(blocks), dim3(64), 0, c->stream, dR, dQ, batch, c->n, qstride);
+        hipLaunchKernelGGL((evd_proj_lds_kernel<M>), dim3(blocks), dim3(64), 0, c->stream, dR, dQ, batch, c->n, qstride, dG);
     }
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
 }
 
-int launch_evd(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ, uint32_t qstride)
+int launch_evd(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ, uint32_t qstride, double* dG)
 {
     ProfScope ps(c, BAZ_MUSIC_STAGE_EVD);
-#define BAZ_CALL(MV) launch_evd_t<MV>(c, dR, batch, dQ, qstride)
+#define BAZ_CALL(MV) launch_evd_t<MV>(c, dR, batch, dQ, qstride, dG)
     switch (c->m) {
         BAZ_M_CASES(BAZ_CALL)
         default: return BAZ_MUSIC_E_UNSUPPORTED;
@@ -328,7 +337,8 @@ int launch_merge_t(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl,
 {
     const ScanGeom G = scan_geometry(batch, c->fb_steps);
     hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream, c->dCand,
-                       d_spec, d_ang, d_lvl, batch, c->res, c->n, G.nsplit, c->keep_mask);
+                       d_spec, d_ang, d_lvl, batch, c->res, c->n, G.nsplit, c->keep_mask, c->refine_below, c->dRefine,
+                       c->dRefine + 1);
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
 }
@@ -410,6 +420,18 @@ int upload_table(baz_music_ctx* c, const float* table_ri)
     build_FB(F, c->m, c->res, c->fb_steps, FB);
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // no batch in flight reads the old table
     HIP_TRY(c, hipMemcpy(c->dFB, FB.data(), FB.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->dTable, table_ri, (size_t)c->res * c->m * sizeof(float2), hipMemcpyHostToDevice));
+    // projector-form accuracy: |error(d)| ~ m^2 eps ||a||^2-scale; below this d the item is redone in literal form
+    double amax2 = 0.0;
+    for (uint32_t b = 0; b < c->res; ++b) {
+        double a2 = 0.0;
+        for (uint32_t i = 0; i < c->m; ++i) {
+            const double re = table_ri[2 * ((size_t)b * c->m + i)], im = table_ri[2 * ((size_t)b * c->m + i) + 1];
+            a2 += re * re + im * im;
+        }
+        if (a2 > amax2 && a2 < 1e300) amax2 = a2;
+    }
+    c->refine_below = amax2 * (double)c->m * 1e-9;
     return BAZ_MUSIC_OK;
 }
 
@@ -479,7 +501,8 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
     const uint32_t qstride = baz_music_q_stride(batch);
     r = launch_cov(c, static_cast<const float*>(d_in), batch, c->dR);
     if (r) return r;
-    r = launch_evd(c, c->dR, batch, c->dQ, qstride);
+    HIP_TRY(c, hipMemsetAsync(c->dRefine, 0, sizeof(uint32_t), c->stream));   // no item flagged yet
+    r = launch_evd(c, c->dR, batch, c->dQ, qstride, c->dG);
     if (r) return r;
     float* spec = static_cast<float*>(d_spec);
     if (c->peak_mode && !spec) {   // the peak picker reads the spectrum: keep a private one when port 2 is not wired
@@ -495,8 +518,17 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
     }
     r = launch_scan(c, c->dQ, qstride, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), spec);
     if (r) return r;
+    r = launch_merge(c, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), spec);
+    if (r) return r;
+    {   // near-null items (flagged by the merge) are redone in the reference's literal form; usually none
+        ProfScope ps(c, BAZ_MUSIC_STAGE_MERGE);
+        hipLaunchKernelGGL(refine_literal_kernel, dim3(64), dim3(256), 0, c->stream, c->dRefine, c->dRefine + 1, c->dG,
+                           qstride, c->dTable, spec, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), c->res, c->m,
+                           c->n, c->keep_mask);
+        HIP_TRY(c, hipGetLastError());
+    }
     if (c->peak_mode) return launch_peaks(c, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), spec);
-    return launch_merge(c, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), spec);
+    return BAZ_MUSIC_OK;
 }
 
 }  // namespace
@@ -540,6 +572,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (resolution > (1u << 20)) { r = BAZ_MUSIC_E_UNSUPPORTED; break; }
         c->keep_mask = (resolution <= (1u << 16)) ? 0xFFFF0000u : 0xFFF00000u;
         if (hipMalloc((void**)&c->dFB, (size_t)c->fb_steps * 2 * ((m * m + 3) / 4) * 64 * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+        if (hipMalloc((void**)&c->dTable, (size_t)resolution * m * sizeof(float2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         r = upload_table(c, table_ri);
     } while (0);
     if (r != BAZ_MUSIC_OK) {
@@ -571,6 +604,9 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->dCand) (void)hipFree(c->dCand);
         if (c->dR) (void)hipFree(c->dR);
         if (c->dQ) (void)hipFree(c->dQ);
+        if (c->dG) (void)hipFree(c->dG);
+        if (c->dTable) (void)hipFree(c->dTable);
+        if (c->dRefine) (void)hipFree(c->dRefine);
         if (c->dPeakSpec) (void)hipFree(c->dPeakSpec);
         free_slots(c);
         if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
@@ -733,7 +769,7 @@ int baz_music_debug_evd(baz_music_ctx* c, const void* d_R, uint32_t batch, void*
     if (!c || !d_R || !d_Q || batch == 0) return BAZ_MUSIC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
-    return launch_evd(c, static_cast<const double2*>(d_R), batch, static_cast<double*>(d_Q), baz_music_q_stride(batch));
+    return launch_evd(c, static_cast<const double2*>(d_R), batch, static_cast<double*>(d_Q), baz_music_q_stride(batch), nullptr);
 }
 
 uint64_t baz_music_bytes_per_item(const baz_music_ctx* c, int with_spectrum)

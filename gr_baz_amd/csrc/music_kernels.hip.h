@@ -302,7 +302,8 @@ __device__ __forceinline__ void jacobi_sweep(Herm<M>& h)
 template <int M>
 __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict__ R,
                                                        double* __restrict__ Qs,
-                                                       uint32_t batch, uint32_t n, uint32_t qstride)
+                                                       uint32_t batch, uint32_t n, uint32_t qstride,
+                                                       double* __restrict__ Gs)
 {
     constexpr int MM = M * M;
     constexpr bool UNROLL = (M <= 4);   // register-resident, statically indexed (m >= 5 uses evd_proj_lds_kernel)
@@ -363,6 +364,15 @@ __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict_
 #pragma unroll
         for (int j = 0; j < M; ++j) rank += (wk[j] < wk[k] || (wk[j] == wk[k] && j < k)) ? 1 : 0;
         msk[k] = (rank < nnoise) ? 1.0 : 0.0;
+        // the noise eigenvectors themselves, for the literal-form refinement of near-null items (refine_literal_kernel):
+        // Gs[((rank*M + i)*2 + {re,im}) * qstride + item] = V[i][k]
+        if (valid && Gs && rank < nnoise) {
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                Gs[(size_t)((rank * M + i) * 2) * qstride + item] = h.Vr[i][k];
+                Gs[(size_t)((rank * M + i) * 2 + 1) * qstride + item] = h.Vi[i][k];
+            }
+        }
     }
 
 #pragma unroll
@@ -423,7 +433,8 @@ __device__ __forceinline__ int tour_idx(int r, int pos)
 template <int M>
 __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restrict__ R,
                                                            double* __restrict__ Qs,
-                                                           uint32_t batch, uint32_t n, uint32_t qstride)
+                                                           uint32_t batch, uint32_t n, uint32_t qstride,
+                                                           double* __restrict__ Gs)
 {
     constexpr int MM = M * M;
     constexpr int IPW = 64 / M;           // items per wave
@@ -632,6 +643,14 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
         for (int k = 0; k < M; ++k) V[j][k] = Vrow[k];
     }
     wave_lds_fence();
+    // the noise eigenvectors themselves (see evd_proj_kernel): lane j writes component j of every noise vector
+    if (valid && Gs) {
+        for (int r = 0; r < nnoise; ++r) {
+            const double2 v = V[j][sSel[sl][r] & 15];
+            Gs[(size_t)((r * M + j) * 2) * qstride + item] = v.x;
+            Gs[(size_t)((r * M + j) * 2 + 1) * qstride + item] = v.y;
+        }
+    }
     // lane j emits row j of Q (upper part): Q_jl = sum_{k in set} V[j][k] conj(V[l][k])
     if (valid) {
         for (int l = j; l < M; ++l) {
@@ -993,7 +1012,9 @@ __global__ __launch_bounds__(256) void topn_merge_kernel(const double* __restric
                                                           const float* __restrict__ spec,
                                                           float* __restrict__ ang, float* __restrict__ lvl,
                                                           uint32_t batch, uint32_t res, uint32_t n, uint32_t nsplit,
-                                                          uint32_t keep_mask)
+                                                          uint32_t keep_mask, double refine_below,
+                                                          uint32_t* __restrict__ refine_count,
+                                                          uint32_t* __restrict__ refine_list)
 {
     const uint32_t it = blockIdx.x * 256 + threadIdx.x;
     if (it >= batch) return;
@@ -1002,6 +1023,14 @@ __global__ __launch_bounds__(256) void topn_merge_kernel(const double* __restric
     for (int i = 0; i < NMAX; ++i) key[i] = key_empty();
     const size_t base = (size_t)it * nsplit * NMAX;
     for (uint32_t k = 0; k < nsplit * NMAX; ++k) key_insert<NMAX>(key, cand[base + k]);
+    // An item whose smallest d = a^H Q a is below ~m^2 1e-9 sits in a near-null of the noise subspace (SNR >~ 55 dB):
+    // there the projector form has lost its relative accuracy (its terms are O(1), fp64 leaves ~m^2 1e-16 absolute),
+    // so the whole item is redone in the reference's literal form by refine_literal_kernel.
+    if (refine_count) {
+        const uint64_t b0 = __builtin_bit_cast(uint64_t, key[0]);
+        const double d0 = __builtin_bit_cast(double, b0 & ~(uint64_t)(~keep_mask));
+        if (b0 < (uint64_t)BAZ_KEY_EMPTY_BITS && d0 < refine_below) refine_list[atomicAdd(refine_count, 1u)] = it;
+    }
 #pragma unroll
     for (int i = 0; i < NMAX; ++i)
         if (i < (int)n) {
@@ -1017,6 +1046,80 @@ __global__ __launch_bounds__(256) void topn_merge_kernel(const double* __restric
             ang[(size_t)it * n + i] = a;
             if (lvl) lvl[(size_t)it * n + i] = l;
         }
+}
+
+// -------------------------------------------------------------------------------------
+// 5b. Literal-form refinement of near-null items (flagged by topn_merge_kernel).  The reference evaluates
+//     strength = 1 / ||G^H a||^2 (.cc:110-121): a sum of squares, accurate to ~1e-10 relative even where it is
+//     1e-12 of ||a||^2.  The projector GEMM of the scan cannot be (see topn_merge_kernel), so for the rare item that
+//     contains such a bin the whole row is recomputed here from the noise eigenvectors the EVD kernel kept (Gs) and
+//     the raw steering table, the spectrum row is rewritten and the item's top-n redone.  One workgroup per flagged
+//     item, generic in m; with no flagged item the launch returns at once.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void refine_literal_kernel(const uint32_t* __restrict__ count,
+                                                              const uint32_t* __restrict__ list,
+                                                              const double* __restrict__ Gs, uint32_t gstride,
+                                                              const float2* __restrict__ table, float* __restrict__ spec,
+                                                              float* __restrict__ ang, float* __restrict__ lvl,
+                                                              uint32_t res, uint32_t m, uint32_t n, uint32_t keep_mask)
+{
+    constexpr int NMAX = 16;
+    __shared__ double2 sG[16 * 15];
+    __shared__ double sKeys[4][NMAX];
+    const uint32_t cnt = *count;
+    const uint32_t nn = m - n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t q = blockIdx.x; q < cnt; q += gridDim.x) {
+        const uint32_t item = list[q];
+        __syncthreads();
+        if (threadIdx.x < nn * m)
+            sG[threadIdx.x] = make_double2(Gs[(size_t)(threadIdx.x * 2) * gstride + item],
+                                           Gs[(size_t)(threadIdx.x * 2 + 1) * gstride + item]);
+        __syncthreads();
+        auto literal_d = [&](uint32_t b) {
+            double d = 0.0;
+            for (uint32_t k = 0; k < nn; ++k) {
+                double re = 0.0, im = 0.0;                      // g_k^H a = sum_i conj(G[k][i]) a_i
+                for (uint32_t i = 0; i < m; ++i) {
+                    const float2 a = table[(size_t)b * m + i];
+                    const double2 g = sG[k * m + i];
+                    re += g.x * (double)a.x + g.y * (double)a.y;
+                    im += g.x * (double)a.y - g.y * (double)a.x;
+                }
+                d += re * re + im * im;
+            }
+            return d;
+        };
+        double key[NMAX];
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) key[i] = key_empty();
+        for (uint32_t b = threadIdx.x; b < res; b += 256) {
+            const double d = literal_d(b);
+            if (spec) spec[(size_t)item * res + b] = strength_f32(d);
+            key_insert<NMAX>(key, make_key(d, b, keep_mask));     // NaN keys never enter (v_min/v_max drop them)
+        }
+#pragma unroll
+        for (int mask = 1; mask < 64; mask <<= 1) key_merge_xor<NMAX>(key, mask);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NMAX; ++i) sKeys[wave][i] = key[i];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w)
+#pragma unroll
+                for (int i = 0; i < NMAX; ++i) key_insert<NMAX>(key, sKeys[w][i]);
+#pragma unroll
+            for (int i = 0; i < NMAX; ++i)
+                if (i < (int)n) {
+                    const uint64_t kb = __builtin_bit_cast(uint64_t, key[i]);
+                    const uint32_t bin = (uint32_t)kb & ~keep_mask;
+                    const bool used = (kb < (uint64_t)BAZ_KEY_EMPTY_BITS) && (bin < res);
+                    ang[(size_t)item * n + i] = used ? (float)((double)bin * 360.0 / (double)res) : 0.0f;
+                    if (lvl) lvl[(size_t)item * n + i] = used ? strength_f32(literal_d(bin)) : 0.0f;   // == spectrum[bin]
+                }
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------
