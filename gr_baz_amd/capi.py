@@ -26,7 +26,7 @@ SYMBOLS = [
     "baz_music_process_device", "baz_music_set_stream", "baz_music_sync", "baz_music_reserve",
     "baz_music_profile", "baz_music_stage_ms", "baz_music_stage_name", "baz_music_debug_cov",
     "baz_music_debug_evd", "baz_music_q_stride", "baz_music_bytes_per_item", "baz_music_strerror",
-    "baz_music_last_hip_error", "baz_music_version", "baz_music_device_count", "baz_music_device", "baz_music_set_peak_mode",
+    "baz_music_last_hip_error", "baz_music_version", "baz_music_device_count", "baz_music_device", "baz_music_set_peak_mode", "baz_music_refined_items",
 ]
 
 _vp = ctypes.c_void_p
@@ -95,6 +95,8 @@ def lib():
     L.baz_music_device_count.argtypes = []
     L.baz_music_device.restype = ctypes.c_int
     L.baz_music_device.argtypes = [_vp]
+    L.baz_music_refined_items.restype = ctypes.c_int64
+    L.baz_music_refined_items.argtypes = [_vp]
     L.baz_music_set_peak_mode.restype = ctypes.c_int
     L.baz_music_set_peak_mode.argtypes = [_vp, ctypes.c_int]
     _lib = L
@@ -179,6 +181,10 @@ class Context:
                                                  _vp(d_lvl) if d_lvl else None,
                                                  _vp(d_spec) if d_spec else None),
                   "baz_music_process_device")
+
+    def refined_items(self):
+        """Items of the last process call that were recomputed in literal form (near-null bins, extreme SNR)."""
+        return int(lib().baz_music_refined_items(self._h))
 
     def set_peak_mode(self, mode):
         """0: the reference's n strongest bins (default); 1: n strongest local maxima (opt-in extension)."""

@@ -522,9 +522,18 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
     if (r) return r;
     {   // near-null items (flagged by the merge) are redone in the reference's literal form; usually none
         ProfScope ps(c, BAZ_MUSIC_STAGE_MERGE);
-        hipLaunchKernelGGL(refine_literal_kernel, dim3(64), dim3(256), 0, c->stream, c->dRefine, c->dRefine + 1, c->dG,
-                           qstride, c->dTable, spec, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), c->res, c->m,
-                           c->n, c->keep_mask);
+        const float keep_below = (float)(0.01 / c->refine_below);
+#define BAZ_REFINE(NM)                                                                                              \
+    hipLaunchKernelGGL((refine_literal_kernel<NM>), dim3(1024), dim3(256), 0, c->stream, c->dRefine, c->dRefine + 1,  \
+                       c->dG, qstride, c->dTable, spec, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), c->res, \
+                       c->m, c->n, c->keep_mask, keep_below)
+        switch (topn_list_len(c->n)) {
+            case 2: BAZ_REFINE(2); break;
+            case 4: BAZ_REFINE(4); break;
+            case 8: BAZ_REFINE(8); break;
+            default: BAZ_REFINE(16); break;
+        }
+#undef BAZ_REFINE
         HIP_TRY(c, hipGetLastError());
     }
     if (c->peak_mode) return launch_peaks(c, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), spec);
@@ -814,6 +823,18 @@ int baz_music_set_peak_mode(baz_music_ctx* c, int mode)
     std::lock_guard<std::mutex> lk(c->mtx);
     c->peak_mode = mode;
     return BAZ_MUSIC_OK;
+}
+
+int64_t baz_music_refined_items(baz_music_ctx* c)
+{
+    if (!c) return -1;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    DeviceGuard guard(c->device);
+    if (!c->dRefine) return 0;
+    uint32_t n = 0;
+    if (hipStreamSynchronize(c->stream) != hipSuccess ||
+        hipMemcpy(&n, c->dRefine, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)n;
 }
 
 int baz_music_device(const baz_music_ctx* c) { return c ? c->device : BAZ_MUSIC_E_INVALID; }

@@ -1056,14 +1056,15 @@ __global__ __launch_bounds__(256) void topn_merge_kernel(const double* __restric
 //     the raw steering table, the spectrum row is rewritten and the item's top-n redone.  One workgroup per flagged
 //     item, generic in m; with no flagged item the launch returns at once.
 // -------------------------------------------------------------------------------------
+template <int NMAX>
 __global__ __launch_bounds__(256) void refine_literal_kernel(const uint32_t* __restrict__ count,
                                                               const uint32_t* __restrict__ list,
                                                               const double* __restrict__ Gs, uint32_t gstride,
                                                               const float2* __restrict__ table, float* __restrict__ spec,
                                                               float* __restrict__ ang, float* __restrict__ lvl,
-                                                              uint32_t res, uint32_t m, uint32_t n, uint32_t keep_mask)
+                                                              uint32_t res, uint32_t m, uint32_t n, uint32_t keep_mask,
+                                                              float keep_strength_below)
 {
-    constexpr int NMAX = 16;
     __shared__ double2 sG[16 * 15];
     __shared__ double sKeys[4][NMAX];
     const uint32_t cnt = *count;
@@ -1094,8 +1095,16 @@ __global__ __launch_bounds__(256) void refine_literal_kernel(const uint32_t* __r
 #pragma unroll
         for (int i = 0; i < NMAX; ++i) key[i] = key_empty();
         for (uint32_t b = threadIdx.x; b < res; b += 256) {
-            const double d = literal_d(b);
-            if (spec) spec[(size_t)item * res + b] = strength_f32(d);
+            double d;
+            // with the spectrum at hand only the bins near a null are redone: a strength below ~1e-2 / threshold means
+            // d is >= 100x above it, where the projector form is good to ~1e-8 (its value is kept, the key uses 1/s)
+            const float s0 = spec ? spec[(size_t)item * res + b] : 0.0f;
+            if (spec && s0 < keep_strength_below) {
+                d = 1.0 / (double)s0;
+            } else {
+                d = literal_d(b);
+                if (spec) spec[(size_t)item * res + b] = strength_f32(d);
+            }
             key_insert<NMAX>(key, make_key(d, b, keep_mask));     // NaN keys never enter (v_min/v_max drop them)
         }
 #pragma unroll
