@@ -281,7 +281,9 @@ def test_extreme_snr_spectra_match_the_literal_form(m, n, K, res, batch, snr, se
     ao, lo, so = mr.work_batch(items, table, m, n)
     with _capi().Context(m, n, m * K, res, table) as ctx:
         ang, lvl, spec = device_run(ctx, items, gpu_device)
+        refined = ctx.refined_items()
         a2, l2, _ = device_run(ctx, items, gpu_device, want_spec=False)
+    assert 0 < refined <= batch                     # the literal-form path did run
     assert_spectrum_close(spec, so)
     assert_doa_match(ang, lvl, ao, lo, res, so.astype(np.float64))
     assert_doa_match(a2, l2, ao, lo, res, so.astype(np.float64))
@@ -304,7 +306,8 @@ def test_peak_mode_is_opt_in_and_matches_its_definition(cfg, n_items, gpu_device
         ctx.set_peak_mode(0)
         a3, l3, s3 = device_run(ctx, c["items"], gpu_device)
     ao, lo, so, st = mo.music_doa_work_batch(c["items"], c["table"], m, n)
-    assert_doa_match(a0, l0, ao, lo, res, st) and np.array_equal(a0, a3) and np.array_equal(l0, l3)
+    assert_doa_match(a0, l0, ao, lo, res, st)
+    assert np.array_equal(a0, a3) and np.array_equal(l0, l3)
     assert np.array_equal(s0, s1) and np.array_equal(s0, s3)
     for b in range(n_items):
         ea, el = mo.peak_pick(s1[b], n)
