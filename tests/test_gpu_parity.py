@@ -283,7 +283,8 @@ def test_extreme_snr_spectra_match_the_literal_form(m, n, K, res, batch, snr, se
         ang, lvl, spec = device_run(ctx, items, gpu_device)
         refined = ctx.refined_items()
         a2, l2, _ = device_run(ctx, items, gpu_device, want_spec=False)
-    assert 0 < refined <= batch                     # the literal-form path did run
+    if float(so.max()) > 2.0 / (m * m * 1e-9):      # some d is clearly below the flag threshold m*max||a||^2*1e-9
+        assert 0 < refined <= batch                 # -> the literal-form path did run
     assert_spectrum_close(spec, so)
     assert_doa_match(ang, lvl, ao, lo, res, so.astype(np.float64))
     assert_doa_match(a2, l2, ao, lo, res, so.astype(np.float64))
