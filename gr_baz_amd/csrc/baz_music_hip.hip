@@ -486,8 +486,8 @@ bool is_pinned_host(const void* p)
     return a.type == hipMemoryTypeHost;
 }
 
-// One pass of the hot path over `batch` device-resident items: three launches (+ the tiny top-n merge) back
-// to back on the context's stream.  (Cutting the batch into sub-batches and overlapping covariance/EVD of
+// One pass of the hot path over `batch` device-resident items: covariance, EVD, scan, the tiny top-n merge and the
+// (normally empty) literal-form refinement, back to back on the context's stream.  (Cutting the batch into sub-batches and overlapping covariance/EVD of
 // sub-batch i+1 with the scan of sub-batch i on two extra streams was measured and is SLOWER -- 0.53 ms ->
 // 0.60 / 0.70 / 1.05 ms at 2 / 4 / 8 sub-batches, profiles/r01_two_stream_pipeline_negative.txt: the
 // cross-stream event dependencies cost more than the overlap buys.)

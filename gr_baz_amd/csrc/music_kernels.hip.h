@@ -6,7 +6,9 @@
 //                                 emitted as the real coefficients of the projector Q = G G^H
 //   scan_mfma_kernel  .cc:101-141 per-bin strength 1/||G^H a||^2 (as 1/(a^H Q a), an fp64 MFMA GEMM),
 //                                 optional spectrum port, per-range top-n candidates
-//   topn_merge_kernel .cc:129-155 final top-n across bin ranges, ang/lvl outputs
+//   topn_merge_kernel .cc:129-155 final top-n across bin ranges, ang/lvl outputs; flags near-null items
+//   refine_literal_kernel .cc:110-141 the flagged items again, in the reference's literal form ||G^H a||^2
+//   peak_pick_kernel  (opt-in extension, no reference counterpart) n strongest local maxima
 //
 // Precision contract: inputs and the steering table stay fp32 in HBM
 // (that is what the reference sees); every accumulation is fp64 (exact widening, like the
