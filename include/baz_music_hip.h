@@ -132,7 +132,8 @@ BAZ_MUSIC_API const char* baz_music_version(void);
 BAZ_MUSIC_API int baz_music_set_peak_mode(baz_music_ctx* ctx, int mode);
 /* Statistic: how many items of the LAST process call were recomputed in the reference's literal form because they
  * contained a near-null bin (d = ||G^H a||^2 below ~m 1e-9 max||a||^2, i.e. SNR >~ 55 dB); blocks until that call is
- * done.  -1 on error.  See DESIGN.md 2 (near-nulls). */
+ * done (a host-fed call that was cut into several chunks reports its last chunk).  -1 on error.  See DESIGN.md 2
+ * (near-nulls). */
 BAZ_MUSIC_API int64_t baz_music_refined_items(baz_music_ctx* ctx);
 BAZ_MUSIC_API int baz_music_device_count(void);
 BAZ_MUSIC_API int baz_music_device(const baz_music_ctx* ctx);
