@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(256) void refine_literal_kernel(const uint32_t* __r
             // d is >= 100x above it, where the projector form is good to ~1e-8 (its value is kept, the key uses 1/s)
             const float s0 = spec ? spec[(size_t)item * res + b] : 0.0f;
             if (spec && s0 < keep_strength_below) {
-                d = 1.0 / (double)s0;
+                d = (double)__builtin_amdgcn_rcpf(s0);     // float precision is all the stored strength carries
             } else {
                 d = literal_d(b);
                 if (spec) spec[(size_t)item * res + b] = strength_f32(d);
