@@ -237,7 +237,7 @@ struct Herm {
 };
 
 template <int M>
-__device__ __forceinline__ void jacobi_rotate(Herm<M>& h, const int p, const int q)
+__device__ __forceinline__ void jacobi_rotate(Herm<M>& h, const int p, const int q, const bool active)
 {
     const double apr = h.Ar[p][q], api = h.Ai[p][q];
     const double g2 = apr * apr + api * api;
@@ -245,7 +245,9 @@ __device__ __forceinline__ void jacobi_rotate(Herm<M>& h, const int p, const int
     // threshold (|a_pq| <= 1e-20) is 4 orders below fp64 resolution.  It also keeps lanes that
     // converged early (while the rest of the wave still sweeps) from rotating on off-diagonals that
     // have shrunk quadratically into the denormal range, where u = a_pq/|a_pq| loses unit modulus.
-    const bool rot = g2 > 1e-40;
+    // `active` is false for a lane whose item has already converged while its wave-mates still sweep: it then applies
+    // the exact identity (c = 1, s = 0), so an item's result never depends on which items share its wave
+    const bool rot = active && g2 > 1e-40;
     const double gg = sqrt(g2);
     const double ig = rot ? 1.0 / gg : 0.0;
     const double ur = rot ? apr * ig : 1.0;
@@ -286,18 +288,18 @@ __device__ __forceinline__ void jacobi_rotate(Herm<M>& h, const int p, const int
 }
 
 template <int M, bool UNROLL>
-__device__ __forceinline__ void jacobi_sweep(Herm<M>& h)
+__device__ __forceinline__ void jacobi_sweep(Herm<M>& h, const bool active)
 {
     if constexpr (UNROLL) {
 #pragma unroll
         for (int p = 0; p < M - 1; ++p)
 #pragma unroll
-            for (int q = p + 1; q < M; ++q) jacobi_rotate<M>(h, p, q);
+            for (int q = p + 1; q < M; ++q) jacobi_rotate<M>(h, p, q, active);
     } else {
 #pragma nounroll
         for (int p = 0; p < M - 1; ++p)
 #pragma nounroll
-            for (int q = p + 1; q < M; ++q) jacobi_rotate<M>(h, p, q);
+            for (int q = p + 1; q < M; ++q) jacobi_rotate<M>(h, p, q, active);
     }
 }
 
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict_
         }
         const bool done = !(off > 1e-33 * dia);   // also true for NaN input -> bounded loop either way
         if (__all(done)) break;
-        jacobi_sweep<M, UNROLL>(h);
+        jacobi_sweep<M, UNROLL>(h, !done);
     }
     // A covariance with NaN/Inf entries has no eigen-decomposition (the reference's eig_sym fails there): poison the
     // projector so that the item's spectrum is NaN and no bin is ever inserted (.cc:131) -> (0, 0) outputs.
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
                     const double2 apq = A[pp][qq];
                     const double app = A[pp][pp].x, aqq = A[qq][qq].x;
                     const double g2 = apq.x * apq.x + apq.y * apq.y;
-                    const bool rot = g2 > 1e-40;
+                    const bool rot = !done && g2 > 1e-40;   // a converged item freezes (exact identity) while wave-mates sweep
                     const double gg = sqrt(g2);
                     const double ig = rot ? 1.0 / gg : 0.0;
                     ur = rot ? apq.x * ig : 1.0;

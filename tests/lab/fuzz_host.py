@@ -1,0 +1,40 @@
+"""Randomised check of the host-fed path (baz_music_process: chunking, optional ports, peak mode) against the
+device-resident path of the same context.  argv: cases [seed]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 77)
+os.environ["BAZ_MUSIC_CHUNK_MIB"] = "1"          # many chunks even for small batches
+from gr_baz_amd import capi
+from oracle import music_oracle as mo
+dev = torch.device("cuda:0")
+fails = 0
+for case in range(ncases):
+    m = int(rng.integers(2, 17)); n = int(rng.integers(1, m)); K = int(rng.choice([4, 16, 64, 256])) ; K = max(K, m)
+    res = int(rng.choice([64, 360, 361, 1000, 3600])); batch = int(rng.choice([1, 7, 64, 200, 1000, 3000]))
+    snr = float(rng.choice([10.0, 20.0, 40.0, 70.0])); peak = bool(rng.random() < 0.3)
+    want_lvl = bool(rng.random() < 0.8); want_spec = bool(rng.random() < 0.7)
+    arr = mo.array_geometry(m)
+    table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
+    items = mo.synth_items(batch, m, m * K, arr, mo.FREQUENCY, mo.SPACING, angles_deg=tuple(rng.uniform(0, 360, n)), snr_db=snr,
+                           seed=int(rng.integers(1 << 30)))
+    with capi.Context(m, n, m * K, res, table) as ctx:
+        ctx.set_peak_mode(1 if peak else 0)
+        x = torch.from_numpy(items.view(np.float32)).to(dev)
+        ang = torch.zeros(batch, n, dtype=torch.float32, device=dev); lvl = torch.zeros_like(ang)
+        spec = torch.zeros(batch, res, dtype=torch.float32, device=dev)
+        ctx.process_device(x.data_ptr(), batch, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr()); ctx.sync()
+        ha, hl, hs = ctx.process(items, want_lvl=want_lvl, want_spectrum=want_spec)
+    ok = np.array_equal(ha, ang.cpu().numpy())
+    if want_lvl:
+        dl = lvl.cpu().numpy()
+        if want_spec: ok &= np.array_equal(hl, dl, equal_nan=True)
+        else: ok &= bool(np.all(np.abs(hl - dl) <= 2e-7 * np.abs(dl)))   # without port 2 lvl comes from the key's d (36 bits)
+    if want_spec: ok &= np.array_equal(hs, spec.cpu().numpy(), equal_nan=True)
+    if not ok:
+        fails += 1
+        da = ang.cpu().numpy()
+        print("FAIL case %d m=%d n=%d K=%d res=%d batch=%d snr=%g peak=%s lvl=%s spec=%s: ang mismatches %d" % (case, m, n, K, res, batch, snr, peak, want_lvl, want_spec, int((ha != da).sum())), flush=True)
+print("fuzz_host: %d cases, %d failures" % (ncases, fails))
+sys.exit(1 if fails else 0)

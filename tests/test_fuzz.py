@@ -27,3 +27,10 @@ def test_music_path_random_shapes(seed, gpu_device):
 @pytest.mark.gpu
 def test_frontend_blocks_random_parameters(gpu_device):
     assert "0 failures" in _run("fuzz_frontend.py", 150, 8)
+
+
+@pytest.mark.gpu
+def test_host_fed_path_equals_device_path_for_random_shapes(gpu_device):
+    """Chunked host-fed calls, optional ports and peak mode against the device-resident path of the same context:
+    bit-identical, i.e. an item's result does not depend on how the batch was cut (converged Jacobi lanes freeze)."""
+    assert "0 failures" in _run("fuzz_host.py", 60, 3)

@@ -238,3 +238,24 @@ def test_host_block_general_work_like_the_scheduler(gpu_device, capfd):
     need = blk.forecast(1000)                      # 1008: still the old ratio, like the reference's forecast
     produced, out, consumed = blk.general_work(g["x"][:need], 1000)
     assert produced == (need - 8) // 2 + 1 and consumed == 2 * produced   # never reads past the window it was given
+
+
+@pytest.mark.gpu
+def test_hip_host_path_with_row_stride_larger_than_the_window(gpu_device):
+    """Stream-major buffers whose row stride exceeds the samples offered (a scheduler hands out a window of a larger
+    buffer): in_stride > ninput and out_stride > noutput through baz_resamp_process."""
+    from gr_baz_amd import resamp
+    rng = np.random.default_rng(21)
+    S, L, OS = 3, 5000, 4000
+    x = (rng.standard_normal((S, L)) + 1j * rng.standard_normal((S, L))).astype(np.complex64)
+    out = np.full((S, OS), np.complex64(-7 - 7j), np.complex64)
+    with resamp.Resampler(0.25, 1.3, nstreams=S) as blk:
+        consumed = ctypes.c_uint64(0)
+        f32p = ctypes.POINTER(ctypes.c_float)
+        n = resamp.lib().baz_resamp_process(blk._h, x.view(np.float32).ctypes.data_as(f32p), L, 2000,
+                                            out.view(np.float32).ctypes.data_as(f32p), OS, 1000, ctypes.byref(consumed))
+        assert n == 1000
+    for s in range(S):
+        o, k = rr.Resampler(0.25, 1.3).work(x[s, :2000], 1000)
+        assert k == consumed.value and np.array_equal(out[s, :1000].view(np.uint32), o.view(np.uint32))
+        assert np.all(out[s, 1000:] == np.complex64(-7 - 7j))        # nothing written past the outputs produced
