@@ -37,9 +37,12 @@ struct baz_music_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;      // the stream process_device() launches on (own or caller's)
     // steering table as the real bilinear-form table F[bin][m*m] (fp64) in MFMA B-operand order:
-    // FB[step][chunk][lane] (double2), see build_FB
+    // FB[step][chunk][lane] (double2), see build_FB; one padded step in front of step 0 and one behind the last
+    // (the scan's row classes read shifted windows), dFB points at the allocation, step 0 is dFB + fb_step_elems
     double2* dFB = nullptr;
     uint32_t fb_steps = 0;   // 64-bin steps
+    size_t fb_step_elems = 0;   // double2 elements per step of FB (2 * KS * 64)
+    uint32_t nclass = 1;     // row classes of the spectrum port: 64 / gcd(res, 64) when res % 4 == 0, else 1
     uint32_t keep_mask = 0;  // low-word mask of the top-n key (bin index lives in the cleared bits)
     // per-range top-n candidate keys (scan_mfma_kernel -> topn_merge_kernel)
     double* dCand = nullptr;
@@ -64,11 +67,15 @@ struct baz_music_ctx {
     std::mutex mtx;   // serialises set_table against process*, like d_mutex (.cc:67,101)
     int profiling = 0;      // 0 off, 1 every stage, 2 only the dominant (scan) stage
     int lab_variant = 0;
-    // literal-form refinement of near-null items (refine_literal_kernel)
+    // literal-form refinement of near-null tiles (literal_tile() inside the scan)
     double* dG = nullptr;          // noise eigenvectors, item-minor like dQ (cap * m*m * 2 doubles)
-    float2* dTable = nullptr;      // raw steering table [res][m] (complex64)
-    uint32_t* dRefine = nullptr;   // [0] = count, [1..cap] = flagged items
+    double2* dTB = nullptr;        // raw steering table as fp64 MFMA B-operand image (build_TB), padded like dFB
+    size_t tb_step_elems = 0;      // double2 elements per step of TB (2 * ceil(2m/4) * 64)
+    unsigned long long* dRefined = nullptr;   // statistic: (item, bin) values recomputed by the last call
     double refine_below = 0.0;     // threshold on d = a^H Q a
+    int refine_off = 0;            // lab (BAZ_MUSIC_NO_REFINE=1): projector form everywhere
+    int lab_cov_old = 0;           // lab (BAZ_MUSIC_COV_OLD=1): the round-1 covariance kernel at m = 4
+    uint32_t cov4_resident_blocks = 256u * 6u;   // blocks of cov4_x4_kernel the device holds at once
     int peak_mode = 0;      // 0: the reference's n strongest bins; 1 (opt-in extension): n strongest local maxima
     float* dPeakSpec = nullptr;   // internal spectrum when peak mode runs without the spectrum port
     size_t peak_spec_cap = 0;     // floats
@@ -131,27 +138,49 @@ void build_F(const float* table_ri, uint32_t m, uint32_t res, std::vector<double
 // component t&1, lane = (g = lane>>4, c = lane&15):
 //     value = F[bin = 64*step + 4*c + t][e = 4*s + g]          (0 for the K padding e >= m*m)
 // i.e. tile t of a 64-bin step carries the bins 4c + t in its columns, so that a lane's accumulator
-// registers of the 4 tiles are 4 consecutive bins.  Bins >= res (only in the last step) get a huge
+// registers of the 4 tiles are 4 consecutive bins.  step runs from -1 to `steps` inclusive (array index step + 1):
+// the scan's row classes read windows shifted by up to 60 bins.  Bins outside [0, res) get a huge
 // diagonal: d = BIG * trace(Q) = BIG * (m - n), finite, never stored, never among the top n.
 void build_FB(const std::vector<double>& F, uint32_t m, uint32_t res, uint32_t steps, std::vector<double>& FB)
 {
     const uint32_t mm = m * m;
     const uint32_t ks = (mm + 3) / 4;
     const double BIG = 1e300;
-    FB.assign((size_t)steps * 2 * ks * 64 * 2, 0.0);
-    for (uint32_t st = 0; st < steps; ++st)
+    FB.assign((size_t)(steps + 2) * 2 * ks * 64 * 2, 0.0);
+    for (uint32_t sti = 0; sti < steps + 2; ++sti)
         for (uint32_t s = 0; s < ks; ++s)
             for (uint32_t t = 0; t < 4; ++t)
                 for (uint32_t lane = 0; lane < 64; ++lane) {
                     const uint32_t g = lane >> 4, c = lane & 15;
-                    const uint32_t bin = 64 * st + 4 * c + t;
+                    const int64_t bin = 64 * ((int64_t)sti - 1) + 4 * c + t;
                     const uint32_t e = 4 * s + g;
                     double v = 0.0;
                     if (e < mm) {
-                        if (bin < res) v = F[(size_t)bin * mm + e];
+                        if (bin >= 0 && bin < (int64_t)res) v = F[(size_t)bin * mm + e];
                         else v = ((e / m) == (e % m)) ? BIG : 0.0;
                     }
-                    FB[(((size_t)st * 2 * ks + 2 * s + (t >> 1)) * 64 + lane) * 2 + (t & 1)] = v;
+                    FB[(((size_t)sti * 2 * ks + 2 * s + (t >> 1)) * 64 + lane) * 2 + (t & 1)] = v;
+                }
+}
+
+// The raw table in the same B-operand order, for the literal form ||G^H a||^2 of near-null tiles (literal_tile):
+// K dimension = the 2m real coordinates (re a_0, im a_0, re a_1, ...), fp32 entries widened exactly (.cc:110-112):
+//     TB[step][2*s + (t>>1)][lane].{x,y}[t&1] = (e & 1 ? imag : real)(table[bin = 64*step + 4*c + t][e >> 1]),  e = 4*s + g
+// zero outside [0, res) (those bins keep their projector value) and for the K padding e >= 2m.
+void build_TB(const float* table_ri, uint32_t m, uint32_t res, uint32_t steps, std::vector<double>& TB)
+{
+    const uint32_t ks2 = (2 * m + 3) / 4;
+    TB.assign((size_t)(steps + 2) * 2 * ks2 * 64 * 2, 0.0);
+    for (uint32_t sti = 0; sti < steps + 2; ++sti)
+        for (uint32_t s = 0; s < ks2; ++s)
+            for (uint32_t t = 0; t < 4; ++t)
+                for (uint32_t lane = 0; lane < 64; ++lane) {
+                    const uint32_t g = lane >> 4, c = lane & 15;
+                    const int64_t bin = 64 * ((int64_t)sti - 1) + 4 * c + t;
+                    const uint32_t e = 4 * s + g;
+                    double v = 0.0;
+                    if (e < 2 * m && bin >= 0 && bin < (int64_t)res) v = (double)table_ri[((size_t)bin * m + (e >> 1)) * 2 + (e & 1)];
+                    TB[(((size_t)sti * 2 * ks2 + 2 * s + (t >> 1)) * 64 + lane) * 2 + (t & 1)] = v;
                 }
 }
 
@@ -165,12 +194,10 @@ int ensure_workspace(baz_music_ctx* c, uint32_t batch)
     if (c->dR) { (void)hipFree(c->dR); c->dR = nullptr; }
     if (c->dQ) { (void)hipFree(c->dQ); c->dQ = nullptr; }
     if (c->dG) { (void)hipFree(c->dG); c->dG = nullptr; }
-    if (c->dRefine) { (void)hipFree(c->dRefine); c->dRefine = nullptr; }
     c->cap = 0;
     HIP_TRY(c, hipMalloc((void**)&c->dR, (size_t)cap * mm * sizeof(double2)));
     HIP_TRY(c, hipMalloc((void**)&c->dQ, (size_t)cap * mm * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->dG, (size_t)cap * mm * 2 * sizeof(double)));
-    HIP_TRY(c, hipMalloc((void**)&c->dRefine, ((size_t)cap + 1) * sizeof(uint32_t)));
     c->cap = cap;
     return BAZ_MUSIC_OK;
 }
@@ -220,6 +247,15 @@ void prof_collect(baz_music_ctx* c)
 template <int M>
 int launch_cov_t(baz_music_ctx* c, const float* d_in, uint32_t batch, double2* dR)
 {
+    if constexpr (M == 4) {
+        if ((c->K % 256u) == 0 && !c->lab_cov_old) {   // dwordx4 stream + LDS transpose + 4x4x4 MFMA blocks
+            // persistent waves: exactly the blocks that are resident at once (no tail wave of blocks)
+            const uint32_t blocks = std::min<uint32_t>((batch + 3) / 4, c->cov4_resident_blocks);
+            hipLaunchKernelGGL(cov4_x4_kernel, dim3(blocks), dim3(256), 0, c->stream, d_in, dR, batch, c->K);
+            HIP_TRY(c, hipGetLastError());
+            return BAZ_MUSIC_OK;
+        }
+    }
     if constexpr (M <= 8) {    // one 16x16 Gram tile holds 16/(2m) items
         constexpr int IPT = 16 / (2 * M);
         const uint32_t ntiles = (batch + IPT - 1) / IPT;
@@ -276,21 +312,25 @@ int launch_evd(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ, 
 #undef BAZ_CALL
 }
 
-// Launch geometry of the scan: (16-item groups) x (`nsplit` ranges of 64-bin steps), chosen so that a launch
-// has >= ~8 waves/SIMD worth of wave tasks even for small batches / long tables (config 3: 4,096 items x
-// 36,000 bins).  Every range of every item yields NMAX candidate keys for topn_merge_kernel.
+// Launch geometry of the scan: rows are taken class by class (class k = items nclass*j + k, see the kernel's ROW
+// CLASSES note), every class padded to a multiple of 64 rows (one block = 4 waves x 16 rows of ONE class), times
+// `nsplit` ranges of 64-bin steps, chosen so that a launch has >= ~8 waves/SIMD worth of wave tasks even for small
+// batches / long tables (config 3: 4,096 items x 36,000 bins).  Every range of every item yields NMAX candidate keys
+// for topn_merge_kernel.
 struct ScanGeom {
-    uint32_t groups, nsplit, blocks;
+    uint32_t groups, nsplit, blocks, rows_per_class;
 };
 
-ScanGeom scan_geometry(uint32_t batch, uint32_t nsteps)
+ScanGeom scan_geometry(uint32_t batch, uint32_t nsteps, uint32_t nclass)
 {
     ScanGeom G;
-    G.groups = (batch + 15) / 16;
+    G.rows_per_class = round_up((batch + nclass - 1) / nclass, 64);
+    G.groups = nclass * (G.rows_per_class / 16);
+    const uint32_t live_groups = (batch + 15) / 16;
     const uint32_t want_tasks = 256u * 4u * 8u * 4u;
-    uint32_t ns = (want_tasks + G.groups - 1) / G.groups;
+    uint32_t ns = (want_tasks + live_groups - 1) / live_groups;
     G.nsplit = std::max<uint32_t>(1u, std::min<uint32_t>(ns, std::min<uint32_t>(nsteps, 64u)));
-    G.blocks = ((G.groups + 3) / 4) * G.nsplit;
+    G.blocks = (G.groups / 4) * G.nsplit;
     return G;
 }
 
@@ -308,26 +348,39 @@ template <int M, int NMAX>
 int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t batch, float* d_ang,
                   float* d_lvl, float* d_spec)
 {
-    const ScanGeom G = scan_geometry(batch, c->fb_steps);
+    const ScanGeom G = scan_geometry(batch, c->fb_steps, c->nclass);
     double* cand = c->dCand;
     if ((size_t)batch * G.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;   // reserve_candidates() sized it
     const bool spec = d_spec != nullptr;
     const bool vec4 = (c->res % 4u) == 0 && (reinterpret_cast<uintptr_t>(d_spec) % 16u) == 0;
-#define BAZ_SCAN_LAUNCH(SPEC, VEC4)                                                                          \
-    hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4>), dim3(G.blocks), dim3(256), 0, c->stream, dQ, \
-                       c->dFB, d_spec, cand, batch, c->res, qstride, c->fb_steps, G.nsplit, G.groups, c->keep_mask)
-    if constexpr (M == 4 && NMAX == 2) {   // lab (BAZ_MUSIC_SCAN_VARIANT=1): cached spectrum stores, for the A/B in DESIGN.md 5.3
-        if (spec && c->lab_variant == 1) {
-            hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, true, false, 32>), dim3(G.blocks), dim3(256), 0, c->stream, dQ,
-                               c->dFB, d_spec, cand, batch, c->res, qstride, c->fb_steps, G.nsplit, G.groups, c->keep_mask);
+    ScanRefine rf;
+    rf.Gs = c->refine_off ? nullptr : c->dG;
+    rf.TB = c->dTB + c->tb_step_elems;
+    rf.below = c->refine_below;
+    rf.count = c->dRefined;
+    const double2* fb0 = c->dFB + c->fb_step_elems;   // step 0 (a padded step lies in front)
+#define BAZ_SCAN_ARGS dQ, fb0, d_spec, cand, batch, c->res, qstride, G.nsplit, c->nclass, G.rows_per_class, c->keep_mask, c->n, rf
+#define BAZ_SCAN_LAUNCH(SPEC, VEC4, ABLV, AUXV)                                                                    \
+    hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4, ABLV, AUXV>), dim3(G.blocks), dim3(256), 0, c->stream, \
+                       BAZ_SCAN_ARGS)
+    if constexpr (M == 4 && NMAX == 2) {   // lab switches for the A/Bs in DESIGN.md 5.3 (BAZ_MUSIC_SCAN_VARIANT)
+        if (spec && vec4 && c->lab_variant) {
+            switch (c->lab_variant) {
+                case 2: BAZ_SCAN_LAUNCH(true, true, 64, (1 | 2 | 16)); break;   // ungated top-n network (round 1)
+                case 3: BAZ_SCAN_LAUNCH(true, true, 0, 0); break;               // plain cached spectrum stores
+                case 4: BAZ_SCAN_LAUNCH(true, true, 0, 2); break;               // nt
+                case 5: BAZ_SCAN_LAUNCH(true, true, 0, (1 | 16)); break;        // sc0 sc1
+                default: BAZ_SCAN_LAUNCH(true, true, 0, (1 | 2 | 16)); break;
+            }
             HIP_TRY(c, hipGetLastError());
             return BAZ_MUSIC_OK;
         }
     }
-    if (spec && vec4) BAZ_SCAN_LAUNCH(true, true);
-    else if (spec) BAZ_SCAN_LAUNCH(true, false);
-    else BAZ_SCAN_LAUNCH(false, false);
+    if (spec && vec4) BAZ_SCAN_LAUNCH(true, true, 0, (1 | 2 | 16));
+    else if (spec) BAZ_SCAN_LAUNCH(true, false, 0, (1 | 2 | 16));
+    else BAZ_SCAN_LAUNCH(false, false, 0, (1 | 2 | 16));
 #undef BAZ_SCAN_LAUNCH
+#undef BAZ_SCAN_ARGS
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
 }
@@ -335,10 +388,9 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
 template <int NMAX>
 int launch_merge_t(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl, float* d_spec)
 {
-    const ScanGeom G = scan_geometry(batch, c->fb_steps);
+    const ScanGeom G = scan_geometry(batch, c->fb_steps, c->nclass);
     hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream, c->dCand,
-                       d_spec, d_ang, d_lvl, batch, c->res, c->n, G.nsplit, c->keep_mask, c->refine_below, c->dRefine,
-                       c->dRefine + 1);
+                       d_spec, d_ang, d_lvl, batch, c->res, c->n, G.nsplit, c->keep_mask);
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
 }
@@ -361,12 +413,24 @@ uint32_t topn_list_len(uint32_t n) { return n <= 2 ? 2u : (n <= 4 ? 4u : (n <= 8
 // candidate keys one scan launch over `nb` items produces (mirrors launch_scan_t's geometry)
 size_t cand_entries(const baz_music_ctx* c, uint32_t nb)
 {
-    return (size_t)nb * scan_geometry(nb, c->fb_steps).nsplit * topn_list_len(c->n);
+    return (size_t)nb * scan_geometry(nb, c->fb_steps, c->nclass).nsplit * topn_list_len(c->n);
+}
+
+// nb * nsplit(nb) is not monotonic in nb (nsplit = ceil(want_tasks / groups) while that is <= 64 and <= nsteps), so
+// a reservation for `batch` items is sized for the worst launch of ANY nb <= batch: nb * nsplit(nb) < nb *
+// (want_tasks / ceil(nb/16) + 1) <= 16 * want_tasks + nb, and <= nb * min(64, nsteps).  A smaller batch or the short
+// tail chunk of baz_music_process then never re-allocates in the middle of the pipeline.
+size_t cand_entries_upto(const baz_music_ctx* c, uint32_t batch)
+{
+    const size_t want_tasks = 256u * 4u * 8u * 4u;   // scan_geometry()
+    const size_t cap_split = std::min<size_t>(64u, std::max<uint32_t>(1u, c->fb_steps));
+    const size_t worst = std::min<size_t>((size_t)batch * cap_split, 16u * want_tasks + (size_t)batch);
+    return std::max(worst, (size_t)batch) * topn_list_len(c->n);
 }
 
 int reserve_candidates(baz_music_ctx* c, uint32_t batch)
 {
-    return ensure_candidates(c, cand_entries(c, batch));
+    return ensure_candidates(c, std::max(cand_entries(c, batch), cand_entries_upto(c, batch)));
 }
 
 int launch_merge(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl, float* d_spec)
@@ -420,8 +484,11 @@ int upload_table(baz_music_ctx* c, const float* table_ri)
     build_FB(F, c->m, c->res, c->fb_steps, FB);
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // no batch in flight reads the old table
     HIP_TRY(c, hipMemcpy(c->dFB, FB.data(), FB.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->dTable, table_ri, (size_t)c->res * c->m * sizeof(float2), hipMemcpyHostToDevice));
-    // projector-form accuracy: |error(d)| ~ m^2 eps ||a||^2-scale; below this d the item is redone in literal form
+    std::vector<double> TB;
+    build_TB(table_ri, c->m, c->res, c->fb_steps, TB);
+    HIP_TRY(c, hipMemcpy(c->dTB, TB.data(), TB.size() * sizeof(double), hipMemcpyHostToDevice));
+    // projector-form accuracy: |error(d)| ~ m^2 eps ||a||^2 absolute; a d at or below m 1e-8 max||a||^2 (relative
+    // error there <~ 1e-7) is recomputed in the reference's literal form (literal_tile() in the scan)
     double amax2 = 0.0;
     for (uint32_t b = 0; b < c->res; ++b) {
         double a2 = 0.0;
@@ -431,7 +498,7 @@ int upload_table(baz_music_ctx* c, const float* table_ri)
         }
         if (a2 > amax2 && a2 < 1e300) amax2 = a2;
     }
-    c->refine_below = amax2 * (double)c->m * 1e-9;
+    c->refine_below = amax2 * (double)c->m * 1e-8;
     return BAZ_MUSIC_OK;
 }
 
@@ -486,8 +553,8 @@ bool is_pinned_host(const void* p)
     return a.type == hipMemoryTypeHost;
 }
 
-// One pass of the hot path over `batch` device-resident items: covariance, EVD, scan, the tiny top-n merge and the
-// (normally empty) literal-form refinement, back to back on the context's stream.  (Cutting the batch into sub-batches and overlapping covariance/EVD of
+// One pass of the hot path over `batch` device-resident items: covariance, EVD, scan (with the literal-form
+// refinement of near-null tiles inside) and the tiny top-n merge, back to back on the context's stream.  (Cutting the batch into sub-batches and overlapping covariance/EVD of
 // sub-batch i+1 with the scan of sub-batch i on two extra streams was measured and is SLOWER -- 0.53 ms ->
 // 0.60 / 0.70 / 1.05 ms at 2 / 4 / 8 sub-batches, profiles/r01_two_stream_pipeline_negative.txt: the
 // cross-stream event dependencies cost more than the overlap buys.)
@@ -501,7 +568,6 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
     const uint32_t qstride = baz_music_q_stride(batch);
     r = launch_cov(c, static_cast<const float*>(d_in), batch, c->dR);
     if (r) return r;
-    HIP_TRY(c, hipMemsetAsync(c->dRefine, 0, sizeof(uint32_t), c->stream));   // no item flagged yet
     r = launch_evd(c, c->dR, batch, c->dQ, qstride, c->dG);
     if (r) return r;
     float* spec = static_cast<float*>(d_spec);
@@ -520,22 +586,6 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
     if (r) return r;
     r = launch_merge(c, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), spec);
     if (r) return r;
-    {   // near-null items (flagged by the merge) are redone in the reference's literal form; usually none
-        ProfScope ps(c, BAZ_MUSIC_STAGE_MERGE);
-        const float keep_below = (float)(0.01 / c->refine_below);
-#define BAZ_REFINE(NM)                                                                                              \
-    hipLaunchKernelGGL((refine_literal_kernel<NM>), dim3(1024), dim3(256), 0, c->stream, c->dRefine, c->dRefine + 1,  \
-                       c->dG, qstride, c->dTable, spec, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), c->res, \
-                       c->m, c->n, c->keep_mask, keep_below)
-        switch (topn_list_len(c->n)) {
-            case 2: BAZ_REFINE(2); break;
-            case 4: BAZ_REFINE(4); break;
-            case 8: BAZ_REFINE(8); break;
-            default: BAZ_REFINE(16); break;
-        }
-#undef BAZ_REFINE
-        HIP_TRY(c, hipGetLastError());
-    }
     if (c->peak_mode) return launch_peaks(c, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), spec);
     return BAZ_MUSIC_OK;
 }
@@ -580,8 +630,27 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         // bin field of the top-n key: 16 bits up to 65,536 bins (d truncated by <= 2^-36), else 20 bits
         if (resolution > (1u << 20)) { r = BAZ_MUSIC_E_UNSUPPORTED; break; }
         c->keep_mask = (resolution <= (1u << 16)) ? 0xFFFF0000u : 0xFFF00000u;
-        if (hipMalloc((void**)&c->dFB, (size_t)c->fb_steps * 2 * ((m * m + 3) / 4) * 64 * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
-        if (hipMalloc((void**)&c->dTable, (size_t)resolution * m * sizeof(float2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+        c->fb_step_elems = (size_t)2 * ((m * m + 3) / 4) * 64;
+        c->tb_step_elems = (size_t)2 * ((2 * m + 3) / 4) * 64;
+        // row classes of the spectrum port (scan kernel, ROW CLASSES): rows whose byte offset 4*res*i agrees mod 256
+        if (resolution % 4u == 0) {
+            uint32_t gcd = 64;
+            while (resolution % gcd) gcd >>= 1;
+            c->nclass = 64u / gcd;
+        }
+        if (const char* v = getenv("BAZ_MUSIC_NO_ROWCLASS")) { if (atoi(v)) c->nclass = 1; }   // lab: round-1 row order
+        if (const char* v = getenv("BAZ_MUSIC_NO_REFINE")) c->refine_off = atoi(v);              // lab
+        if (const char* v = getenv("BAZ_MUSIC_COV_OLD")) c->lab_cov_old = atoi(v);               // lab
+        if (hipMalloc((void**)&c->dFB, (size_t)(c->fb_steps + 2) * c->fb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+        if (hipMalloc((void**)&c->dTB, (size_t)(c->fb_steps + 2) * c->tb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+        {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cov4_x4_kernel, 256, 0) == hipSuccess && per_cu > 0)
+                c->cov4_resident_blocks = (uint32_t)per_cu * (uint32_t)std::max(1, prop.multiProcessorCount);
+            else (void)hipGetLastError();
+        }
+        if (hipMalloc((void**)&c->dRefined, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+        if (hipMemset(c->dRefined, 0, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         r = upload_table(c, table_ri);
     } while (0);
     if (r != BAZ_MUSIC_OK) {
@@ -614,8 +683,8 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->dR) (void)hipFree(c->dR);
         if (c->dQ) (void)hipFree(c->dQ);
         if (c->dG) (void)hipFree(c->dG);
-        if (c->dTable) (void)hipFree(c->dTable);
-        if (c->dRefine) (void)hipFree(c->dRefine);
+        if (c->dTB) (void)hipFree(c->dTB);
+        if (c->dRefined) (void)hipFree(c->dRefined);
         if (c->dPeakSpec) (void)hipFree(c->dPeakSpec);
         free_slots(c);
         if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
@@ -670,6 +739,7 @@ int baz_music_process_device(baz_music_ctx* c, const void* d_in, uint32_t batch,
     if (batch == 0) return BAZ_MUSIC_OK;
     std::lock_guard<std::mutex> lk(c->mtx);   // .cc:101
     DeviceGuard guard(c->device);
+    HIP_TRY(c, hipMemsetAsync(c->dRefined, 0, sizeof(unsigned long long), c->stream));
     return process_device_locked(c, d_in, batch, d_ang, d_lvl, d_spec);
 }
 
@@ -699,30 +769,38 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
 
     int rc = BAZ_MUSIC_OK;
     uint32_t idx = 0;
+    HIP_TRY(c, hipMemsetAsync(c->dRefined, 0, sizeof(unsigned long long), c->stream));   // statistic of this call (all chunks)
+    // A failing HIP call must not return from inside the loop: copies already queued still target the caller's
+    // buffers, so every exit goes through the drain below.
+#define HIP_STEP(call)                                                     \
+    if (rc == BAZ_MUSIC_OK) {                                              \
+        hipError_t e__ = (call);                                           \
+        if (e__ != hipSuccess) rc = hip_fail(c, e__, #call);               \
+    }
     for (uint32_t done = 0; done < batch && rc == BAZ_MUSIC_OK; done += chunk, ++idx) {
         baz_music_ctx::Slot& sl = c->slot[idx & 1];
         const uint32_t nb = std::min(chunk, batch - done);
         if (sl.busy) {   // chunk idx-2 used this slot: its outputs must be on the host before we reuse it
-            HIP_TRY(c, hipEventSynchronize(sl.d2h));
+            HIP_STEP(hipEventSynchronize(sl.d2h));
             sl.busy = false;
         }
-        HIP_TRY(c, hipMemcpyAsync(sl.in, in_ri + (size_t)done * c->nsamples * 2, (size_t)nb * c->nsamples * 8,
-                                  hipMemcpyHostToDevice, c->s_h2d));
-        HIP_TRY(c, hipEventRecord(sl.h2d, c->s_h2d));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.h2d, 0));
-        rc = process_device_locked(c, sl.in, nb, sl.ang, sl.lvl, want_spec ? sl.spec : nullptr);
-        if (rc) break;
-        HIP_TRY(c, hipEventRecord(sl.comp, c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->s_d2h, sl.comp, 0));
-        HIP_TRY(c, hipMemcpyAsync(ang + (size_t)done * c->n, sl.ang, (size_t)nb * c->n * 4, hipMemcpyDeviceToHost, c->s_d2h));
+        HIP_STEP(hipMemcpyAsync(sl.in, in_ri + (size_t)done * c->nsamples * 2, (size_t)nb * c->nsamples * 8,
+                                hipMemcpyHostToDevice, c->s_h2d));
+        HIP_STEP(hipEventRecord(sl.h2d, c->s_h2d));
+        HIP_STEP(hipStreamWaitEvent(c->stream, sl.h2d, 0));
+        if (rc == BAZ_MUSIC_OK) rc = process_device_locked(c, sl.in, nb, sl.ang, sl.lvl, want_spec ? sl.spec : nullptr);
+        HIP_STEP(hipEventRecord(sl.comp, c->stream));
+        HIP_STEP(hipStreamWaitEvent(c->s_d2h, sl.comp, 0));
+        HIP_STEP(hipMemcpyAsync(ang + (size_t)done * c->n, sl.ang, (size_t)nb * c->n * 4, hipMemcpyDeviceToHost, c->s_d2h));
         if (lvl)
-            HIP_TRY(c, hipMemcpyAsync(lvl + (size_t)done * c->n, sl.lvl, (size_t)nb * c->n * 4, hipMemcpyDeviceToHost, c->s_d2h));
+            HIP_STEP(hipMemcpyAsync(lvl + (size_t)done * c->n, sl.lvl, (size_t)nb * c->n * 4, hipMemcpyDeviceToHost, c->s_d2h));
         if (want_spec)
-            HIP_TRY(c, hipMemcpyAsync(spectrum + (size_t)done * c->res, sl.spec, (size_t)nb * c->res * 4,
-                                      hipMemcpyDeviceToHost, c->s_d2h));
-        HIP_TRY(c, hipEventRecord(sl.d2h, c->s_d2h));
-        sl.busy = true;
+            HIP_STEP(hipMemcpyAsync(spectrum + (size_t)done * c->res, sl.spec, (size_t)nb * c->res * 4,
+                                    hipMemcpyDeviceToHost, c->s_d2h));
+        HIP_STEP(hipEventRecord(sl.d2h, c->s_d2h));
+        sl.busy = (rc == BAZ_MUSIC_OK);
     }
+#undef HIP_STEP
     // drain (also on the error path) so that no copy still targets the caller's buffers
     (void)hipStreamSynchronize(c->s_h2d);
     (void)hipStreamSynchronize(c->stream);
@@ -830,10 +908,10 @@ int64_t baz_music_refined_items(baz_music_ctx* c)
     if (!c) return -1;
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
-    if (!c->dRefine) return 0;
-    uint32_t n = 0;
+    if (!c->dRefined) return 0;
+    unsigned long long n = 0;
     if (hipStreamSynchronize(c->stream) != hipSuccess ||
-        hipMemcpy(&n, c->dRefine, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        hipMemcpy(&n, c->dRefined, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int64_t)n;
 }
 

@@ -4,10 +4,10 @@
 //   cov_mfma_kernel   .cc:74-85   widen c64->c128, x = reshape(m,K), R = x x^H / K
 //   evd_proj_kernel   .cc:88-93   Hermitian EVD (ascending), noise basis G = first m-n eigenvectors;
 //                                 emitted as the real coefficients of the projector Q = G G^H
-//   scan_mfma_kernel  .cc:101-141 per-bin strength 1/||G^H a||^2 (as 1/(a^H Q a), an fp64 MFMA GEMM),
+//   scan_mfma_kernel  .cc:101-141 per-bin strength 1/||G^H a||^2 (as 1/(a^H Q a), an fp64 MFMA GEMM; near-null
+//                                 tiles again in the reference's literal form ||G^H a||^2, literal_tile()),
 //                                 optional spectrum port, per-range top-n candidates
-//   topn_merge_kernel .cc:129-155 final top-n across bin ranges, ang/lvl outputs; flags near-null items
-//   refine_literal_kernel .cc:110-141 the flagged items again, in the reference's literal form ||G^H a||^2
+//   topn_merge_kernel .cc:129-155 final top-n across bin ranges, ang/lvl outputs
 //   peak_pick_kernel  (opt-in extension, no reference counterpart) n strongest local maxima
 //
 // Precision contract: inputs and the steering table stay fp32 in HBM
@@ -220,6 +220,112 @@ __global__ __launch_bounds__(256) void cov_mfma2_kernel(const float* __restrict_
     }
 }
 
+// -------------------------------------------------------------------------------------
+// 1c. Covariance for m = 4, K % 256 == 0 (cfg2, the headline shape) -- round 2.
+//
+//     What bounds the kernels above at m = 4 is not HBM but how they ask for it: one dword per lane = 256 B per
+//     wave-instruction, 4x the load instructions and address cycles per byte of a 16-B-per-lane stream (measured,
+//     scripts/ubench_hbm.hip: 5.5-6.0 TB/s for dword streams against 7.0 TB/s for dwordx4; cov_mfma_kernel<4> itself
+//     4.9-5.5 TB/s), and the 16x16x4 tiles spend half their flops on the zero blocks between the two items they hold.
+//     Here a wave streams ONE item at a time with global_load_dwordx4 (1 KiB = 32 time columns per instruction, 8
+//     instructions = 8 KiB always in flight per wave), and the MFMA operand layout -- one matrix row per lane, which a
+//     16-B load of 4 consecutive rows cannot supply -- is produced by a per-wave LDS transpose:
+//         lane l of a chunk holds rows 4(l&1)..+3 of column l>>1  ->  widened (exactly) to fp64  ->  T[row][col] in LDS
+//         operand P: lane (i = l&3, h = (l>>2)&1, w = (l>>3)&1, k = l>>4) reads T[4h+i][8k+4w .. +3]   (4 MFMA steps)
+//         operand Q: the same with the other half of the rows, T[4(1-h)+i][..]
+//     v_mfma_f64_4x4x4_4b_f64 multiplies four independent 4x4x4 blocks (block = (lane>>2)&3 = (w, h); layout measured
+//     with scripts/probe_mfma4.hip: A[i][k] and B[k][j] in lane i|j + 4*block + 16*k, D[i][j] in lane j + 4*block
+//     + 16*i; CBSZ/ABID do not broadcast for this opcode).  With X_h = rows 4h..4h+3 of the realified item:
+//         D1 += P P^T  -> block (w, h) accumulates X_h X_h^T over its quarter of the columns
+//         D2 += P Q^T  -> block (w, 0) accumulates X_0 X_1^T  (block (w, 1) the transposed duplicate)
+//     i.e. every issued flop but that duplicate is useful: 2 x 20.3 cycles per 8 columns instead of 65.
+//     The Gram blocks go through LDS once per item to form R (.cc:85), exactly Hermitian by construction.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cov4_x4_kernel(const float* __restrict__ in, double2* __restrict__ R,
+                                                      uint32_t batch, uint32_t K)
+{
+    constexpr int RSD = 36;                       // row stride of the transposed chunk, doubles (8-row x 32-col chunk)
+    __shared__ double stage[4][2][8 * RSD];       // per wave, double-buffered
+    __shared__ double gram[4][2][64];             // per wave: D1, D2
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t chunks = K >> 5;               // 1-KiB chunks per item
+    // writer role: column l>>1, rows 4(l&1)..+3
+    const int wcol = lane >> 1, wrow = 4 * (lane & 1);
+    // reader role (MFMA operand layout)
+    const int ri = lane & 3, rh = (lane >> 2) & 1, rw = (lane >> 3) & 1, rk = lane >> 4;
+    const int p_off = (4 * rh + ri) * RSD + 8 * rk + 4 * rw;
+    const int q_off = (4 * (1 - rh) + ri) * RSD + 8 * rk + 4 * rw;
+    double* const g1 = gram[wave][0];
+    double* const g2 = gram[wave][1];
+    const double dK = (double)K;
+
+    // The 8-deep load ring runs ACROSS items (a slot is re-armed, unconditionally, with the next 8-chunk group of
+    // this item or the first group of the wave's next item; past the end it re-reads the last item), so the stream
+    // never drains at an item boundary and the compiler can count vmcnt exactly.  K % 256 == 0: 8-chunk groups.
+    const uint32_t groups = chunks >> 3;
+    const uint32_t stride = gridDim.x * 4;
+    uint32_t item = blockIdx.x * 4 + wave;
+    if (item >= batch) return;
+    const v4f32* __restrict__ src = reinterpret_cast<const v4f32*>(in + (size_t)item * K * 8) + lane;
+    v4f32 pf[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) pf[u] = __builtin_nontemporal_load(src + (size_t)u * 64);
+    for (; item < batch; item += stride) {
+        const uint32_t nitem = (item + stride < batch) ? item + stride : item;
+        const v4f32* __restrict__ nsrc = reinterpret_cast<const v4f32*>(in + (size_t)nitem * K * 8) + lane;
+        double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0;       // two accumulator pairs: independent MFMA chains
+        for (uint32_t cg = 0; cg < groups; ++cg) {
+            const v4f32* __restrict__ rearm = (cg + 1 < groups) ? src + (size_t)(cg + 1) * 8 * 64 : nsrc;   // wave-uniform
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                double* __restrict__ T = stage[wave][u & 1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) T[(wrow + j) * RSD + wcol] = (double)pf[u][j];   // exact widening (.cc:77)
+                // re-arm the slot only after its values are consumed: the load lands in the SAME registers (a copy at
+                // the loop's back edge would have to wait for every load in flight)
+                asm volatile("" ::: "memory");
+                pf[u] = __builtin_nontemporal_load(rearm + (size_t)u * 64);
+                wave_lds_fence();
+                const v4f64 P = *reinterpret_cast<const v4f64*>(T + p_off);
+                const v4f64 Q = *reinterpret_cast<const v4f64*>(T + q_off);
+                a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(P[0], P[0], a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f64_4x4x4f64(P[0], Q[0], a2, 0, 0, 0);
+                b1 = __builtin_amdgcn_mfma_f64_4x4x4f64(P[1], P[1], b1, 0, 0, 0);
+                b2 = __builtin_amdgcn_mfma_f64_4x4x4f64(P[1], Q[1], b2, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(P[2], P[2], a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f64_4x4x4f64(P[2], Q[2], a2, 0, 0, 0);
+                b1 = __builtin_amdgcn_mfma_f64_4x4x4f64(P[3], P[3], b1, 0, 0, 0);
+                b2 = __builtin_amdgcn_mfma_f64_4x4x4f64(P[3], Q[3], b2, 0, 0, 0);
+                wave_lds_fence();     // (the buffer is rewritten two chunks later; LDS ops of a wave retire in order)
+            }
+        }
+        src = nsrc;
+        // D layout: lane = j + 4*(2w+h) + 16*i.  G[x][y] (x, y < 8 realified rows):
+        //   same half h:   sum_w D1[(y&3) + 4(2w+h) + 16(x&3)]      x < 4 <= y:   sum_w D2[(y-4) + 8w + 16x]
+        g1[lane] = a1 + b1;
+        g2[lane] = a2 + b2;
+        wave_lds_fence();
+        if (lane < 16) {
+            const int a = lane >> 2, b = lane & 3;
+            auto G = [&](int x, int y) -> double {
+                if ((x >> 2) == (y >> 2)) {
+                    const int hh = x >> 2, o = (y & 3) + 4 * hh + 16 * (x & 3);
+                    return g1[o] + g1[o + 8];
+                }
+                if (x > y) { const int t = x; x = y; y = t; }      // G is symmetric: the X_1 X_0^T block is the transpose
+                const int o = (y - 4) + 16 * x;
+                return g2[o] + g2[o + 8];
+            };
+            // Re R_ab = G[2a][2b] + G[2a+1][2b+1]      Im R_ab = G[2a+1][2b] - G[2a][2b+1]
+            const double re = G(2 * a, 2 * b) + G(2 * a + 1, 2 * b + 1);
+            const double im = G(2 * a + 1, 2 * b) - G(2 * a, 2 * b + 1);
+            R[(size_t)item * 16 + lane] = make_double2(re / dK, im / dK);    // .cc:85 "/ (double)average_over"
+        }
+        wave_lds_fence();
+    }
+}
+
 // =====================================================================================
 // 2. Batched Hermitian EVD (cyclic complex Jacobi, fp64), one item per lane, then the
 //    noise-subspace projector Q = G G^H, G = eigenvectors of the (m-n) smallest eigenvalues
@@ -368,7 +474,7 @@ __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict_
 #pragma unroll
         for (int j = 0; j < M; ++j) rank += (wk[j] < wk[k] || (wk[j] == wk[k] && j < k)) ? 1 : 0;
         msk[k] = (rank < nnoise) ? 1.0 : 0.0;
-        // the noise eigenvectors themselves, for the literal-form refinement of near-null items (refine_literal_kernel):
+        // the noise eigenvectors themselves, for the literal-form refinement of near-null tiles (literal_tile() in the scan):
         // Gs[((rank*M + i)*2 + {re,im}) * qstride + item] = V[i][k]
         if (valid && Gs && rank < nnoise) {
 #pragma unroll
@@ -775,31 +881,104 @@ __device__ __forceinline__ float strength_f32(const double d)
 //    held in registers for the whole range), B_t = F for 4 bin tiles t = 0..3 whose COLUMNS are
 //    permuted on the host (build_FB) so that tile t, column c is bin 64*step + 4c + t.  The fp64 MFMA
 //    accumulator layout (col = lane&15, row = (lane>>4) + 4*reg) then gives lane (g, c), register r,
-//    tile t  <->  item g + 4r, bin 64*step + 4c + t: a lane holds 4 CONSECUTIVE bins of one item in
+//    tile t  <->  row g + 4r, bin 64*step + 4c + t: a lane holds 4 CONSECUTIVE bins of one item in
 //    acc[0..3][r] -> one 16-B store, and the 16 lanes c = 0..15 of a row write 256 B contiguous.
-//    (A first version with rows = bins wrote 64-B pieces scattered over 16 item rows per instruction:
-//    ablation showed the store pattern and a branchy top-n, not the MFMAs, bound it -- DESIGN.md 5.)
 //
-//    F delivery: the 4 waves of a workgroup own 4 different 16-item groups but walk the SAME range of bin
-//    steps in lockstep, and share every piece of FB through a double-buffered LDS stage (each wave fetches
-//    a quarter of the next phase from L2 while the current phase's MFMAs run; one s_barrier per phase).
-//    Letting every wave stream FB itself costs 8 KiB of L2 reads per 16 MFMAs = 1.9 GB / 11 TB/s per cfg-2
-//    launch -- the measured floor of that form (0.175 ms with everything but loads + MFMAs removed,
-//    profiles/r01c_scan_ablation.txt).  Ordering inside a phase: stage-loads(next) ... MFMAs ... epilogue
-//    VALU ... s_waitcnt (only the stage loads and the PREVIOUS step's stores are outstanding) ... LDS write
-//    ... this step's stores ... barrier: on gfx9-family ISAs loads and stores share vmcnt and complete out
+//    ROW CLASSES (round 2).  The spectrum port's layout is [item][res] float32 (the GNU Radio buffer): row i starts
+//    at byte 4*res*i, which is a multiple of 256 only when res % 64 == 0.  At cfg2 (res = 3600) three rows in
+//    four start 64 / 128 / 192 B into a 256-B window, so a step's 256-B pieces straddle 128-B lines and every
+//    line is written in two halves by two steps ~1,500 cycles apart: measured 4.4 TB/s for that pattern against
+//    5.8-6.0 TB/s for line-aligned rows (scripts/ubench_hbm.hip, profiles/r02_ubench_hbm.txt) -- the round-1
+//    scan sat exactly on the lower figure.  Rows are therefore processed BY CLASS: class k = the rows
+//    i = nclass*j + k, nclass = 64 / gcd(res, 64), which all share the shift sh = (res*k) % 64 bins, and a wave's
+//    step st covers the bins [64*st - sh, 64*st - sh + 64) -- for every row of the class that is one 256-B ALIGNED
+//    window.  A wave's 16 rows are 16 consecutive j of one class, the 4 waves of a block share the class (they
+//    share the F slices), and the shifted slice is assembled by the stage LOADS: lane (g, c) fetches column
+//    c - sh/4 of step st, or column c - sh/4 + 16 of step st - 1 (FB carries one padded step in front and
+//    behind).  LDS layout, MFMA loop and epilogue are unchanged; bins outside [0, res) (first / last step of
+//    a row) are masked in the stores and carry a never-selected key.
+//
+//    F delivery: the 4 waves of a workgroup walk the SAME range of bin steps in lockstep and share every piece of
+//    FB through a double-buffered LDS stage (each wave fetches a quarter of the next phase from L2 while the
+//    current phase's MFMAs run; one s_barrier per phase).  Ordering inside a phase: stage-loads(next) ... MFMAs
+//    ... epilogue VALU ... s_waitcnt (only the stage loads and the PREVIOUS step's stores are outstanding) ... LDS
+//    write ... this step's stores ... barrier: on gfx9-family ISAs loads and stores share vmcnt and complete out
 //    of order with each other, so a wait must never sit right behind fresh stores.
 //    A phase is up to SCH = 8 k-steps (8 or 16 KiB of LDS per buffer); m = 4 has one phase per step.
 //    ABL is a lab-only ablation mask (scripts/scan_lab.hip); product launches use ABL = 0.
+//
+//    NEAR-NULL TILES (round 2; replaces the item-level refine pass of round 1).  The projector form's terms are
+//    O(||a||^2), so fp64 leaves ~m^2 1e-16 ||a||^2 ABSOLUTE error in d, while the reference's sum of squares
+//    ||G^H a||^2 (.cc:110-121) stays relatively accurate however small d is.  When some d of a step falls below
+//    `refine_below` (~m 1e-8 max||a||^2: SNR >~ 55 dB, a few steps around each emitter) the wave recomputes THAT
+//    16-item x 64-bin tile in the reference's literal form on the matrix core -- c_k = g_k^H a as 2(m-n) real
+//    planes of a [16 x 2m] x [2m x 64] GEMM over the raw table image TB, d = sum of the squared planes, same
+//    accumulator layout -- and the epilogue continues with the refined d: spectrum, keys and lvl stay consistent
+//    by construction, nothing is re-read, and ordinary steps pay one compare per row (shared with the top-n gate).
 // =====================================================================================
-template <int M, int NMAX, bool SPEC, bool VEC4, int ABL = 0>
+struct ScanRefine {
+    const double* Gs;          // noise eigenvectors, [((k*M + i)*2 + re/im) * qstride + item]; nullptr: refinement off
+    const double2* TB;         // raw-table B-operand image (build_TB), same step padding and shift rule as FB
+    double below;              // |d| <= below -> the step's tile is recomputed in literal form
+    unsigned long long* count; // statistic: (item, bin) values recomputed (may be nullptr)
+};
+
+template <int M>
+__device__ __forceinline__ uint32_t literal_tile(v4f64 (&acc)[4], const ScanRefine& rf, const v2f64* __restrict__ tbl,
+                                             const uint32_t st, const uint32_t itc, const int g,
+                                             const uint32_t qstride, const int nn, const uint32_t bin, const uint32_t res,
+                                             const bool (&row_ok)[4])
+{
+    constexpr int KS2 = (2 * M + 3) / 4;      // k-steps over the 2m real coordinates (re a_0, im a_0, re a_1, ...)
+    const double* __restrict__ tb1 = reinterpret_cast<const double*>(tbl + (size_t)st * KS2 * 2 * 64);
+    uint32_t cnt = 0;
+    // One bin tile at a time (the scheduling barriers keep the four chains apart): this rare path must not raise the
+    // register count -- hence the occupancy -- of the ordinary steps around it.
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        v4f64 d = {0, 0, 0, 0};
+        for (int k = 0; k < nn; ++k) {            // noise eigenvector k (.cc:93,116-119)
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {   // Re / Im of c_k = sum_i conj(G_ik) a_i
+                v4f64 p = {0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < KS2; ++s) {
+                    const int e = 4 * s + g;      // real coordinate: antenna e/2, re (even) or im (odd) part of a
+                    double a = 0.0;
+                    if (e < 2 * M) {
+                        // Re c: +gr*ar +gi*ai      Im c: -gi*ar +gr*ai
+                        const int comp = part ? ((e & 1) ^ 1) : (e & 1);
+                        a = rf.Gs[(size_t)((k * M + (e >> 1)) * 2 + comp) * qstride + itc];
+                        if (part && !(e & 1)) a = -a;
+                    }
+                    const double b = tb1[((size_t)(2 * s + (t >> 1)) * 64) * 2 + (t & 1)];   // tile t of k-step s
+                    p = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, p, 0, 0, 0);
+                }
+                d += p * p;
+            }
+        }
+        // Per VALUE: only a d at or below the threshold is replaced, so what an (item, bin) pair gets never depends on
+        // which items share its wave, on its row class or on how a batch was cut.  Bins outside the table keep their
+        // (huge) projector value: never stored, never selected.
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool redo = (fabs(acc[t][r]) <= rf.below) && (bin + t < res);
+            acc[t][r] = redo ? d[r] : acc[t][r];
+            cnt += (redo && row_ok[r]) ? 1u : 0u;       // (rows beyond the batch repeat the last item: not counted)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return cnt;
+}
+
+template <int M, int NMAX, bool SPEC, bool VEC4, int ABL = 0, int AUX = (1 | 2 | 16)>
 __global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict__ Qs,
                                                          const double2* __restrict__ FB,
                                                          float* __restrict__ spec,
                                                          double* __restrict__ cand,
                                                          uint32_t batch, uint32_t res, uint32_t qstride,
-                                                         uint32_t nsteps, uint32_t nsplit, uint32_t ngroups,
-                                                         uint32_t keep_mask)
+                                                         uint32_t nsplit, uint32_t nclass, uint32_t rows_per_class,
+                                                         uint32_t keep_mask, uint32_t n, ScanRefine rf)
 {
     constexpr int MM = M * M;
     constexpr int KS = (MM + 3) / 4;                  // MFMA k-steps per bin step
@@ -813,18 +992,25 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, g = lane >> 4;
 
-    // wave task = (16-item group, range of 64-bin steps); the 4 waves of a block take 4 consecutive groups
+    // wave task = (16 rows of one class, range of 64-bin steps); the 4 waves of a block take 4 consecutive row groups
+    // of the SAME class (rows_per_class is a multiple of 64) and the same step range.
     const uint32_t split = blockIdx.x % nsplit;
-    const uint32_t igroup = (blockIdx.x / nsplit) * 4 + wave;        // may be >= ngroups in the last block:
-    const uint32_t st_begin = (uint32_t)(((uint64_t)nsteps * split) / nsplit);   // such a wave still stages and
-    const uint32_t st_end = (uint32_t)(((uint64_t)nsteps * (split + 1)) / nsplit);   // syncs, but stores nothing
-    const uint32_t item0 = igroup * 16;
+    const uint32_t p0 = ((blockIdx.x / nsplit) * 4 + wave) * 16;     // first row of the wave in class-major order
+    const uint32_t cls = __builtin_amdgcn_readfirstlane(p0 / rows_per_class);
+    const uint32_t j0 = p0 - cls * rows_per_class;
+    const uint32_t sh = ((res & 63u) * cls) & 63u;                   // bins: row start of the class inside its 256-B window
+    const int shc = (int)(sh >> 2);                                  // ... in 4-bin columns (sh % 4 == 0 when nclass > 1)
+    const uint32_t nsteps = (res + sh + 63u) >> 6;
+    const uint32_t st_begin = (uint32_t)(((uint64_t)nsteps * split) / nsplit);
+    const uint32_t st_end = (uint32_t)(((uint64_t)nsteps * (split + 1)) / nsplit);
+    const uint32_t item0 = nclass * j0 + cls;                        // row x of the wave is item item0 + nclass*x
+    // (rows beyond the batch, in the last groups of a class, still stage and sync but store nothing)
 
-    // A operand: q[item0 + c][e = 4 s + g]   (zero for the K padding e >= MM)
+    // A operand: q[item of row c][e = 4 s + g]   (zero for the K padding e >= MM)
     double qa[KS];
+    const uint32_t it_c = item0 + nclass * (uint32_t)c;
+    const uint32_t itc = (it_c < batch) ? it_c : (batch - 1);
     {
-        const uint32_t it = item0 + c;
-        const uint32_t itc = (it < batch) ? it : (batch - 1);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int e = 4 * s + g;
@@ -832,17 +1018,31 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict
         }
     }
 
-    double key[4][NMAX];                    // per item row r = 0..3 (item g + 4r)
+    double key[4][NMAX];                    // per item row r = 0..3 (row g + 4r)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int i = 0; i < NMAX; ++i) key[r][i] = key_empty();
+    // upper bounds of key[r][NMAX-1] for the top-n gate (see the epilogue): empty lists accept every finite value
+    [[maybe_unused]] float gate_f[4];
+    [[maybe_unused]] double gate_d[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        gate_f[r] = __builtin_inff();
+        gate_d[r] = __builtin_bit_cast(double, (uint64_t)BAZ_KEY_EMPTY_BITS | 0xFFFFFull);
+    }
+    const bool refine_on = rf.Gs != nullptr;                         // wave-uniform
+    [[maybe_unused]] const float below_f = refine_on ? (float)rf.below : -1.0f;
+    [[maybe_unused]] const double below_d = refine_on ? rf.below : -1.0;
 
-    // FB is one flat array of chunks: step st, k-step s, tile pair h -> chunk (st*KS + s)*2 + h.
-    // Phase (st, p) covers k-steps [p*SCH, min(KS, (p+1)*SCH)): chunks [ (st*KS + p*SCH)*2, ... ).
+    // FB is one flat array of chunks: step st, k-step s, tile pair h -> chunk (st*KS + s)*2 + h (st = -1 and
+    // st = steps exist as padding).  Phase (st, p) covers k-steps [p*SCH, min(KS, (p+1)*SCH)).
+    // This lane's element of a chunk: column c - shc of the step, or column c - shc + 16 of the step before.
     // Staging registers are four named clang vectors, not an array: an array written under `if (more)` and
     // read under a later `if (more)` was left in scratch by the compiler (with a full wait after every load).
-    const v2f64* __restrict__ fb = reinterpret_cast<const v2f64*>(FB) + lane;
+    const int cc = c - shc;
+    const v2f64* __restrict__ fb = reinterpret_cast<const v2f64*>(FB) + (g * 16 + (cc < 0 ? cc + 16 : cc)) -
+                                   (cc < 0 ? KS * 2 * 64 : 0);
     const int wave4 = wave & 3;             // 256-thread blocks: lets the compiler fold `chunk < chunks-per-phase`
     v2f64 sreg0 = {0, 0}, sreg1 = {0, 0}, sreg2 = {0, 0}, sreg3 = {0, 0};
     static_assert(SPW <= 4, "a wave stages at most 4 chunks per phase");
@@ -872,23 +1072,24 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict
 
     int buf = 0;
     v4f32 sv[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // spectrum values of item row r
-    // spectrum addressing: uniform base of this wave's 16 item rows + per-lane 32-bit byte offsets of row r
-    float* __restrict__ spec_base = SPEC ? spec + (size_t)item0 * res : nullptr;
+    // spectrum addressing: uniform base = the wave's first row + per-lane 32-bit byte offsets of row r (rows are
+    // nclass items apart), minus the class shift; the step offset goes into the SGPR soffset
+    float* __restrict__ spec_base = SPEC ? spec + (size_t)item0 * res - sh : nullptr;   // (sh > 0 only for classes k >= 1: item0 >= 1)
     uint32_t soff[4];
-    // raw buffer over this wave's 16 rows: offsets stay < 16*res*4 + res*4 <= 4.25 MiB (res <= 65536)
+    // raw buffer over this wave's rows: offsets stay < 16*nclass*res*4 <= 64 MiB (nclass <= 16, res <= 65536)
     [[maybe_unused]] __amdgpu_buffer_rsrc_t spec_rsrc = __builtin_amdgcn_make_buffer_rsrc(spec_base, 0, 0x7FFFFFFF, 0x00020000);
-    constexpr int SPEC_STORE_AUX = 1 | 2 | 16;   // gfx94x/gfx950 cache-policy bits: sc0 | nt | sc1
     bool row_ok[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        soff[r] = ((uint32_t)(g + 4 * r) * res + 4u * (uint32_t)c) * 4u;   // BYTE offset, < 16*res*4
-        row_ok[r] = (item0 + g + 4 * r) < batch;
+        // BYTE offset, from the shifted base, of bin (64*st - sh + 4c) at st = 0 (lanes with negative bins never store)
+        soff[r] = ((uint32_t)(g + 4 * r) * nclass * res + 4u * (uint32_t)c) * 4u;
+        row_ok[r] = (item0 + nclass * (uint32_t)(g + 4 * r)) < batch;
     }
     for (uint32_t st = st_begin; st < st_end; ++st) {
         v4f64 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0, 0, 0, 0};
-        const uint32_t bin = st * 64 + 4 * c;   // this lane's first bin of the step
+        const uint32_t bin = st * 64 + 4 * c - sh;   // this lane's first bin of the step (wraps above res when negative)
 
 #pragma unroll
         for (int p = 0; p < PPS; ++p) {
@@ -924,18 +1125,80 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict
             if (last_p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(sv[r]));
+                // Top-n gate.  The key network below (3 fp64 min/max + the key packing per value: ~80 of the ~145
+                // VALU instructions of a round-1 step) only changes a list when some value beats the list's LAST
+                // entry.  gate[r] bounds that entry from above in the precision the step has at hand anyway --
+                // (float)|d| with the spectrum port, |d| itself without -- and the network runs only in steps where
+                // SOME lane of the wave sees a value at or below its bound (wave-uniform branch, no divergence).
+                // Conservative by monotonicity of the f64->f32 rounding: a key k < list[last] has
+                // |d| <= (list[last] | low bits), hence (float)|d| <= (float)(list[last] | low bits) = gate, so no
+                // insertion is ever skipped and the lists are bit-identical to running the network on every value;
+                // NaN never passes (like .cc:131).  The bound never drops below `refine_below`, so the same vote
+                // also catches the near-null tiles.  Items of one stream see the same scene, so the 16 items of a
+                // wave rise together and most steps skip (profiles/r02_scan_gate.txt).
+                bool hit = false, low = false;
+                [[maybe_unused]] float fd[4][4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if constexpr (SPEC && !(ABL & 4)) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) fd[r][t] = (float)acc[t][r];   // sign (rounding noise around 0) dropped by |.| below
+                        if constexpr (!(ABL & 2)) {
+                            float mn;
+                            asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(mn) : "v"(fd[r][0]), "v"(fd[r][1]), "v"(fd[r][2]));
+                            asm("v_min_f32 %0, %1, |%2|" : "=v"(mn) : "v"(mn), "v"(fd[r][3]));
+                            hit |= (mn <= gate_f[r]);
+                            low |= (mn <= below_f);
+                        }
+                    } else {
+                        if constexpr (!(ABL & 2)) {
+                            double m01, m23, mn;
+                            asm("v_min_f64 %0, |%1|, |%2|" : "=v"(m01) : "v"(acc[0][r]), "v"(acc[1][r]));
+                            asm("v_min_f64 %0, |%1|, |%2|" : "=v"(m23) : "v"(acc[2][r]), "v"(acc[3][r]));
+                            mn = vmin64(m01, m23);
+                            hit |= (mn <= gate_d[r]);
+                            low |= (mn <= below_d);
+                        }
+                    }
+                }
+                if constexpr (!(ABL & 2)) {
+                    if ((ABL & 64) || __any(hit)) {     // (ABL & 64: lab, the ungated network of round 1)
+                        if (refine_on && __any(low)) {  // near-null tile: redo it in the reference's literal form
+                            const int cr = c - shc;
+                            const v2f64* __restrict__ tbl = reinterpret_cast<const v2f64*>(rf.TB) +
+                                (g * 16 + (cr < 0 ? cr + 16 : cr)) - (cr < 0 ? ((2 * M + 3) / 4) * 2 * 64 : 0);
+                            uint32_t cnt = literal_tile<M>(acc, rf, tbl, st, itc, g, qstride, (int)M - (int)n, bin, res, row_ok);
+                            if constexpr (SPEC && !(ABL & 4)) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                    for (int t = 0; t < 4; ++t) fd[r][t] = (float)acc[t][r];
+                            }
+                            if (rf.count) {         // statistic (baz_music_refined_items): values recomputed
+#pragma unroll
+                                for (int msk = 1; msk < 64; msk <<= 1) cnt += __shfl_xor(cnt, msk, 64);
+                                if (lane == 0 && cnt) atomicAdd(rf.count, (unsigned long long)cnt);
+                            }
+                        }
+                        const uint32_t nobin = ~keep_mask;          // bin field of a key that must never be selected
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                key_insert_new<NMAX>(key[r], make_key(acc[t][r], (bin + t < res) ? bin + t : nobin, keep_mask));
+                            const uint64_t kb = __builtin_bit_cast(uint64_t, key[r][NMAX - 1]) | (uint64_t)(~keep_mask);
+                            gate_d[r] = fmax(__builtin_bit_cast(double, kb), below_d);
+                            gate_f[r] = (float)gate_d[r];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         if constexpr (ABL & 4) sv[r][t] = __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint64_t, acc[t][r]));
-                        else sv[r][t] = strength_f32(fabs(acc[t][r]));   // ||G^H a||^2 >= 0 in the reference
+                        else if constexpr (SPEC) sv[r][t] = __builtin_amdgcn_rcpf(fabsf(fd[r][t]));   // strength_f32(|d|); ||G^H a||^2 >= 0 in the reference
                     }
-                    if constexpr (!(ABL & 2)) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) key_insert_new<NMAX>(key[r], make_key(acc[t][r], bin + t, keep_mask));
-                    }
-                }
             }
 
             // 4. publish the next phase (waits only for the stage loads and the previous step's stores) ...
@@ -948,30 +1211,22 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict
                     for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(sv[r]));
                 }
                 if constexpr (SPEC && !(ABL & 1)) {
-                    // Buffer stores: wave-uniform resource (this wave's 16 item rows) + loop-invariant 32-bit lane
-                    // offsets + the step offset as SGPR soffset: the store operands are never recomputed, so no
-                    // register they occupy is recycled while a store is in flight.  Cache policy sc0|sc1|nt: the
-                    // spectrum is written once and not read by this pipeline (the merge fetches n floats per item),
-                    // so it streams to HBM instead of parking ~290 MB of dirty lines in L2 / Infinity Cache that the
-                    // NEXT kernel (covariance of the following batch) then pays to drain: step 0.434 -> 0.358 ms,
-                    // covariance 0.156 -> 0.108 ms, scan 0.244 -> 0.219 ms (profiles/r01g_store_policy.txt).
+                    // Buffer stores: wave-uniform resource (this wave's rows) + loop-invariant 32-bit lane offsets +
+                    // the step offset as SGPR soffset: the store operands are never recomputed, so no register they
+                    // occupy is recycled while a store is in flight.  Default cache policy sc0|sc1|nt: the spectrum
+                    // is written once and not read by this pipeline (the merge fetches n floats per item), so it
+                    // streams to HBM instead of parking ~290 MB of dirty lines in L2 / Infinity Cache that the NEXT
+                    // kernel (covariance of the following batch) then pays to drain (profiles/r01g_store_policy.txt).
                     const int step_off = (int)(st * 256u);
-                    if constexpr (ABL & 32) {      // lab: the plain cached stores of the measurement above
-                        char* __restrict__ srow = reinterpret_cast<char*>(spec_base + (size_t)st * 64);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-#pragma unroll
-                            for (int t = 0; t < 4; ++t)
-                                if (row_ok[r] && bin + t < res) *reinterpret_cast<float*>(srow + soff[r] + 4u * t) = sv[r][t];
-                    } else if constexpr (VEC4) {   // res % 4 == 0: a lane's 4 bins are all in or all out
-                        if (st * 64 + 64 <= res) { // wave-uniform: whole step inside the table
+                    if constexpr (VEC4) {   // res % 4 == 0: a lane's 4 bins are all in or all out
+                        if ((st > 0 || sh == 0) && st * 64 + 64 - sh <= res) { // wave-uniform: whole step inside the row
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                if (row_ok[r]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, SPEC_STORE_AUX);
+                                if (row_ok[r]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, AUX);
                         } else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                if (row_ok[r] && bin < res) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, SPEC_STORE_AUX);
+                                if (row_ok[r] && bin < res) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, AUX);
                         }
                     } else {
 #pragma unroll
@@ -980,7 +1235,7 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict
 #pragma unroll
                             for (int t = 0; t < 4; ++t)
                                 if (row_ok[r] && bin + t < res)
-                                    __builtin_amdgcn_raw_buffer_store_b32(u[t], spec_rsrc, (int)(soff[r] + 4u * t), step_off, SPEC_STORE_AUX);
+                                    __builtin_amdgcn_raw_buffer_store_b32(u[t], spec_rsrc, (int)(soff[r] + 4u * t), step_off, AUX);
                         }
                     }
                 }
@@ -997,7 +1252,7 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict
         key_merge_xor<NMAX>(key[r], 2);
         key_merge_xor<NMAX>(key[r], 4);
         key_merge_xor<NMAX>(key[r], 8);
-        const uint32_t it = item0 + g + 4 * r;
+        const uint32_t it = item0 + nclass * (uint32_t)(g + 4 * r);
         if (c == 0 && it < batch) {
 #pragma unroll
             for (int i = 0; i < NMAX; ++i) cand[((size_t)it * nsplit + split) * NMAX + i] = key[r][i];
@@ -1016,9 +1271,7 @@ __global__ __launch_bounds__(256) void topn_merge_kernel(const double* __restric
                                                           const float* __restrict__ spec,
                                                           float* __restrict__ ang, float* __restrict__ lvl,
                                                           uint32_t batch, uint32_t res, uint32_t n, uint32_t nsplit,
-                                                          uint32_t keep_mask, double refine_below,
-                                                          uint32_t* __restrict__ refine_count,
-                                                          uint32_t* __restrict__ refine_list)
+                                                          uint32_t keep_mask)
 {
     const uint32_t it = blockIdx.x * 256 + threadIdx.x;
     if (it >= batch) return;
@@ -1027,14 +1280,6 @@ __global__ __launch_bounds__(256) void topn_merge_kernel(const double* __restric
     for (int i = 0; i < NMAX; ++i) key[i] = key_empty();
     const size_t base = (size_t)it * nsplit * NMAX;
     for (uint32_t k = 0; k < nsplit * NMAX; ++k) key_insert<NMAX>(key, cand[base + k]);
-    // An item whose smallest d = a^H Q a is below ~m^2 1e-9 sits in a near-null of the noise subspace (SNR >~ 55 dB):
-    // there the projector form has lost its relative accuracy (its terms are O(1), fp64 leaves ~m^2 1e-16 absolute),
-    // so the whole item is redone in the reference's literal form by refine_literal_kernel.
-    if (refine_count) {
-        const uint64_t b0 = __builtin_bit_cast(uint64_t, key[0]);
-        const double d0 = __builtin_bit_cast(double, b0 & ~(uint64_t)(~keep_mask));
-        if (b0 < (uint64_t)BAZ_KEY_EMPTY_BITS && d0 < refine_below) refine_list[atomicAdd(refine_count, 1u)] = it;
-    }
 #pragma unroll
     for (int i = 0; i < NMAX; ++i)
         if (i < (int)n) {
@@ -1050,89 +1295,6 @@ __global__ __launch_bounds__(256) void topn_merge_kernel(const double* __restric
             ang[(size_t)it * n + i] = a;
             if (lvl) lvl[(size_t)it * n + i] = l;
         }
-}
-
-// -------------------------------------------------------------------------------------
-// 5b. Literal-form refinement of near-null items (flagged by topn_merge_kernel).  The reference evaluates
-//     strength = 1 / ||G^H a||^2 (.cc:110-121): a sum of squares, accurate to ~1e-10 relative even where it is
-//     1e-12 of ||a||^2.  The projector GEMM of the scan cannot be (see topn_merge_kernel), so for the rare item that
-//     contains such a bin the whole row is recomputed here from the noise eigenvectors the EVD kernel kept (Gs) and
-//     the raw steering table, the spectrum row is rewritten and the item's top-n redone.  One workgroup per flagged
-//     item, generic in m; with no flagged item the launch returns at once.
-// -------------------------------------------------------------------------------------
-template <int NMAX>
-__global__ __launch_bounds__(256) void refine_literal_kernel(const uint32_t* __restrict__ count,
-                                                              const uint32_t* __restrict__ list,
-                                                              const double* __restrict__ Gs, uint32_t gstride,
-                                                              const float2* __restrict__ table, float* __restrict__ spec,
-                                                              float* __restrict__ ang, float* __restrict__ lvl,
-                                                              uint32_t res, uint32_t m, uint32_t n, uint32_t keep_mask,
-                                                              float keep_strength_below)
-{
-    __shared__ double2 sG[16 * 15];
-    __shared__ double sKeys[4][NMAX];
-    const uint32_t cnt = *count;
-    const uint32_t nn = m - n;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t q = blockIdx.x; q < cnt; q += gridDim.x) {
-        const uint32_t item = list[q];
-        __syncthreads();
-        if (threadIdx.x < nn * m)
-            sG[threadIdx.x] = make_double2(Gs[(size_t)(threadIdx.x * 2) * gstride + item],
-                                           Gs[(size_t)(threadIdx.x * 2 + 1) * gstride + item]);
-        __syncthreads();
-        auto literal_d = [&](uint32_t b) {
-            double d = 0.0;
-            for (uint32_t k = 0; k < nn; ++k) {
-                double re = 0.0, im = 0.0;                      // g_k^H a = sum_i conj(G[k][i]) a_i
-                for (uint32_t i = 0; i < m; ++i) {
-                    const float2 a = table[(size_t)b * m + i];
-                    const double2 g = sG[k * m + i];
-                    re += g.x * (double)a.x + g.y * (double)a.y;
-                    im += g.x * (double)a.y - g.y * (double)a.x;
-                }
-                d += re * re + im * im;
-            }
-            return d;
-        };
-        double key[NMAX];
-#pragma unroll
-        for (int i = 0; i < NMAX; ++i) key[i] = key_empty();
-        for (uint32_t b = threadIdx.x; b < res; b += 256) {
-            double d;
-            // with the spectrum at hand only the bins near a null are redone: a strength below ~1e-2 / threshold means
-            // d is >= 100x above it, where the projector form is good to ~1e-8 (its value is kept, the key uses 1/s)
-            const float s0 = spec ? spec[(size_t)item * res + b] : 0.0f;
-            if (spec && s0 < keep_strength_below) {
-                d = (double)__builtin_amdgcn_rcpf(s0);     // float precision is all the stored strength carries
-            } else {
-                d = literal_d(b);
-                if (spec) spec[(size_t)item * res + b] = strength_f32(d);
-            }
-            key_insert<NMAX>(key, make_key(d, b, keep_mask));     // NaN keys never enter (v_min/v_max drop them)
-        }
-#pragma unroll
-        for (int mask = 1; mask < 64; mask <<= 1) key_merge_xor<NMAX>(key, mask);
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < NMAX; ++i) sKeys[wave][i] = key[i];
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < 4; ++w)
-#pragma unroll
-                for (int i = 0; i < NMAX; ++i) key_insert<NMAX>(key, sKeys[w][i]);
-#pragma unroll
-            for (int i = 0; i < NMAX; ++i)
-                if (i < (int)n) {
-                    const uint64_t kb = __builtin_bit_cast(uint64_t, key[i]);
-                    const uint32_t bin = (uint32_t)kb & ~keep_mask;
-                    const bool used = (kb < (uint64_t)BAZ_KEY_EMPTY_BITS) && (bin < res);
-                    ang[(size_t)item * n + i] = used ? (float)((double)bin * 360.0 / (double)res) : 0.0f;
-                    if (lvl) lvl[(size_t)item * n + i] = used ? strength_f32(literal_d(bin)) : 0.0f;   // == spectrum[bin]
-                }
-        }
-    }
 }
 
 // -------------------------------------------------------------------------------------

@@ -59,6 +59,16 @@ static int next_device()
     return g > 0 ? (int)(s_instances.fetch_add(1) % (unsigned)g) : -1;
 }
 
+static long env_long(const char* name, long dflt, long lo, long hi)
+{
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    char* end = NULL;
+    const long x = strtol(v, &end, 10);
+    if (end == v) return dflt;
+    return x < lo ? lo : (x > hi ? hi : x);
+}
+
 baz_music_doa_sptr baz_make_music_doa(unsigned int m, unsigned int n, unsigned int nsamples,
                                       const array_response_t& array_response, unsigned int resolution)
 {
@@ -82,8 +92,22 @@ baz_music_doa::baz_music_doa(unsigned int m, unsigned int n, unsigned int nsampl
     if (rc != BAZ_MUSIC_OK)
         throw std::runtime_error(std::string("music_doa: cannot open the gfx950 engine: ") + baz_music_strerror(rc));
 
-    /* One launch per work() call: ask the scheduler for large calls. */
-    set_max_noutput_items(4096);
+    /* Scheduler hints.  The reference handles ONE item per work() call (.cc:74,160); here a
+     * call is one launch sequence over all its items, so the block asks the scheduler for large calls:
+     *   set_output_multiple(N)     work() only ever sees multiples of N items, and GNU Radio sizes the buffers on
+     *                              both sides for at least 2 N items (flat_flowgraph::allocate_buffer) instead of
+     *                              the default 64 KiB (= 8 cfg2 items);
+     *   set_min_output_buffer(B)   output buffers of at least B items, so that several multiples fit one call;
+     *   set_max_noutput_items(C)   a CAP, separate from the two requests above, unset by default.
+     * N trades latency for launch efficiency (N items must have arrived before work() runs); the environment
+     * overrides the defaults: BAZ_MUSIC_OUTPUT_MULTIPLE (64), BAZ_MUSIC_MIN_OUTPUT_BUFFER (8 multiples),
+     * BAZ_MUSIC_MAX_NOUTPUT (0 = no cap). */
+    const long multiple = env_long("BAZ_MUSIC_OUTPUT_MULTIPLE", 64, 1, 1 << 20);
+    const long min_buffer = env_long("BAZ_MUSIC_MIN_OUTPUT_BUFFER", 8 * multiple, 0, 1L << 30);
+    const long cap = env_long("BAZ_MUSIC_MAX_NOUTPUT", 0, 0, 1L << 30);
+    set_output_multiple((int)multiple);
+    if (min_buffer > 0) set_min_output_buffer(min_buffer);
+    if (cap > 0) set_max_noutput_items((int)std::max(cap, multiple));
 
     fprintf(stderr, "[%s<%li>] MUSIC DOA: M: %d, N: %d, # samples: %d, angular resolution: %d\n",
             name().c_str(), unique_id(), m, n, nsamples, resolution);

@@ -130,10 +130,10 @@ BAZ_MUSIC_API const char* baz_music_version(void);
  * strongest bins (lib/baz_music_doa.cc:129-141, which usually are neighbours on one lobe).  Same output format,
  * descending strength, (0, 0) for missing peaks.  Mode 0 (default) is the reference. */
 BAZ_MUSIC_API int baz_music_set_peak_mode(baz_music_ctx* ctx, int mode);
-/* Statistic: how many items of the LAST process call were recomputed in the reference's literal form because they
- * contained a near-null bin (d = ||G^H a||^2 below ~m 1e-9 max||a||^2, i.e. SNR >~ 55 dB); blocks until that call is
- * done (a host-fed call that was cut into several chunks reports its last chunk).  -1 on error.  See DESIGN.md 2
- * (near-nulls). */
+/* Statistic: how many (item, bin) values of the LAST process call were recomputed in the reference's literal form
+ * ||G^H a||^2 because the projector form a^H Q a put them at or below ~m 1e-8 max||a||^2 (near-nulls of the noise
+ * subspace, SNR >~ 55 dB); blocks until that call is done (a host-fed call cut into chunks reports their sum).
+ * -1 on error.  See DESIGN.md 2 (near-nulls).  (The name is kept from round 1, which redid whole items.) */
 BAZ_MUSIC_API int64_t baz_music_refined_items(baz_music_ctx* ctx);
 BAZ_MUSIC_API int baz_music_device_count(void);
 BAZ_MUSIC_API int baz_music_device(const baz_music_ctx* ctx);

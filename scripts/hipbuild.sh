@@ -7,5 +7,5 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -ml
 rc=$?
 echo "hipcc rc=$rc in $(( $(date +%s) - t0 )) s"
 grep -E "error" -A6 /tmp/build.log | head -40
-if [ -n "$1" ]; then python tools_resusage.py /tmp/build.log | grep -E "$1"; fi
+if [ -n "$1" ]; then python scripts/resusage.py /tmp/build.log | grep -E "$1"; fi
 exit $rc
