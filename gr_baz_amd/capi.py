@@ -25,7 +25,7 @@ SYMBOLS = [
     "baz_music_create", "baz_music_destroy", "baz_music_set_table", "baz_music_process",
     "baz_music_process_device", "baz_music_set_stream", "baz_music_sync", "baz_music_reserve",
     "baz_music_profile", "baz_music_stage_ms", "baz_music_stage_name", "baz_music_debug_cov",
-    "baz_music_debug_evd", "baz_music_q_stride", "baz_music_bytes_per_item", "baz_music_strerror",
+    "baz_music_debug_evd", "baz_music_debug_q", "baz_music_q_stride", "baz_music_bytes_per_item", "baz_music_strerror",
     "baz_music_last_hip_error", "baz_music_version", "baz_music_device_count", "baz_music_device", "baz_music_set_peak_mode", "baz_music_refined_items",
 ]
 
@@ -81,6 +81,8 @@ def lib():
     L.baz_music_debug_cov.argtypes = [_vp, _vp, _u32, _vp]
     L.baz_music_debug_evd.restype = ctypes.c_int
     L.baz_music_debug_evd.argtypes = [_vp, _vp, _u32, _vp]
+    L.baz_music_debug_q.restype = ctypes.c_int
+    L.baz_music_debug_q.argtypes = [_vp, _vp, _u32, _vp]
     L.baz_music_q_stride.restype = _u32
     L.baz_music_q_stride.argtypes = [_u32]
     L.baz_music_bytes_per_item.restype = ctypes.c_uint64
@@ -219,6 +221,9 @@ class Context:
 
     def debug_evd(self, d_R, batch, d_Q):
         self._chk(lib().baz_music_debug_evd(self._h, _vp(d_R), int(batch), _vp(d_Q)), "baz_music_debug_evd")
+
+    def debug_q(self, d_in, batch, d_Q):
+        self._chk(lib().baz_music_debug_q(self._h, _vp(d_in), int(batch), _vp(d_Q)), "baz_music_debug_q")
 
     def bytes_per_item(self, with_spectrum=True):
         return int(lib().baz_music_bytes_per_item(self._h, 1 if with_spectrum else 0))

@@ -660,6 +660,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     char buf[128];
     snprintf(buf, sizeof(buf), m <= 8 ? "bazmusic::cov_mfma_kernel<%u>" : "bazmusic::cov_mfma2_kernel<%u>", m);
     c->stage_name[BAZ_MUSIC_STAGE_COV] = buf;
+    if (m == 4 && (c->K % 256u) == 0 && !c->lab_cov_old) c->stage_name[BAZ_MUSIC_STAGE_COV] = "bazmusic::cov4_x4_kernel";
     snprintf(buf, sizeof(buf), m <= 4 ? "bazmusic::evd_proj_kernel<%u>" : "bazmusic::evd_proj_lds_kernel<%u>", m);
     c->stage_name[BAZ_MUSIC_STAGE_EVD] = buf;
     snprintf(buf, sizeof(buf), "bazmusic::scan_mfma_kernel<%u,", m);
@@ -849,6 +850,19 @@ int baz_music_debug_cov(baz_music_ctx* c, const void* d_in, uint32_t batch, void
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
     return launch_cov(c, static_cast<const float*>(d_in), batch, static_cast<double2*>(d_R));
+}
+
+int baz_music_debug_q(baz_music_ctx* c, const void* d_in, uint32_t batch, void* d_Q)
+{
+    if (!c || !d_in || !d_Q || batch == 0) return BAZ_MUSIC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    DeviceGuard guard(c->device);
+    int r = ensure_workspace(c, batch);
+    if (r) return r;
+    const uint32_t qstride = baz_music_q_stride(batch);
+    r = launch_cov(c, static_cast<const float*>(d_in), batch, c->dR);
+    if (r) return r;
+    return launch_evd(c, c->dR, batch, static_cast<double*>(d_Q), qstride, c->dG);
 }
 
 int baz_music_debug_evd(baz_music_ctx* c, const void* d_R, uint32_t batch, void* d_Q)

@@ -409,27 +409,25 @@ __device__ __forceinline__ void jacobi_sweep(Herm<M>& h, const bool active)
     }
 }
 
-template <int M>
-__global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict__ R,
-                                                       double* __restrict__ Qs,
-                                                       uint32_t batch, uint32_t n, uint32_t qstride,
-                                                       double* __restrict__ Gs)
+// The per-lane EVD + projector of one item (m <= 4, register resident, statically indexed).  getR(i, j) returns
+// R_ij as double2; every lane of the wave must call this (wave-uniform early exit of the sweeps).
+// (A fused covariance + EVD kernel built on this function -- 64 items per wave, R parked in LDS -- took exactly the
+// sum of the two kernels, 0.436 vs 0.353 + 0.078 ms per 262,144 cfg2 items: the Jacobi's ~220 VGPRs leave one
+// streaming wave per SIMD, which cannot feed the HBM pipe and share issue slots with the other wave's sweeps.
+// profiles/r02_fused_covevd_negative.txt; removed.)
+template <int M, class GetR>
+__device__ __forceinline__ void evd_project_lane(GetR getR, const bool valid, const uint32_t item, const uint32_t n,
+                                                 const uint32_t qstride, double* __restrict__ Qs, double* __restrict__ Gs)
 {
-    constexpr int MM = M * M;
     constexpr bool UNROLL = (M <= 4);   // register-resident, statically indexed (m >= 5 uses evd_proj_lds_kernel)
     constexpr int MAX_SWEEPS = 16;
-    const uint32_t item = blockIdx.x * 64 + threadIdx.x;
-    const bool valid = item < batch;
-    const uint32_t itc = valid ? item : (batch - 1);
-
     Herm<M> h;
-    const double2* Rp = R + (size_t)itc * MM;
     // The projector is invariant under R -> s R (s > 0): scale by an exact power of two so that the
     // largest diagonal entry lies in [0.5,1) (R is PSD, so every |R_ij| <= that).  LAPACK's zheev
     // (behind the reference's eig_sym, .cc:90) likewise rescales out-of-range matrices.
     double dmax = 0.0;
 #pragma unroll
-    for (int i = 0; i < M; ++i) dmax = fmax(dmax, fabs(Rp[i * M + i].x));
+    for (int i = 0; i < M; ++i) dmax = fmax(dmax, fabs(getR(i, i).x));
     int ex = 0;
     (void)frexp(dmax, &ex);
     const double scl = (dmax > 0.0 && dmax < __builtin_huge_val()) ? ldexp(1.0, -ex) : 1.0;
@@ -438,7 +436,7 @@ __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict_
     for (int i = 0; i < M; ++i)
 #pragma unroll
         for (int j = 0; j < M; ++j) {
-            const double2 v = Rp[i * M + j];
+            const double2 v = getR(i, j);
             psum += v.x + v.y;
             h.Ar[i][j] = v.x * scl;
             h.Ai[i][j] = (i == j) ? 0.0 : v.y * scl;
@@ -504,6 +502,20 @@ __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict_
                 }
             }
         }
+}
+
+template <int M>
+__global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict__ R,
+                                                       double* __restrict__ Qs,
+                                                       uint32_t batch, uint32_t n, uint32_t qstride,
+                                                       double* __restrict__ Gs)
+{
+    constexpr int MM = M * M;
+    const uint32_t item = blockIdx.x * 64 + threadIdx.x;
+    const bool valid = item < batch;
+    const uint32_t itc = valid ? item : (batch - 1);
+    const double2* Rp = R + (size_t)itc * MM;
+    evd_project_lane<M>([&](int i, int j) { return Rp[i * M + j]; }, valid, item, n, qstride, Qs, Gs);
 }
 
 // -------------------------------------------------------------------------------------
@@ -971,8 +983,9 @@ __device__ __forceinline__ uint32_t literal_tile(v4f64 (&acc)[4], const ScanRefi
     return cnt;
 }
 
+// (m <= 4: 4 waves/SIMD = 128 VGPRs; the few values this displaces live in the rare literal / statistic paths)
 template <int M, int NMAX, bool SPEC, bool VEC4, int ABL = 0, int AUX = (1 | 2 | 16)>
-__global__ __launch_bounds__(256) void scan_mfma_kernel(const double* __restrict__ Qs,
+__global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : 1) void scan_mfma_kernel(const double* __restrict__ Qs,
                                                          const double2* __restrict__ FB,
                                                          float* __restrict__ spec,
                                                          double* __restrict__ cand,

@@ -112,6 +112,9 @@ BAZ_MUSIC_API const char* baz_music_stage_name(baz_music_ctx* ctx, int stage);
  * q_stride is returned by baz_music_q_stride() for the given batch. */
 BAZ_MUSIC_API int baz_music_debug_cov(baz_music_ctx* ctx, const void* d_in, uint32_t batch, void* d_R);
 BAZ_MUSIC_API int baz_music_debug_evd(baz_music_ctx* ctx, const void* d_R, uint32_t batch, void* d_Q);
+/*   q   : d_in -> d_Q      the two stages back to back, exactly as process_device() runs them for this
+ *                          configuration; projector coefficients as for `evd` */
+BAZ_MUSIC_API int baz_music_debug_q(baz_music_ctx* ctx, const void* d_in, uint32_t batch, void* d_Q);
 BAZ_MUSIC_API uint32_t baz_music_q_stride(uint32_t batch);
 
 /* Algorithmic HBM bytes per item: 8*nsamples + 8*n + 4*resolution (the last

@@ -44,14 +44,16 @@ __global__ __launch_bounds__(256) void read_dw(const float* __restrict__ p, size
     if (acc == 1.2345f) sink[0] = 1.0f;
 }
 
+// POLICY 0 plain, 1 nt (global_store ... nt), 2 sc0 sc1 nt, 3 sc0 sc1, 4 nt via buffer store (aux = 2)
 template <int POLICY>
-__device__ __forceinline__ void store16(v4f* p, v4f v)
+__device__ __forceinline__ void store16(char* base, uint32_t off, v4f v)
 {
-    if constexpr (POLICY == 0) *p = v;
-    else if constexpr (POLICY == 1) __builtin_nontemporal_store(v, p);
-    else {
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p, 0, 16, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rs, 0, 0, POLICY == 2 ? (1 | 2 | 16) : (1 | 16));
+    if constexpr (POLICY == 0) *reinterpret_cast<v4f*>(base + off) = v;
+    else if constexpr (POLICY == 1) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(base + off));
+    else {   // wave-uniform resource over the whole buffer, per-lane 32-bit byte offset
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFF, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rs, (int)off, 0,
+                                               POLICY == 2 ? (1 | 2 | 16) : (POLICY == 3 ? (1 | 16) : 2));
     }
 }
 
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void write_x4(v4f* __restrict__ p, size_t n16)
 {
     const v4f v = {1.0f, 2.0f, 3.0f, (float)threadIdx.x};
     const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) store16<POLICY>(p + i, v);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) store16<POLICY>(reinterpret_cast<char*>(p), (uint32_t)(i * 16), v);
 }
 
 // the scan's store pattern: block = 4 waves = 64 rows; wave w owns rows 16w..16w+15 of the block; nsplit ranges of steps
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void write_rows(char* __restrict__ base, uint3
         for (int r = 0; r < 4; ++r) {
             const uint32_t row = row0 + g + 4 * r;
             if (row < rows && st * 256u + 16u * c + 16u <= pitch)
-                store16<POLICY>(reinterpret_cast<v4f*>(base + (size_t)row * pitch + (size_t)st * 256 + 16 * c), v);
+                store16<POLICY>(base, row * pitch + st * 256u + 16u * c, v);
         }
     }
 }
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void mixed(const v4f* __restrict__ src, size_t
     } else {
         const uint32_t b = blockIdx.x >> 1;
         const v4f v = {1.0f, 2.0f, 3.0f, (float)threadIdx.x};
-        for (size_t i = (size_t)b * 256 + threadIdx.x; i < nw16; i += (size_t)half * 256) store16<POLICY>(dst + i, v);
+        for (size_t i = (size_t)b * 256 + threadIdx.x; i < nw16; i += (size_t)half * 256) store16<POLICY>(reinterpret_cast<char*>(dst), (uint32_t)(i * 16), v);
     }
 }
 
@@ -146,9 +148,9 @@ int main()
         timeit(nm, (double)WR, [&] { hipLaunchKernelGGL(write_x4<3>, dim3(gsz), dim3(256), 0, 0, (v4f*)dst, WR / 16); });
     }
     const uint32_t nsteps = 57;
-    for (uint32_t nsplit : {1u, 2u, 4u}) {
+    for (uint32_t nsplit : {2u}) {
         const uint32_t blocks = (rows / 64) * nsplit;
-        for (uint32_t spin : {0u, 64u}) {
+        for (uint32_t spin : {0u, 64u, 256u}) {
             char nm[160];
             snprintf(nm, sizeof nm, "write_rows pitch 14400 plain      nsplit %u spin %u", nsplit, spin);
             timeit(nm, (double)rows * pitchA, [&] { hipLaunchKernelGGL(write_rows<0>, dim3(blocks), dim3(256), 0, 0, dst, rows, pitchA, nsteps, nsplit, spin); });
@@ -158,6 +160,8 @@ int main()
             timeit(nm, (double)rows * pitchA, [&] { hipLaunchKernelGGL(write_rows<2>, dim3(blocks), dim3(256), 0, 0, dst, rows, pitchA, nsteps, nsplit, spin); });
             snprintf(nm, sizeof nm, "write_rows pitch 14336 sc0 sc1 nt nsplit %u spin %u", nsplit, spin);
             timeit(nm, (double)rows * pitchB, [&] { hipLaunchKernelGGL(write_rows<2>, dim3(blocks), dim3(256), 0, 0, dst, rows, pitchB, 56, nsplit, spin); });
+            snprintf(nm, sizeof nm, "write_rows pitch 14336 nt         nsplit %u spin %u", nsplit, spin);
+            timeit(nm, (double)rows * pitchB, [&] { hipLaunchKernelGGL(write_rows<1>, dim3(blocks), dim3(256), 0, 0, dst, rows, pitchB, 56, nsplit, spin); });
             snprintf(nm, sizeof nm, "write_rows pitch 14336 plain      nsplit %u spin %u", nsplit, spin);
             timeit(nm, (double)rows * pitchB, [&] { hipLaunchKernelGGL(write_rows<0>, dim3(blocks), dim3(256), 0, 0, dst, rows, pitchB, 56, nsplit, spin); });
         }

@@ -85,6 +85,8 @@ def test_stage_taps_covariance_and_projector(gpu_device):
             ctx.debug_cov(x.data_ptr(), B, R.data_ptr())
             Q = torch.zeros(m * m, capi.q_stride(B), dtype=torch.float64, device=gpu_device)
             ctx.debug_evd(R.data_ptr(), B, Q.data_ptr())
+            Qp = torch.zeros_like(Q)                       # the same two stages the way process_device() runs them
+            ctx.debug_q(x.data_ptr(), B, Qp.data_ptr())
             ctx.sync()
         Rg = R.cpu().numpy()
         Rg = (Rg[..., 0] + 1j * Rg[..., 1]).reshape(B, m, m)
@@ -95,7 +97,8 @@ def test_stage_taps_covariance_and_projector(gpu_device):
         w, V = np.linalg.eigh(Rn)
         G = V[:, :, :m - n]
         P = G @ G.conj().transpose(0, 2, 1)
-        Qg = Q.cpu().numpy()[:, :B].T.reshape(B, m, m)
+        assert np.abs((Qp - Q).cpu().numpy()[:, :B]).max() < 1e-12
+        Qg = Qp.cpu().numpy()[:, :B].T.reshape(B, m, m)
         for i in range(m):
             assert np.abs(Qg[:, i, i] - P[:, i, i].real).max() < 1e-12
             for j in range(i + 1, m):
