@@ -339,50 +339,72 @@ __global__ __launch_bounds__(256) void cov4_x4_kernel(const float* __restrict__ 
 // =====================================================================================
 template <int M>
 struct Herm {
-    double Ar[M][M], Ai[M][M], Vr[M][M], Vi[M][M];
+    // A = the Hermitian iterate: real diagonal D and the strict UPPER triangle U (entries i < j only; the lower one
+    // is its conjugate and is never formed -- round 1 carried and rotated the full matrix: 16 instead of 4 complex
+    // entry updates per rotation at m = 4).  V = accumulated rotations (eigenvectors in its columns).
+    double D[M], Ur[M][M], Ui[M][M], Vr[M][M], Vi[M][M];
 };
 
+// One complex Jacobi rotation on the pair (p, q), p < q, both compile-time after unrolling:
+//     J = [[c, s], [-s conj(u), c conj(u)]] on (p, q),  u = a_pq / |a_pq|,  A <- J^H A J,  V <- V J
+// with t = tan of the rotation angle chosen to annihilate a_pq (the smaller root), so that
+//     a_pp <- a_pp - t |a_pq|,   a_qq <- a_qq + t |a_pq|,   a_pq <- 0,
+// and for every k outside the pair the two entries that couple k with p and q, taken from / stored into the upper
+// triangle:   k < p:      (U_kp, U_kq) <- (c U_kp - conj(s u) U_kq,   s U_kp + conj(c u) U_kq)
+//             p < k < q:  (U_pk, U_kq) <- (c U_pk - (s u) conj(U_kq), s conj(U_pk) + conj(c u) U_kq)
+//             k > q:      (U_pk, U_qk) <- (c U_pk - (s u) U_qk,       s U_pk + (c u) U_qk)
 template <int M>
 __device__ __forceinline__ void jacobi_rotate(Herm<M>& h, const int p, const int q, const bool active)
 {
-    const double apr = h.Ar[p][q], api = h.Ai[p][q];
+    const double apr = h.Ur[p][q], api = h.Ui[p][q];
     const double g2 = apr * apr + api * api;
-    // The matrix is normalised to max diagonal in [0.5,1) (see evd_proj_kernel), so this absolute
+    // The matrix is normalised to max diagonal in [0.5,1) (see evd_project_lane), so this absolute
     // threshold (|a_pq| <= 1e-20) is 4 orders below fp64 resolution.  It also keeps lanes that
     // converged early (while the rest of the wave still sweeps) from rotating on off-diagonals that
     // have shrunk quadratically into the denormal range, where u = a_pq/|a_pq| loses unit modulus.
     // `active` is false for a lane whose item has already converged while its wave-mates still sweep: it then applies
     // the exact identity (c = 1, s = 0), so an item's result never depends on which items share its wave
     const bool rot = active && g2 > 1e-40;
+    // (Replacing the IEEE divide / sqrt sequences below by v_rcp_f64 / v_rsq_f64 seeds + Newton steps removed 14 % of
+    // the kernel's VALU instructions and not one microsecond: 0.065 vs 0.066 ms per 262,144 items.)
     const double gg = sqrt(g2);
     const double ig = rot ? 1.0 / gg : 0.0;
-    const double ur = rot ? apr * ig : 1.0;
-    const double ui = rot ? api * ig : 0.0;
-    const double tau = (h.Ar[q][q] - h.Ar[p][p]) * 0.5 * ig;
+    const double tau = (h.D[q] - h.D[p]) * 0.5 * ig;
     double t = copysign(1.0, tau) / (fabs(tau) + sqrt(1.0 + tau * tau));
     t = rot ? t : 0.0;
     const double c = 1.0 / sqrt(1.0 + t * t);
+    const double ur = rot ? apr * ig : 1.0;
+    const double ui = rot ? api * ig : 0.0;
     const double s = t * c;
     const double sur = s * ur, sui = s * ui, cur = c * ur, cui = c * ui;
-    // J = [[c, s],[-s conj(u), c conj(u)]] on (p,q);   A <- J^H A J,  V <- V J
+    const double shift = rot ? t * gg : 0.0;
+    h.D[p] -= shift;
+    h.D[q] += shift;
+    h.Ur[p][q] = rot ? 0.0 : apr;
+    h.Ui[p][q] = rot ? 0.0 : api;
 #pragma unroll
-    for (int k = 0; k < M; ++k) {   // A J : columns p,q
-        const double xr = h.Ar[k][p], xi = h.Ai[k][p], yr = h.Ar[k][q], yi = h.Ai[k][q];
-        h.Ar[k][p] = c * xr - (sur * yr + sui * yi);
-        h.Ai[k][p] = c * xi - (sur * yi - sui * yr);
-        h.Ar[k][q] = s * xr + (cur * yr + cui * yi);
-        h.Ai[k][q] = s * xi + (cur * yi - cui * yr);
+    for (int k = 0; k < M; ++k) {
+        if (k == p || k == q) continue;
+        if (k < p) {
+            const double xr = h.Ur[k][p], xi = h.Ui[k][p], yr = h.Ur[k][q], yi = h.Ui[k][q];
+            h.Ur[k][p] = c * xr - (sur * yr + sui * yi);
+            h.Ui[k][p] = c * xi - (sur * yi - sui * yr);
+            h.Ur[k][q] = s * xr + (cur * yr + cui * yi);
+            h.Ui[k][q] = s * xi + (cur * yi - cui * yr);
+        } else if (k < q) {
+            const double xr = h.Ur[p][k], xi = h.Ui[p][k], yr = h.Ur[k][q], yi = h.Ui[k][q];
+            h.Ur[p][k] = c * xr - (sur * yr + sui * yi);       // c x - (s u) conj(y)
+            h.Ui[p][k] = c * xi - (sui * yr - sur * yi);
+            h.Ur[k][q] = s * xr + (cur * yr + cui * yi);       // s conj(x) + conj(c u) y
+            h.Ui[k][q] = -s * xi + (cur * yi - cui * yr);
+        } else {
+            const double xr = h.Ur[p][k], xi = h.Ui[p][k], yr = h.Ur[q][k], yi = h.Ui[q][k];
+            h.Ur[p][k] = c * xr - (sur * yr - sui * yi);
+            h.Ui[p][k] = c * xi - (sur * yi + sui * yr);
+            h.Ur[q][k] = s * xr + (cur * yr - cui * yi);
+            h.Ui[q][k] = s * xi + (cur * yi + cui * yr);
+        }
     }
-#pragma unroll
-    for (int k = 0; k < M; ++k) {   // J^H (A J) : rows p,q
-        const double xr = h.Ar[p][k], xi = h.Ai[p][k], yr = h.Ar[q][k], yi = h.Ai[q][k];
-        h.Ar[p][k] = c * xr - (sur * yr - sui * yi);
-        h.Ai[p][k] = c * xi - (sur * yi + sui * yr);
-        h.Ar[q][k] = s * xr + (cur * yr - cui * yi);
-        h.Ai[q][k] = s * xi + (cur * yi + cui * yr);
-    }
-    h.Ar[p][q] = 0.0; h.Ai[p][q] = 0.0; h.Ar[q][p] = 0.0; h.Ai[q][p] = 0.0;
-    h.Ai[p][p] = 0.0; h.Ai[q][q] = 0.0;
 #pragma unroll
     for (int k = 0; k < M; ++k) {   // V J
         const double xr = h.Vr[k][p], xi = h.Vi[k][p], yr = h.Vr[k][q], yi = h.Vi[k][q];
@@ -393,20 +415,13 @@ __device__ __forceinline__ void jacobi_rotate(Herm<M>& h, const int p, const int
     }
 }
 
-template <int M, bool UNROLL>
+template <int M>
 __device__ __forceinline__ void jacobi_sweep(Herm<M>& h, const bool active)
 {
-    if constexpr (UNROLL) {
 #pragma unroll
-        for (int p = 0; p < M - 1; ++p)
+    for (int p = 0; p < M - 1; ++p)
 #pragma unroll
-            for (int q = p + 1; q < M; ++q) jacobi_rotate<M>(h, p, q, active);
-    } else {
-#pragma nounroll
-        for (int p = 0; p < M - 1; ++p)
-#pragma nounroll
-            for (int q = p + 1; q < M; ++q) jacobi_rotate<M>(h, p, q, active);
-    }
+        for (int q = p + 1; q < M; ++q) jacobi_rotate<M>(h, p, q, active);
 }
 
 // The per-lane EVD + projector of one item (m <= 4, register resident, statically indexed).  getR(i, j) returns
@@ -419,7 +434,7 @@ template <int M, class GetR>
 __device__ __forceinline__ void evd_project_lane(GetR getR, const bool valid, const uint32_t item, const uint32_t n,
                                                  const uint32_t qstride, double* __restrict__ Qs, double* __restrict__ Gs)
 {
-    constexpr bool UNROLL = (M <= 4);   // register-resident, statically indexed (m >= 5 uses evd_proj_lds_kernel)
+    static_assert(M <= 4, "register-resident, statically indexed (m >= 5 uses evd_proj_lds_kernel)");
     constexpr int MAX_SWEEPS = 16;
     Herm<M> h;
     // The projector is invariant under R -> s R (s > 0): scale by an exact power of two so that the
@@ -437,9 +452,9 @@ __device__ __forceinline__ void evd_project_lane(GetR getR, const bool valid, co
 #pragma unroll
         for (int j = 0; j < M; ++j) {
             const double2 v = getR(i, j);
-            psum += v.x + v.y;
-            h.Ar[i][j] = v.x * scl;
-            h.Ai[i][j] = (i == j) ? 0.0 : v.y * scl;
+            psum += v.x + v.y;                     // (every entry, also the lower triangle: NaN / Inf anywhere poisons)
+            if (i == j) h.D[i] = v.x * scl;
+            if (i < j) { h.Ur[i][j] = v.x * scl; h.Ui[i][j] = v.y * scl; }
             h.Vr[i][j] = (i == j) ? 1.0 : 0.0;
             h.Vi[i][j] = 0.0;
         }
@@ -448,13 +463,13 @@ __device__ __forceinline__ void evd_project_lane(GetR getR, const bool valid, co
         double off = 0.0, dia = 0.0;
 #pragma unroll
         for (int i = 0; i < M; ++i) {
-            dia += h.Ar[i][i] * h.Ar[i][i];
+            dia += h.D[i] * h.D[i];
 #pragma unroll
-            for (int j = i + 1; j < M; ++j) off += h.Ar[i][j] * h.Ar[i][j] + h.Ai[i][j] * h.Ai[i][j];
+            for (int j = i + 1; j < M; ++j) off += h.Ur[i][j] * h.Ur[i][j] + h.Ui[i][j] * h.Ui[i][j];
         }
         const bool done = !(off > 1e-33 * dia);   // also true for NaN input -> bounded loop either way
         if (__all(done)) break;
-        jacobi_sweep<M, UNROLL>(h, !done);
+        jacobi_sweep<M>(h, !done);
     }
     // A covariance with NaN/Inf entries has no eigen-decomposition (the reference's eig_sym fails there): poison the
     // projector so that the item's spectrum is NaN and no bin is ever inserted (.cc:131) -> (0, 0) outputs.
@@ -463,7 +478,7 @@ __device__ __forceinline__ void evd_project_lane(GetR getR, const bool valid, co
     // ascending rank of each eigenvalue (ties -> lower column first), noise = rank < m-n
     double wk[M];
 #pragma unroll
-    for (int k = 0; k < M; ++k) wk[k] = h.Ar[k][k];
+    for (int k = 0; k < M; ++k) wk[k] = h.D[k];
     double msk[M];
     const int nnoise = (int)M - (int)n;
 #pragma unroll
