@@ -4,22 +4,34 @@
 metric   : BASELINE.json's "MUSIC-DoA snapshots/s (4 ant, 1024 samp, 3600 bins)".
 workload : BASELINE.json configs[1] = SURVEY.md 8d cfg2: m=4, n=2, nsamples=1024 (K=256 columns),
            resolution=3600, spectrum port wired; per GPU 8 independent synthetic streams of 32,768
-           items (262,144 items = one "step" = one pass of the hot path: covariance -> EVD -> scan),
+           items (262,144 items = one "step" = one pass of the hot path: covariance -> EVD -> scan -> merge),
            device-resident in HBM before the timed region.
+timing   : W warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides, max over ranks.
+           A K-step region is ~25 ms at the driver's K = 20, so the measurement is REPEATED (rounds of exactly K
+           steps, each bracketed the same way) until >= --min-seconds of timed work has accumulated; the line
+           reports the MEDIAN round (ms_per_step, value) and lists every round under "rounds".
 N GPUs   : one process per GPU (torch.distributed.run), streams dealt s mod N, NO data-path
            collective; torch.distributed (RCCL) only provides the barrier and the max-over-ranks
-           clock.  scaling = weak (per-GPU work fixed).
+           clock.  scaling = weak (per-GPU work fixed).  "ranks" lists what every rank processed.
 roofline : dominant kernel = the scan (scan_mfma_kernel); achieved = its algorithmic bytes per launch
            (4*resolution + 8*n per item) / its average launch duration, measured with
-           hipEvents recorded on the launch stream inside the timed region (baz_music_profile).
+           hipEvents recorded on the launch stream inside the timed rounds (baz_music_profile).  "traffic" = HBM
+           bytes per launch from the rocprofv3 PMC passes kept under profiles/ -- used ONLY when that profile was
+           taken on the kernel sources this run executes (sha256 over gr_baz_amd/csrc + include), else null and
+           "traffic_stale": true.
+extras   : config.extra carries three secondary, clearly labelled measurements (rank 0, N=1): cfg2 WITHOUT the
+           spectrum port (the GRC default wiring), cfg3 (8 ant, 4096 samp, 36000 bins: fp64-matrix bound) and the cfg5
+           chain (16 ant: resampler -> AGC -> MUSIC on one stream), each with its own ms, bound and fraction.
 cpu_baseline : rank 0, N=1 only: oracle/_ref (the reference's own baz_music_doa.cc compiled in place, kind
            "reference") when its prebuilt .so is present, else the plain-C restatement (oracle/music_ref.c, kind
            "port"); one work() per item like the GNU Radio scheduler drives the reference, on all host cores
            (one independent block instance per thread) for a bounded sample (~2 s per leg).
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import threading
 import time
@@ -35,6 +47,18 @@ FREQUENCY, SPACING = 299792458.0, 0.5
 STREAMS_PER_GPU, ITEMS_PER_STREAM = 8, 32768
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_MFMA_PEAK_TF = 78.6   # AMD datasheet; ubench: v_mfma_f64_16x16x4_f64 = 65 cycles/SIMD -> 77 TF (profiles/r01_ubench_fp64_rates.txt)
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r02_scan_pmc_traffic.json")
+
+
+def kernel_sources_sha():
+    """sha256 over the sources the device code is built from: ties a kept rocprof profile to the code that ran."""
+    h = hashlib.sha256()
+    for d in (os.path.join(ROOT, "gr_baz_amd", "csrc"), os.path.join(ROOT, "include")):
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".hip", ".h")):
+                h.update(name.encode())
+                h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _usable_cpus():
@@ -121,19 +145,148 @@ def cpu_baseline(table, seconds_per_thread=2.0):
     return out
 
 
+def helper_table(np, synth, m, res):
+    """Steering table exactly as music_doa_helper builds it, rounded to complex64 like SWIG does."""
+    from gr_baz_amd.baz.music_doa_helper import calculate_antenna_array_response
+    arr = synth.array_geometry(m)
+    lam = synth.C_LIGHT / FREQUENCY
+    return arr, np.array(calculate_antenna_array_response([[SPACING * x, SPACING * y] for x, y in arr], res, lam)
+                         ).astype(np.complex64)
+
+
+def timed_loop(torch, step, sync, min_seconds, chunk=5, max_steps=2000):
+    """ms per step of `step()` after a short ramp: at least min_seconds of back-to-back launches."""
+    for _ in range(chunk):
+        step()
+    sync()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for _ in range(chunk):
+            step()
+        sync()
+        n += chunk
+        if time.perf_counter() - t0 >= min_seconds or n >= max_steps:
+            break
+    return (time.perf_counter() - t0) / n * 1e3, n
+
+
+def extra_music(torch, np, capi, synth, dev, stream, m, nsamples, res, batch, with_spectrum, seconds):
+    """One secondary MUSIC configuration on the bench stream: ms/step, per-stage ms, dominant-kernel rooflines."""
+    arr, table = helper_table(np, synth, m, res)
+    per = batch // 8
+    x = torch.cat([synth.synth_stream(torch, dev, per, m, nsamples, arr, FREQUENCY, SPACING, seed=1000 + 3 + s)
+                   for s in range(8)], dim=0)
+    ang = torch.zeros(batch, N_EMIT, dtype=torch.float32, device=dev)
+    lvl = torch.zeros_like(ang)
+    spec = torch.zeros(batch, res, dtype=torch.float32, device=dev) if with_spectrum else None
+    with capi.Context(m, N_EMIT, nsamples, res, table, device_id=dev.index) as ctx:
+        ctx.set_stream(stream.cuda_stream)
+        ctx.reserve(batch)
+        sp = spec.data_ptr() if with_spectrum else None
+        step = lambda: ctx.process_device(x.data_ptr(), batch, ang.data_ptr(), lvl.data_ptr(), sp)
+        ms, n = timed_loop(torch, step, stream.synchronize, seconds)
+        ctx.profile(1)
+        for _ in range(3):
+            step()
+        stream.synchronize()
+        st = [ctx.stage_ms(s) for s in range(capi.NUM_STAGES)]
+        ctx.profile(False)
+        bpi = ctx.bytes_per_item(with_spectrum)
+        ctx.set_stream(None)
+    stage = {nm: st[s][0] / max(st[s][1], 1) for s, nm in enumerate(("cov", "evd", "scan", "merge"))}
+    scan_s = stage["scan"] * 1e-3
+    mm = m * m
+    scan_tf = 2.0 * mm * res * batch / scan_s / 1e12 if scan_s > 0 else 0.0
+    out = {"items_per_step": batch, "ms_per_step": ms, "steps_timed": n, "snapshots_per_s": batch / ms * 1e3,
+           "algorithmic_bytes_per_item": bpi, "pipeline_hbm_fraction_of_8TBs": batch / ms * 1e3 * bpi / 8e12,
+           "stage_ms_per_launch": stage,
+           "scan_fp64_tflops": scan_tf, "scan_frac_of_fp64_matrix_peak": scan_tf / FP64_MFMA_PEAK_TF}
+    if with_spectrum:
+        wr = (4 * res + 8 * N_EMIT) * batch / scan_s / 1e9 if scan_s > 0 else 0.0
+        out["scan_write_GBs"] = wr
+        out["scan_frac_of_hbm_8TBs"] = wr / HBM_PEAK_GBS
+    return out
+
+
+def extra_cfg5(torch, np, capi, synth, dev, stream, nitems, seconds):
+    """BASELINE config 5 on one GPU: 16-antenna front-end (fractional resampler -> AGC + interleave) ahead of MUSIC
+    (m16, n2, N4096 = 16 x 256, res3600), device resident, one stream, nothing leaves HBM between the engines."""
+    from gr_baz_amd import agc, resamp
+    m, K, res, ratio = 16, 256, 3600, 1.25
+    N = m * K
+    arr, table = helper_table(np, synth, m, res)
+    T_out = nitems * K
+    L = int(T_out * ratio) + 16
+    it = synth.synth_stream(torch, dev, (L + K - 1) // K, m, N, arr, FREQUENCY, SPACING, seed=1005)
+    raw = torch.view_as_real(it.view(torch.complex64).reshape(-1, m).t().contiguous()[:, :L].contiguous()).reshape(m, 2 * L)
+    del it
+    d_rs = torch.zeros(m, 2 * T_out, dtype=torch.float32, device=dev)
+    d_items = torch.zeros(nitems, 2 * N, dtype=torch.float32, device=dev)
+    ang = torch.zeros(nitems, N_EMIT, dtype=torch.float32, device=dev)
+    lvl = torch.zeros_like(ang)
+    spec = torch.zeros(nitems, res, dtype=torch.float32, device=dev)
+    R = resamp.Resampler(0.0, ratio, nstreams=m)
+    A = agc.Agc(1e-4, 1.0, nstreams=m)
+    Mx = capi.Context(m, N_EMIT, N, res, table, device_id=dev.index)
+    try:
+        Mx.reserve(nitems)
+        for e in (R, A, Mx):
+            e.set_stream(stream.cuda_stream)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+        def step(timed=False):
+            R.set_mu(0.0)                                    # every step resamples the same capture from its start
+            if timed:
+                ev[0].record(stream)
+            R.process_device(raw.data_ptr(), L, L, d_rs.data_ptr(), T_out, T_out)
+            if timed:
+                ev[1].record(stream)
+            A.process_device_interleaved(d_rs.data_ptr(), T_out, T_out, d_items.data_ptr())
+            if timed:
+                ev[2].record(stream)
+            Mx.process_device(d_items.data_ptr(), nitems, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr())
+            if timed:
+                ev[3].record(stream)
+
+        torch.cuda.synchronize()
+        ms, n = timed_loop(torch, step, stream.synchronize, seconds)
+        step(True)
+        stream.synchronize()
+        eng = [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
+        Mx.profile(1)
+        step()
+        stream.synchronize()
+        st = [Mx.stage_ms(s)[0] for s in range(capi.NUM_STAGES)]
+        Mx.profile(False)
+    finally:
+        for e in (R, A, Mx):
+            e.set_stream(None)
+            e.close()
+    in_b, rs_b = m * L * 8, m * T_out * 8
+    chain_bytes = in_b + rs_b + rs_b + nitems * N * 8 + nitems * N * 8 + nitems * (4 * res + 8 * N_EMIT)
+    return {"items_per_step": nitems, "ms_per_step": ms, "steps_timed": n, "snapshots_per_s": nitems / ms * 1e3,
+            "complex_samples_per_s_per_antenna": T_out / ms * 1e3,
+            "engine_ms": {"resampler": eng[0], "agc_interleave": eng[1], "music": eng[2]},
+            "music_stage_ms": dict(zip(("cov", "evd", "scan", "merge"), st)),
+            "bound": "fp64 VALU issue (16x16 Jacobi EVD) + hbm (front-end)",
+            "resampler_GBs": (in_b + rs_b) / eng[0] / 1e6, "agc_GBs": (rs_b + 2 * nitems * N * 8) / eng[1] / 1e6,
+            "chain_bytes_per_step": chain_bytes, "chain_hbm_fraction_of_8TBs": chain_bytes / (ms * 1e-3) / 8e12}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary cfg2-no-spectrum / cfg3 / cfg5 measurements")
     ap.add_argument("--ramp-seconds", type=float, default=0.25, help="untimed steady load before warm-up (clock ramp)")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat the K-step timed region until this much timed work")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     from gr_baz_amd import capi, sharding, synth
-    from gr_baz_amd.baz.music_doa_helper import calculate_antenna_array_response
 
     rank, local_rank, world = sharding.dist_env()
     if world != max(1, args.gpus) and world > 1:
@@ -143,12 +296,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     active = sharding.init_process_group(use_gpu=True, local_rank=local_rank)
+    backend = sharding._BACKEND if active else None
 
-    # steering table exactly as music_doa_helper builds it, rounded to complex64 like SWIG does
-    arr = synth.array_geometry(M)
-    lam = synth.C_LIGHT / FREQUENCY
-    table = np.array(calculate_antenna_array_response([[SPACING * x, SPACING * y] for x, y in arr], RES, lam)
-                     ).astype(np.complex64)
+    arr, table = helper_table(np, synth, M, RES)
 
     # this rank's streams: global stream s lives on rank s mod world (config 4), seed = 1002 + s
     n_streams = STREAMS_PER_GPU * world
@@ -160,8 +310,12 @@ def main():
     lvl = torch.zeros_like(ang)
     spec = torch.zeros(batch, RES, dtype=torch.float32, device=dev)
 
+    # One explicit stream for everything the engine does (ordered against the fills above by the synchronize below)
+    stream = torch.cuda.Stream(device=dev)
     ctx = capi.Context(M, N_EMIT, NSAMPLES, RES, table, device_id=local_rank)
+    ctx.set_stream(stream.cuda_stream)
     ctx.reserve(batch)
+    torch.cuda.synchronize()
 
     def step():
         ctx.process_device(x.data_ptr(), batch, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr())
@@ -177,16 +331,26 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    sharding.barrier(active, True)
+
+    # Timed rounds: each is EXACTLY args.steps steps between barrier + synchronize on both sides, max over ranks.
     ctx.profile(int(os.environ.get("BAZ_BENCH_PROFILE", "2")))   # 2: hipEvents around the dominant kernel only
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    sharding.barrier(active, True)
-    scan_ms, scan_n = ctx.stage_ms(capi.STAGE_SCAN)       # dominant kernel, timed region only
+    rounds, scan_ms_total, scan_launches, timed_total = [], 0.0, 0, 0.0
+    while True:
+        sharding.barrier(active, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        sharding.barrier(active, True)
+        tmax = sharding.max_over_ranks(elapsed, active, True)
+        rounds.append(tmax)
+        timed_total += tmax
+        sm, sn = ctx.stage_ms(capi.STAGE_SCAN)            # cumulative since profile(): dominant kernel, timed rounds only
+        scan_ms_total, scan_launches = sm, sn
+        if timed_total >= args.min_seconds or len(rounds) >= 200:
+            break
     ctx.profile(False)
     # informational per-stage breakdown from a separate short pass (events around every kernel add launch gaps,
     # so they stay out of the timed region)
@@ -196,55 +360,99 @@ def main():
     torch.cuda.synchronize()
     stage = [ctx.stage_ms(s) for s in range(capi.NUM_STAGES)]
     ctx.profile(False)
+    cov_name = ctx.stage_name(capi.STAGE_COV)
+    bpi = ctx.bytes_per_item(True)
+    ctx.set_stream(None)
+    ctx.close()
 
-    value, tmax, total_items = sharding.whole_job_rate(batch * args.steps, elapsed, active, True)
+    t_med = statistics.median(rounds)
+    total_items = sharding.sum_over_ranks(float(batch * args.steps), active, True)
+    value = total_items / t_med
+    ranks = [{"rank": rank, "items_per_step": batch, "streams": mine, "device": torch.cuda.get_device_name(local_rank)}]
+    if active:
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ranks[0])
+        ranks = gathered
 
     if rank == 0:
-        scan_avg_s = scan_ms / max(scan_n, 1) * 1e-3
+        scan_avg_s = scan_ms_total / max(scan_launches, 1) * 1e-3
         scan_bytes = (4 * RES + 8 * N_EMIT) * batch                 # spectrum + ang/lvl-equivalent written per launch
         achieved = scan_bytes / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_scan_pmc_traffic.json")
-        if os.path.exists(tj):
+        src_sha = kernel_sources_sha()
+        traffic, traffic_stale, traffic_src = None, None, None
+        if os.path.exists(TRAFFIC_PROFILE):
             try:
-                tinfo = json.load(open(tj))
-                traffic = tinfo.get("scan_hbm_bytes_per_launch")
-                if traffic and tinfo.get("items_per_launch") and tinfo["items_per_launch"] != batch:
-                    traffic = int(traffic * batch / tinfo["items_per_launch"])   # the profile used another launch size
+                tinfo = json.load(open(TRAFFIC_PROFILE))
+                traffic_src = os.path.relpath(TRAFFIC_PROFILE, ROOT)
+                if tinfo.get("kernel_sources_sha") == src_sha and tinfo.get("items_per_launch") == batch:
+                    traffic, traffic_stale = tinfo.get("scan_hbm_bytes_per_launch"), False
+                else:
+                    traffic_stale = True                            # profile of other code / launch size: not reported
             except Exception:
-                traffic = None
+                traffic_stale = True
         cov_s = stage[capi.STAGE_COV][0] / max(stage[capi.STAGE_COV][1], 1) * 1e-3
         cov_tf = 8.0 * M * NSAMPLES * batch / cov_s / 1e12 if cov_s > 0 else 0.0
-        cov_mfma = {"useful_tflops": cov_tf, "fp64_matrix_peak_tflops": FP64_MFMA_PEAK_TF,
-                    "frac_of_peak": cov_tf / FP64_MFMA_PEAK_TF, "issued_over_useful": 2.0,
+        x4 = "cov4_x4" in cov_name
+        cov_mfma = {"kernel": cov_name, "useful_tflops": cov_tf, "fp64_matrix_peak_tflops": FP64_MFMA_PEAK_TF,
+                    "frac_of_peak": cov_tf / FP64_MFMA_PEAK_TF, "issued_over_useful": 4.0 / 3.0 if x4 else 2.0,
                     "hbm_read_GBs": 8.0 * NSAMPLES * batch / cov_s / 1e9 if cov_s > 0 else 0.0,
-                    "note": "16x16x4 fp64 MFMA tiles hold 2 items block-diagonally at m=4 (half the issued flops are "
-                            "structural zeros); the kernel is HBM-read bound"}
+                    "hbm_read_frac_of_8TBs": 8.0 * NSAMPLES * batch / cov_s / 1e9 / HBM_PEAK_GBS if cov_s > 0 else 0.0,
+                    "note": ("v_mfma_f64_4x4x4_4b blocks: X0X0^T, X0X1^T, X1X1^T + one transposed duplicate per pair of "
+                             "instructions; dwordx4 input stream; the kernel is HBM-read bound") if x4 else
+                            ("16x16x4 fp64 MFMA tiles hold 2 items block-diagonally at m=4 (half the issued flops are "
+                             "structural zeros); the kernel is HBM-read bound")}
+        per_round = [t / args.steps * 1e3 for t in rounds]
         line = {
             "metric": "MUSIC-DoA snapshots/s (4 ant, 1024 samp, 3600 bins)",
             "value": value, "unit": "snapshots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": tmax / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": t_med / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "rounds": {"count": len(rounds), "steps_each": args.steps, "statistic": "median",
+                       "ms_per_step_min": min(per_round), "ms_per_step_max": max(per_round),
+                       "timed_seconds_total": timed_total},
+            "kernel_sources_sha": src_sha,
             "config": {"workload": "cfg2 (BASELINE.json configs[1]): m=4 n=2 nsamples=1024 (K=256) resolution=3600, "
                                    "spectrum port wired, %d streams x %d items per GPU per step, device-resident"
                                    % (STREAMS_PER_GPU, ITEMS_PER_STREAM),
                        "items_per_gpu_per_step": batch, "parallelism": "independent streams, s mod %d, no collective" % world,
-                       "algorithmic_bytes_per_item": ctx.bytes_per_item(True),
-                       "pipeline_hbm_fraction_of_8TBs": value / world * ctx.bytes_per_item(True) / 8e12,
+                       "collective_backend_for_barrier_and_clock": backend, "ranks": ranks,
+                       "algorithmic_bytes_per_item": bpi,
+                       "pipeline_hbm_fraction_of_8TBs": value / world * bpi / 8e12,
                        "stage_ms_per_launch_separate_pass": {nm: stage[s][0] / max(stage[s][1], 1)
-                                               for s, nm in enumerate(("cov_mfma", "evd_proj", "scan_mfma", "topn_merge"))},
+                                               for s, nm in enumerate(("cov", "evd_proj", "scan_mfma", "topn_merge"))},
                        # the one dense contraction (north_star): useful fp64 flops 8*m*N per item against the fp64
-                       # matrix peak; rocprofv3 MFMA-busy for the same kernel is in profiles/r01g_bench_pmc_summary.txt
+                       # matrix peak; rocprofv3 MFMA-busy for the same kernel is in profiles/r02_bench_pmc_summary.txt
                        "covariance_mfma": cov_mfma},
             "roofline": {"bound": "hbm", "kernel": "scan_mfma_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_stale": traffic_stale, "traffic_profile": traffic_src,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_avg_s * 1e3,
-                         "launches": scan_n},
+                         "launches": scan_launches},
         }
+        if world == 1 and not args.no_extras:
+            extra = {}
+            del x, spec
+            torch.cuda.empty_cache()
+            for name, fn in (
+                    ("cfg2_without_spectrum_port", lambda: dict(extra_music(torch, np, capi, synth, dev, stream, 4, 1024, 3600, 262144, False, 0.4),
+                                                                bound="fp64 matrix issue (no stores); HBM read for the covariance",
+                                                                workload="cfg2 with only ang/lvl wired (music_doa_helper's default output_spectrum=False)")),
+                    ("cfg3", lambda: dict(extra_music(torch, np, capi, synth, dev, stream, 8, 4096, 36000, 16384, True, 0.5),
+                                          bound="fp64 matrix (scan: 2*m^2 flop per item and bin)",
+                                          workload="BASELINE configs[2]: m=8 n=2 nsamples=4096 (K=512) resolution=36000, spectrum wired")),
+                    ("cfg5_chain", lambda: dict(extra_cfg5(torch, np, capi, synth, dev, stream, 16384, 0.5),
+                                                workload="BASELINE configs[4] on one GPU: 16 antennas, fractional_resampler_cc "
+                                                         "(ratio 1.25) -> agc_cc -> music_doa (m16 n2 N4096 res3600), one stream"))):
+                try:
+                    extra[name] = fn()
+                except Exception as e:                       # a secondary measurement never takes the headline down
+                    extra[name] = {"error": repr(e)}
+                torch.cuda.empty_cache()
+            line["config"]["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(table)
         print(json.dumps(line), flush=True)
-    ctx.close()
     if active:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -30,6 +30,7 @@ baz_music_doa_sptr = _native.baz_music_doa_sptr
 agc_cc = _native.agc_cc                    # GR_SWIG_BLOCK_MAGIC(baz, agc_cc) in the reference
 baz_agc_cc_sptr = _native.baz_agc_cc_sptr
 fractional_resampler_cc = _native.fractional_resampler_cc   # GR_SWIG_BLOCK_MAGIC2(baz, fractional_resampler_cc)
+deal_device = _native.deal_device          # placement rule of block instances (not part of the reference surface)
 
 from . import music_doa_helper  # noqa: E402,F401
 

@@ -23,7 +23,7 @@ MAX_M, MAX_N = 16, 15
 # every symbol include/baz_music_hip.h declares (tests/test_abi.py checks the .so exports them all)
 SYMBOLS = [
     "baz_music_create", "baz_music_destroy", "baz_music_set_table", "baz_music_process",
-    "baz_music_process_device", "baz_music_set_stream", "baz_music_sync", "baz_music_reserve",
+    "baz_music_process_device", "baz_music_process_device_on", "baz_music_set_stream", "baz_music_sync", "baz_music_reserve",
     "baz_music_profile", "baz_music_stage_ms", "baz_music_stage_name", "baz_music_debug_cov",
     "baz_music_debug_evd", "baz_music_debug_q", "baz_music_q_stride", "baz_music_bytes_per_item", "baz_music_strerror",
     "baz_music_last_hip_error", "baz_music_version", "baz_music_device_count", "baz_music_device", "baz_music_set_peak_mode", "baz_music_refined_items",
@@ -64,6 +64,8 @@ def lib():
     L.baz_music_process.argtypes = [_vp, _f32p, _u32, _f32p, _f32p, _f32p]
     L.baz_music_process_device.restype = ctypes.c_int
     L.baz_music_process_device.argtypes = [_vp, _vp, _u32, _vp, _vp, _vp]
+    L.baz_music_process_device_on.restype = ctypes.c_int
+    L.baz_music_process_device_on.argtypes = [_vp, _vp, _vp, _u32, _vp, _vp, _vp]
     L.baz_music_set_stream.restype = ctypes.c_int
     L.baz_music_set_stream.argtypes = [_vp, _vp]
     L.baz_music_sync.restype = ctypes.c_int
@@ -178,11 +180,18 @@ class Context:
         return ang, lvl, spec
 
     # ---- device-resident path (pointers are plain integers, e.g. torch.Tensor.data_ptr()) ----
-    def process_device(self, d_in, batch, d_ang, d_lvl=None, d_spec=None):
-        self._chk(lib().baz_music_process_device(self._h, _vp(d_in), int(batch), _vp(d_ang),
-                                                 _vp(d_lvl) if d_lvl else None,
-                                                 _vp(d_spec) if d_spec else None),
-                  "baz_music_process_device")
+    def process_device(self, d_in, batch, d_ang, d_lvl=None, d_spec=None, stream=None):
+        """Enqueues one batch.  stream=None: on the context's stream, unordered against other streams (the caller
+        orders: set_stream(), sync(), or a device-wide synchronize).  stream=<hipStream_t as int, 0 = the legacy
+        default stream, e.g. torch.cuda.current_stream().cuda_stream>: with stream semantics relative to it."""
+        if stream is None:
+            r = lib().baz_music_process_device(self._h, _vp(d_in), int(batch), _vp(d_ang),
+                                               _vp(d_lvl) if d_lvl else None, _vp(d_spec) if d_spec else None)
+        else:
+            r = lib().baz_music_process_device_on(self._h, _vp(stream) if stream else None, _vp(d_in), int(batch),
+                                                  _vp(d_ang), _vp(d_lvl) if d_lvl else None,
+                                                  _vp(d_spec) if d_spec else None)
+        self._chk(r, "baz_music_process_device")
 
     def refined_items(self):
         """Items of the last process call that were recomputed in literal form (near-null bins, extreme SNR)."""

@@ -64,6 +64,7 @@ struct baz_music_ctx {
     uint32_t s_cap = 0;
     bool s_has_spec = false;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;   // baz_music_process_device_on: ordering against the caller's stream
     std::mutex mtx;   // serialises set_table against process*, like d_mutex (.cc:67,101)
     int profiling = 0;      // 0 off, 1 every stage, 2 only the dominant (scan) stage
     int lab_variant = 0;
@@ -632,8 +633,10 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         c->keep_mask = (resolution <= (1u << 16)) ? 0xFFFF0000u : 0xFFF00000u;
         c->fb_step_elems = (size_t)2 * ((m * m + 3) / 4) * 64;
         c->tb_step_elems = (size_t)2 * ((2 * m + 3) / 4) * 64;
-        // row classes of the spectrum port (scan kernel, ROW CLASSES): rows whose byte offset 4*res*i agrees mod 256
-        if (resolution % 4u == 0) {
+        // row classes of the spectrum port (scan kernel, ROW CLASSES): rows whose byte offset 4*res*i agrees mod 256.
+        // Only where the scan is bound by its stores (m <= 5: <= 28 fp64 FMAs per 4 stored bytes); from m = 6 on it is
+        // bound by the matrix core and the shifted table windows only cost (config 5: scan 0.706 -> 0.773 ms).
+        if (resolution % 4u == 0 && m <= 5) {
             uint32_t gcd = 64;
             while (resolution % gcd) gcd >>= 1;
             c->nclass = 64u / gcd;
@@ -688,6 +691,8 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->dRefined) (void)hipFree(c->dRefined);
         if (c->dPeakSpec) (void)hipFree(c->dPeakSpec);
         free_slots(c);
+        if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+        if (c->ev_out) (void)hipEventDestroy(c->ev_out);
         if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
         if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -742,6 +747,31 @@ int baz_music_process_device(baz_music_ctx* c, const void* d_in, uint32_t batch,
     DeviceGuard guard(c->device);
     HIP_TRY(c, hipMemsetAsync(c->dRefined, 0, sizeof(unsigned long long), c->stream));
     return process_device_locked(c, d_in, batch, d_ang, d_lvl, d_spec);
+}
+
+int baz_music_process_device_on(baz_music_ctx* c, void* caller_stream, const void* d_in, uint32_t batch, void* d_ang,
+                                void* d_lvl, void* d_spec)
+{
+    if (!c || !d_in || !d_ang) return BAZ_MUSIC_E_INVALID;
+    if (batch == 0) return BAZ_MUSIC_OK;
+    std::lock_guard<std::mutex> lk(c->mtx);   // .cc:101
+    DeviceGuard guard(c->device);
+    hipStream_t cs = static_cast<hipStream_t>(caller_stream);
+    const bool foreign = (cs != c->stream);
+    if (foreign) {
+        if (!c->ev_in) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+        if (!c->ev_out) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->ev_in, cs));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    }
+    HIP_TRY(c, hipMemsetAsync(c->dRefined, 0, sizeof(unsigned long long), c->stream));
+    int r = process_device_locked(c, d_in, batch, d_ang, d_lvl, d_spec);
+    if (foreign) {   // also after a failed launch: whatever was enqueued is ordered before the caller's next work
+        hipError_t e = hipEventRecord(c->ev_out, c->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(cs, c->ev_out, 0);
+        if (e != hipSuccess && r == BAZ_MUSIC_OK) r = hip_fail(c, e, "hipStreamWaitEvent(caller_stream)");
+    }
+    return r;
 }
 
 int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, float* ang, float* lvl,

@@ -968,18 +968,26 @@ __device__ __forceinline__ uint32_t literal_tile(v4f64 (&acc)[4], const ScanRefi
 #pragma unroll
             for (int part = 0; part < 2; ++part) {   // Re / Im of c_k = sum_i conj(G_ik) a_i
                 v4f64 p = {0, 0, 0, 0};
+                // Real coordinate e = 4 s + g: antenna e/2 = 2 s + (g >> 1), re (g even) or im (g odd) part of a.
+                //   Re c: +gr*ar +gi*ai      Im c: -gi*ar +gr*ai
+                // A rolled loop over s for m >= 5: unrolled, its 2 x KS2 loop-invariant operand addresses get hoisted
+                // out of the STEP loop of the scan and cost the ordinary steps up to 32 VGPRs (m = 16: spills).
+                const int comp = part ? ((g & 1) ^ 1) : (g & 1);
+                const double sgn = (part && !(g & 1)) ? -1.0 : 1.0;
+                const double* __restrict__ ga = rf.Gs + (size_t)((k * M + (g >> 1)) * 2 + comp) * qstride + itc;
+                const double* __restrict__ tb = tb1 + (size_t)(t >> 1) * 128 + (t & 1);
+                if constexpr (KS2 <= 2) {
 #pragma unroll
-                for (int s = 0; s < KS2; ++s) {
-                    const int e = 4 * s + g;      // real coordinate: antenna e/2, re (even) or im (odd) part of a
-                    double a = 0.0;
-                    if (e < 2 * M) {
-                        // Re c: +gr*ar +gi*ai      Im c: -gi*ar +gr*ai
-                        const int comp = part ? ((e & 1) ^ 1) : (e & 1);
-                        a = rf.Gs[(size_t)((k * M + (e >> 1)) * 2 + comp) * qstride + itc];
-                        if (part && !(e & 1)) a = -a;
+                    for (int s = 0; s < KS2; ++s) {
+                        const double a = (4 * s + g < 2 * M) ? sgn * ga[(size_t)s * 4 * qstride] : 0.0;
+                        p = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tb[(size_t)s * 256], p, 0, 0, 0);
                     }
-                    const double b = tb1[((size_t)(2 * s + (t >> 1)) * 64) * 2 + (t & 1)];   // tile t of k-step s
-                    p = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, p, 0, 0, 0);
+                } else {
+#pragma nounroll
+                    for (int s = 0; s < KS2; ++s) {
+                        const double a = (4 * s + g < 2 * M) ? sgn * ga[(size_t)s * 4 * qstride] : 0.0;
+                        p = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tb[(size_t)s * 256], p, 0, 0, 0);
+                    }
                 }
                 d += p * p;
             }
@@ -998,9 +1006,11 @@ __device__ __forceinline__ uint32_t literal_tile(v4f64 (&acc)[4], const ScanRefi
     return cnt;
 }
 
-// (m <= 4: 4 waves/SIMD = 128 VGPRs; the few values this displaces live in the rare literal / statistic paths)
+// Occupancy floors: m <= 4: 4 waves/SIMD = 128 registers; m >= 9 (q alone is m^2/2 registers): 2 waves/SIMD = 256
+// registers INCLUDING accumulation registers (without the floor the m = 16 kernel took 256 + 28 and ran one wave per
+// SIMD: scan 0.56 -> 0.78 ms on config 5).  What this displaces lives in the rare literal / statistic paths.
 template <int M, int NMAX, bool SPEC, bool VEC4, int ABL = 0, int AUX = (1 | 2 | 16)>
-__global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : 1) void scan_mfma_kernel(const double* __restrict__ Qs,
+__global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) void scan_mfma_kernel(const double* __restrict__ Qs,
                                                          const double2* __restrict__ FB,
                                                          float* __restrict__ spec,
                                                          double* __restrict__ cand,
@@ -1165,19 +1175,24 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : 1) void scan_mfma_
                 // also catches the near-null tiles.  Items of one stream see the same scene, so the 16 items of a
                 // wave rise together and most steps skip (profiles/r02_scan_gate.txt).
                 bool hit = false, low = false;
-                [[maybe_unused]] float fd[4][4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if constexpr (SPEC && !(ABL & 4)) {
+                        float fd[4];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) fd[r][t] = (float)acc[t][r];   // sign (rounding noise around 0) dropped by |.| below
+                        for (int t = 0; t < 4; ++t) fd[t] = (float)acc[t][r];   // sign (rounding noise around 0) dropped by |.| below
                         if constexpr (!(ABL & 2)) {
                             float mn;
-                            asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(mn) : "v"(fd[r][0]), "v"(fd[r][1]), "v"(fd[r][2]));
-                            asm("v_min_f32 %0, %1, |%2|" : "=v"(mn) : "v"(mn), "v"(fd[r][3]));
+                            asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(mn) : "v"(fd[0]), "v"(fd[1]), "v"(fd[2]));
+                            asm("v_min_f32 %0, %1, |%2|" : "=v"(mn) : "v"(mn), "v"(fd[3]));
                             hit |= (mn <= gate_f[r]);
                             low |= (mn <= below_f);
                         }
+                        // the spectrum values right away (strength_f32(|d|); ||G^H a||^2 >= 0 in the reference): the
+                        // converted values then die here instead of living across the branch below, which matters for
+                        // the register budget at m >= 9; a refined tile redoes its 16 values
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) sv[r][t] = __builtin_amdgcn_rcpf(fabsf(fd[t]));
                     } else {
                         if constexpr (!(ABL & 2)) {
                             double m01, m23, mn;
@@ -1200,7 +1215,7 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : 1) void scan_mfma_
 #pragma unroll
                                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                                    for (int t = 0; t < 4; ++t) fd[r][t] = (float)acc[t][r];
+                                    for (int t = 0; t < 4; ++t) sv[r][t] = strength_f32(fabs(acc[t][r]));
                             }
                             if (rf.count) {         // statistic (baz_music_refined_items): values recomputed
 #pragma unroll
@@ -1220,13 +1235,12 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : 1) void scan_mfma_
                         }
                     }
                 }
+                if constexpr (ABL & 4) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        if constexpr (ABL & 4) sv[r][t] = __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint64_t, acc[t][r]));
-                        else if constexpr (SPEC) sv[r][t] = __builtin_amdgcn_rcpf(fabsf(fd[r][t]));   // strength_f32(|d|); ||G^H a||^2 >= 0 in the reference
-                    }
+                        for (int t = 0; t < 4; ++t) sv[r][t] = __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint64_t, acc[t][r]));
+                }
             }
 
             // 4. publish the next phase (waits only for the stage loads and the previous step's stores) ...

@@ -51,12 +51,16 @@ void check_config(unsigned int m, unsigned int n, unsigned int nsamples, unsigne
 /* Independent block instances (BASELINE config 4: 64 streams in one flowgraph) are dealt over the node's GPUs
  * round-robin -- instance i -> device i mod G -- unless BAZ_MUSIC_DEVICE pins one; -1 = the current
  * HIP device when no gfx950 device is visible (create() then reports the error). */
+int baz_music_doa_deal_device(unsigned int instance, int device_count)
+{
+    return device_count > 0 ? (int)(instance % (unsigned)device_count) : -1;
+}
+
 static int next_device()
 {
     if (const char* v = getenv("BAZ_MUSIC_DEVICE")) return atoi(v);
     static std::atomic<unsigned> s_instances(0);
-    const int g = baz_music_device_count();
-    return g > 0 ? (int)(s_instances.fetch_add(1) % (unsigned)g) : -1;
+    return baz_music_doa_deal_device(s_instances.fetch_add(1), baz_music_device_count());
 }
 
 static long env_long(const char* name, long dflt, long lo, long hi)
@@ -117,6 +121,8 @@ baz_music_doa::~baz_music_doa()
 {
     baz_music_destroy(d_ctx);
 }
+
+int baz_music_doa::device() const { return baz_music_device(d_ctx); }
 
 void baz_music_doa::set_peak_mode(bool local_maxima)
 {

@@ -66,6 +66,8 @@ public:
     unsigned int nsamples() const { return d_nsamples; }
     unsigned int resolution() const { return d_resolution; }
     array_response_t array_response();
+    /* HIP device this instance's context lives on (see baz_music_doa_deal_device). */
+    int device() const;
 
 private:
     unsigned int d_m;
@@ -76,5 +78,10 @@ private:
     gr::thread::mutex d_mutex;
     baz_music_ctx* d_ctx;                /* device-side state (table, workspace, stream) */
 };
+
+/* Placement rule of independent block instances (BASELINE config 4: 64 streams in one flowgraph; SURVEY.md 8e,
+ * stream s -> GPU s mod G): the instance-th block made by this process goes to device instance % device_count;
+ * -1 (= the current HIP device) when no gfx950 device is visible.  BAZ_MUSIC_DEVICE pins every instance instead. */
+int baz_music_doa_deal_device(unsigned int instance, int device_count);
 
 #endif /* INCLUDED_BAZ_MUSIC_DOA_H */

@@ -115,6 +115,11 @@ PYBIND11_MODULE(_baz_music, mod)
         .def("output_streams", [](music_doa_handle& h) {
             return py::make_tuple(h.blk->output_signature()->min_streams(), h.blk->output_signature()->max_streams());
         })
+        /* scheduler hints the block registered (recorded by the API stand-in; a real runtime acts on them) */
+        .def("device", [](music_doa_handle& h) { return h.blk->device(); })
+        .def("output_multiple", [](music_doa_handle& h) { return h.blk->output_multiple(); })
+        .def("min_output_buffer", [](music_doa_handle& h) { return h.blk->min_output_buffer(); })
+        .def("max_noutput_items", [](music_doa_handle& h) { return h.blk->max_noutput_items(); })
         .def("work", &drive_work, py::arg("items"), py::arg("n_outputs") = 3);
     py::class_<agc_handle>(mod, "baz_agc_cc_sptr")
         .def("name", [](agc_handle& h) { return h.blk->name(); })
@@ -154,6 +159,8 @@ PYBIND11_MODULE(_baz_music, mod)
                 return h;
             },
             py::arg("rate") = 1e-4f, py::arg("reference") = 1.0f, py::arg("gain") = 1.0f, py::arg("max_gain") = 0.0f);
+    mod.def("deal_device", &baz_music_doa_deal_device, py::arg("instance"), py::arg("device_count"),
+            "placement rule of block instances: instance % device_count (-1 without devices)");
     mod.def("music_doa",
             [](unsigned int m, unsigned int n, unsigned int nsamples, const array_response_t& table, unsigned int resolution) {
                 music_doa_handle h;

@@ -80,9 +80,18 @@ BAZ_MUSIC_API int baz_music_process(baz_music_ctx* ctx, const float* in_ri, uint
 
 /* Same arithmetic on DEVICE-resident buffers (HBM), asynchronous on the context's stream:
  * d_in batch*nsamples complex64; d_ang, d_lvl batch*n float; d_spectrum batch*resolution
- * float or NULL. d_lvl may be NULL. Returns 0 or <0. */
+ * float or NULL. d_lvl may be NULL. Returns 0 or <0.
+ * ORDERING: the launches go to the context's stream -- its own non-blocking stream unless baz_music_set_stream()
+ * installed the caller's -- and nothing orders that stream against whatever produced d_in or pre-filled / will read
+ * the outputs.  Either make it the producer's stream (set_stream), or call the _on form below, or synchronise. */
 BAZ_MUSIC_API int baz_music_process_device(baz_music_ctx* ctx, const void* d_in, uint32_t batch,
                                            void* d_ang, void* d_lvl, void* d_spectrum);
+
+/* The same call with stream semantics relative to `caller_stream` (a hipStream_t; NULL = the legacy default
+ * stream): the batch starts after everything enqueued on caller_stream so far, and work enqueued on caller_stream
+ * afterwards sees the outputs (two event record / wait pairs; none when caller_stream IS the context's stream). */
+BAZ_MUSIC_API int baz_music_process_device_on(baz_music_ctx* ctx, void* caller_stream, const void* d_in,
+                                              uint32_t batch, void* d_ang, void* d_lvl, void* d_spectrum);
 
 /* Use an externally owned hipStream_t (e.g. the host framework's current stream) for all
  * subsequent launches; NULL restores the context's own stream (so the legacy default stream, whose

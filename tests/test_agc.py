@@ -108,6 +108,7 @@ def test_hip_agc_multi_stream_device_path_and_tail_alignment(gpu_device):
         d_out = torch.zeros_like(d_in)
         d_env = torch.zeros(S, stride, dtype=torch.float32, device=gpu_device)
         d_mul = torch.zeros_like(d_env)
+        torch.cuda.synchronize()                       # the engine runs on its own stream: fills first
         for lo, hi in ((0, 4097), (4097, n)):          # second call starts at an odd offset (unaligned float2 pairs)
             blk.process_device(d_in.data_ptr() + lo * 8, hi - lo, stride, d_out.data_ptr() + lo * 8,
                                d_env.data_ptr() + lo * 4, d_mul.data_ptr() + lo * 4)

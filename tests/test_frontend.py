@@ -35,6 +35,7 @@ def test_agc_interleaved_equals_per_stream_oracle(S, calls, gpu_device):
         for c in calls:
             items = torch.full((c * S * 2,), -7.0, dtype=torch.float32, device=gpu_device)
             pl = torch.zeros(S, 2 * x.shape[1], dtype=torch.float32, device=gpu_device)   # in and out share `stride`
+            torch.cuda.synchronize()                   # the engines run on their own streams: fills first
             blk.process_device_interleaved(xd.data_ptr() + pos * 8, c, x.shape[1], items.data_ptr())
             planar.process_device(xd.data_ptr() + pos * 8, c, x.shape[1], pl.data_ptr())
             blk.sync(); planar.sync()
@@ -79,6 +80,7 @@ def test_config5_frontend_fused_ahead_of_music(gpu_device):
     ang = torch.zeros(nitems, n, dtype=torch.float32, device=gpu_device)
     lvl = torch.zeros_like(ang)
     spec = torch.zeros(nitems, res, dtype=torch.float32, device=gpu_device)
+    torch.cuda.synchronize()                           # fills (torch's stream) before the engines' stream starts
     with resamp.Resampler(0.0, ratio, nstreams=m) as R, agc.Agc(1e-3, 1.0, nstreams=m) as A, \
             capi.Context(m, n, N, res, table) as M:
         stream = torch.cuda.Stream(device=gpu_device)            # one stream for the three engines: ordered, no host syncs

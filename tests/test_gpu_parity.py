@@ -32,9 +32,9 @@ def device_run(ctx, items, gpu_device, want_lvl=True, want_spec=True):
     ang = torch.full((B, ctx.n), -1.0, dtype=torch.float32, device=gpu_device)
     lvl = torch.full((B, ctx.n), -1.0, dtype=torch.float32, device=gpu_device) if want_lvl else None
     spec = torch.full((B, ctx.res), -1.0, dtype=torch.float32, device=gpu_device) if want_spec else None
+    # stream semantics against torch's stream: the fills above precede the batch, the reads below follow it
     ctx.process_device(x.data_ptr(), B, ang.data_ptr(), lvl.data_ptr() if want_lvl else None,
-                       spec.data_ptr() if want_spec else None)
-    ctx.sync()
+                       spec.data_ptr() if want_spec else None, stream=torch.cuda.current_stream().cuda_stream)
     return (ang.cpu().numpy(), lvl.cpu().numpy() if want_lvl else None,
             spec.cpu().numpy() if want_spec else None)
 
@@ -86,6 +86,7 @@ def test_stage_taps_covariance_and_projector(gpu_device):
             Q = torch.zeros(m * m, capi.q_stride(B), dtype=torch.float64, device=gpu_device)
             ctx.debug_evd(R.data_ptr(), B, Q.data_ptr())
             Qp = torch.zeros_like(Q)                       # the same two stages the way process_device() runs them
+            torch.cuda.synchronize()                       # (the taps run on the context's own stream)
             ctx.debug_q(x.data_ptr(), B, Qp.data_ptr())
             ctx.sync()
         Rg = R.cpu().numpy()
@@ -250,7 +251,8 @@ def test_full_size_properties(cfg, batch, distinct, gpu_device):
         ang = torch.full((batch, c["n"]), -1.0, dtype=torch.float32, device=gpu_device)
         lvl = torch.full_like(ang, -1.0)
         spec = torch.full((batch, c["res"]), -1.0, dtype=torch.float32, device=gpu_device)
-        ctx.process_device(x.data_ptr(), batch, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr())
+        ctx.process_device(x.data_ptr(), batch, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr(),
+                           stream=torch.cuda.current_stream().cuda_stream)
         ctx.sync()
     first = spec[:distinct]
     assert bool((spec.view(reps, distinct, -1) == first.unsqueeze(0)).all())
@@ -324,15 +326,66 @@ def test_peak_mode_is_opt_in_and_matches_its_definition(cfg, n_items, gpu_device
 
 
 # ------------------------------------------------------------------ boundary behaviour
-def test_device_dealing_of_block_instances(gpu_device):
-    """Host-block instances are dealt over the visible gfx950 devices (instance i -> device i mod G)."""
+def test_device_dealing_of_block_instances(gpu_device, monkeypatch):
+    """Host-block instances are dealt over the visible gfx950 devices (instance i -> device i mod G,
+    baz_music_doa_deal_device); BAZ_MUSIC_DEVICE pins them; a device that does not exist fails loudly."""
     capi = _capi()
+    from gr_baz_amd import baz
     g = capi.device_count()
     assert g >= 1
+    tab = [[1 + 0j] * 4] * 8
+    monkeypatch.delenv("BAZ_MUSIC_DEVICE", raising=False)
+    devs = [baz.music_doa(4, 2, 16, tab, 8).device() for _ in range(2 * g + 1)]
+    assert all(0 <= d < g for d in devs)
+    assert all((devs[i + 1] - devs[i]) % g == 1 % g for i in range(len(devs) - 1))        # round robin, whatever the start
+    monkeypatch.setenv("BAZ_MUSIC_DEVICE", str(g - 1))
+    assert [baz.music_doa(4, 2, 16, tab, 8).device() for _ in range(3)] == [g - 1] * 3
+    monkeypatch.setenv("BAZ_MUSIC_DEVICE", str(g + 3))
+    with pytest.raises(RuntimeError, match="gfx950"):
+        baz.music_doa(4, 2, 16, tab, 8)
+    monkeypatch.delenv("BAZ_MUSIC_DEVICE")
     c = mo.make_config("cfg1", 4)
     with capi.Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"], device_id=g - 1) as ctx:
         assert capi.lib().baz_music_device(ctx._h) == g - 1
-        a, l, s = device_run(ctx, c["items"], gpu_device) if g == 1 else (None, None, None)
+
+
+def test_config4_64_streams_over_4_contexts(gpu_device):
+    """BASELINE config 4, literally: 64 independent cfg2 streams (seed 1000 + 2 + s), dealt s mod G over G = 4
+    engines -- here 4 contexts on the one visible GPU, each with its own stream, table copy and workspace, exactly what
+    4 ranks (or 4 block instances) would own -- every stream checked against the oracle."""
+    torch = _torch()
+    capi = _capi()
+    from gr_baz_amd import sharding
+    G, S, per = 4, 64, 12
+    c0 = mo.make_config("cfg2", 1)
+    m, n, N, res, table = c0["m"], c0["n"], c0["nsamples"], c0["res"], c0["table"]
+    arr = mo.array_geometry(m)
+    streams = [mo.synth_items(per, m, N, arr, mo.FREQUENCY, mo.SPACING, seed=1000 + 2 + s) for s in range(S)]
+    ctxs = [capi.Context(m, n, N, res, table) for _ in range(G)]
+    try:
+        outs = []
+        for r, ctx in enumerate(ctxs):                       # launch everything first: the 4 engines run concurrently
+            mine = sharding.streams_of_rank(S, G, r)
+            x = torch.from_numpy(np.concatenate([streams[s] for s in mine]).view(np.float32)).to(gpu_device)
+            B = x.shape[0]
+            ang = torch.full((B, n), -1.0, device=gpu_device)
+            lvl = torch.full_like(ang, -1.0)
+            spec = torch.full((B, res), -1.0, device=gpu_device)
+            ctx.process_device(x.data_ptr(), B, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr(),
+                               stream=torch.cuda.current_stream().cuda_stream)
+            outs.append((mine, x, ang, lvl, spec))
+        seen = []
+        for mine, x, ang, lvl, spec in outs:
+            a, l, sp = ang.cpu().numpy(), lvl.cpu().numpy(), spec.cpu().numpy()
+            for k, s in enumerate(mine):
+                ao, lo, so, st = mo.music_doa_work_batch(streams[s], table, m, n)
+                assert_spectrum_close(sp[k * per:(k + 1) * per], so)
+                assert_doa_match(a[k * per:(k + 1) * per], l[k * per:(k + 1) * per], ao, lo, res, st)
+                seen.append(s)
+        assert sorted(seen) == list(range(S))
+    finally:
+        for ctx in ctxs:
+            ctx.close()
 
 
 def test_more_than_65536_bins_uses_the_wide_key(gpu_device):
@@ -387,6 +440,31 @@ def test_caller_stream_ordering(gpu_device):
         ctx.set_stream(None)
     assert_spectrum_close(spec.cpu().numpy(), so)
     assert np.allclose(total.cpu().numpy(), so.astype(np.float64).sum(axis=1), rtol=1e-4)
+
+
+def test_process_device_on_orders_against_the_callers_stream(gpu_device):
+    """baz_music_process_device_on: stream semantics against a stream the context does NOT run on: a slow
+    producer chain and a late output fill on torch's stream come BEFORE the batch, a consumer after it, no host sync."""
+    torch = _torch()
+    c = mo.make_config("cfg1", 256, seed=43)
+    ao, lo, so, st = mo.music_doa_work_batch(c["items"], c["table"], c["m"], c["n"])
+    with _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"]) as ctx:
+        src = torch.from_numpy(c["items"].view(np.float32)).to(gpu_device)
+        junk = torch.randn(4096, 4096, device=gpu_device)
+        torch.cuda.synchronize()
+        for rep in range(3):
+            for _ in range(6):
+                junk = junk @ junk * 1e-3                       # keeps torch's stream busy for a while ...
+            x = src + 0.0 * junk[0, 0]                          # ... before the input even exists
+            ang = torch.full((256, c["n"]), -1.0, device=gpu_device)
+            lvl = torch.full_like(ang, -1.0)
+            spec = torch.full((256, c["res"]), -1.0, device=gpu_device)      # late fills must not overwrite results
+            ctx.process_device(x.data_ptr(), 256, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr(),
+                               stream=torch.cuda.current_stream().cuda_stream)
+            total = spec.double().sum(dim=1)                    # consumer on torch's stream
+            assert_spectrum_close(spec.cpu().numpy(), so)
+            assert np.allclose(total.cpu().numpy(), so.astype(np.float64).sum(axis=1), rtol=1e-4)
+            assert_doa_match(ang.cpu().numpy(), lvl.cpu().numpy(), ao, lo, c["res"], st)
 
 
 def test_two_contexts_interleaved(gpu_device):

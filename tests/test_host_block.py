@@ -107,6 +107,26 @@ def test_host_block_work_matches_golden(name, gpu_device, capfd):
 
 
 @pytest.mark.gpu
+def test_scheduler_hints_are_requests_not_caps(gpu_device, monkeypatch):
+    """the block asks for large work() calls (output multiple + minimum output buffer) and sets NO cap
+    unless told to (lib/baz_music_doa.cc:160 returns 1 item per call; here one call = one launch sequence)."""
+    tab = [[1 + 0j] * 4] * 8
+    for k in ("BAZ_MUSIC_OUTPUT_MULTIPLE", "BAZ_MUSIC_MIN_OUTPUT_BUFFER", "BAZ_MUSIC_MAX_NOUTPUT"):
+        monkeypatch.delenv(k, raising=False)
+    blk = _baz().music_doa(4, 2, 16, tab, 8)
+    assert blk.output_multiple() == 64 and blk.min_output_buffer() == 512 and blk.max_noutput_items() == 0
+    monkeypatch.setenv("BAZ_MUSIC_OUTPUT_MULTIPLE", "256")
+    monkeypatch.setenv("BAZ_MUSIC_MAX_NOUTPUT", "4096")
+    blk = _baz().music_doa(4, 2, 16, tab, 8)
+    assert blk.output_multiple() == 256 and blk.min_output_buffer() == 2048 and blk.max_noutput_items() == 4096
+    monkeypatch.setenv("BAZ_MUSIC_OUTPUT_MULTIPLE", "1")
+    monkeypatch.setenv("BAZ_MUSIC_MIN_OUTPUT_BUFFER", "0")
+    monkeypatch.delenv("BAZ_MUSIC_MAX_NOUTPUT")
+    blk = _baz().music_doa(4, 2, 16, tab, 8)          # the reference's behaviour: no hints at all
+    assert blk.output_multiple() == 1 and blk.min_output_buffer() == -1 and blk.max_noutput_items() == 0
+
+
+@pytest.mark.gpu
 def test_helper_end_to_end_and_retune(gpu_device, capfd):
     """music_doa_helper -> baz.music_doa -> host block -> C-ABI -> HIP, incl. set_frequency
     (grc/baz_music_doa.xml:7-8)."""

@@ -177,6 +177,7 @@ def test_hip_short_input_produces_what_fits_and_device_path(gpu_device):
     with resamp.Resampler(0.5, 0.8, nstreams=2) as blk:
         xd = torch.from_numpy(np.stack([x, x[::-1].copy()]).view(np.float32)).to(gpu_device)
         od = torch.zeros(2, 2 * 1100, dtype=torch.float32, device=gpu_device)
+        torch.cuda.synchronize()                       # the engine runs on its own stream: fills first
         n, k = blk.process_device(xd.data_ptr(), 1000, 1000, od.data_ptr(), 1100, 1100)
         blk.sync()
         got = od.cpu().numpy().view(np.complex64)[:, :n]

@@ -22,6 +22,17 @@ def test_stream_deal_is_disjoint_and_complete():
     assert sharding.streams_of_rank(8, 1, 0) == list(range(8))
 
 
+def test_block_instances_are_dealt_like_streams():
+    """The host block's in-process placement (config 4 as one flowgraph of 64 music_doa blocks): instance i ->
+    device i mod G, the same rule as stream -> rank; -1 (current device) when no gfx950 device is visible."""
+    from gr_baz_amd import baz
+    for g in (1, 2, 4, 8):
+        placed = [baz.deal_device(i, g) for i in range(64)]
+        assert placed == [sharding.stream_owner(i, g) for i in range(64)]
+        assert all(placed.count(d) == 64 // g for d in range(g))
+    assert baz.deal_device(5, 0) == -1 and baz.deal_device(0, -3) == -1
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
