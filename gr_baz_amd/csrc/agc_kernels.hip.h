@@ -13,8 +13,8 @@
 //   agc_tile_kernel<2>  per tile: recompute the local recurrence from its carry-in, emit out / env / mul (planar), or
 //   agc_tile_kernel<1>  the same with the S streams of a tile written interleaved as MUSIC items (config 5)
 // Each lane runs 4 consecutive samples in registers (32 contiguous bytes per lane, 2 KiB per wave: coalesced without
-// an LDS transpose).  The result differs from the sequential loop only by fp64 re-association (~1e-15), far inside
-// the 1e-5 tolerance of the float32 outputs.
+// an LDS transpose).  Per sample the arithmetic is the reference's, operation for operation (agc_env_step & co.); only
+// a tile's ENTRY state carries the scan's fp64 re-association (~1e-15 relative), see the note at agc_mag().
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -27,6 +27,34 @@ struct AgcParams {
     double b;          // (double)rate
     double reference;
 };
+
+// The reference's per-sample expressions (.cc:74-100), operation for operation: every product and sum is rounded
+// on its own (the host compiler does not fuse them), so the device code must not contract them into FMAs either --
+// hipcc would (fp-contract=fast): these helpers switch contraction off.  With them a tile that starts from the
+// sequential loop's state reproduces its float32 outputs BIT FOR BIT; what remains is the tile's entry state, which
+// comes out of the re-associated scan a few ulp_f64 (~1e-15) away from the sequential value and flips the float32
+// rounding of about one output sample in 1e8 by one ulp (tests/lab/agc_exact.py; an exact parallel evaluation does
+// not exist: the rounded recurrence is not associative, and two states one ulp apart only coalesce after ~1/rate samples).
+// (ROCm's __dadd_rn / __dmul_rn are plain operators and get contracted like any other: the pragma is what holds.)
+__device__ __forceinline__ double agc_mag(const float2 x)
+{
+#pragma clang fp contract(off)
+    const double d0 = x.x, d1 = x.y;
+    const double p0 = d0 * d0, p1 = d1 * d1;
+    return __dsqrt_rn(p0 + p1);                                                // .cc:74-77
+}
+__device__ __forceinline__ double agc_env_step(const double e, const double mag, const double a, const double b)
+{
+#pragma clang fp contract(off)
+    const double p0 = e * a, p1 = mag * b;
+    return p0 + p1;                                                            // .cc:82
+}
+__device__ __forceinline__ float2 agc_apply(const float2 x, const double gain)
+{
+#pragma clang fp contract(off)
+    const double re = (double)x.x * gain, im = (double)x.y * gain;             // .cc:97-100
+    return make_float2((float)re, (float)im);
+}
 
 // (A2,S2) o (A1,S1): apply 1 first, then 2
 __device__ __forceinline__ void compose(double& A, double& S, const double A1, const double S1)
@@ -54,9 +82,7 @@ __global__ __launch_bounds__(AGC_CARRY_THREADS) void agc_carry_kernel(const floa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double e0;
     if (first) {
-        const float2 x0 = in[(size_t)stream * stride];
-        const double d0 = x0.x, d1 = x0.y;
-        e0 = sqrt(d0 * d0 + d1 * d1);
+        e0 = agc_mag(in[(size_t)stream * stride]);
     } else {
         e0 = env_state[stream];
     }
@@ -151,8 +177,7 @@ __global__ __launch_bounds__(1024) void agc_tile_kernel(const float2* __restrict
     double A = 1.0, S = 0.0;
 #pragma unroll
     for (int j = 0; j < AGC_IE; ++j) {
-        const double d0 = x[j].x, d1 = x[j].y;
-        mag[j] = sqrt(d0 * d0 + d1 * d1);                    // .cc:74-77
+        mag[j] = agc_mag(x[j]);                              // .cc:74-77
         if (j < cnt) { S = fma(P.a, S, P.b * mag[j]); A *= P.a; }
     }
     double Ai = A, Si = S;                                   // inclusive wave scan of the lane maps
@@ -175,9 +200,9 @@ __global__ __launch_bounds__(1024) void agc_tile_kernel(const float2* __restrict
         for (int j = 0; j < AGC_IE; ++j) {
             y[j] = make_float2(0.f, 0.f); ev[j] = 0.f; gv[j] = 0.f;
             if (j < cnt) {
-                e = (e * P.a) + (mag[j] * P.b);                   // .cc:82
-                const double gain = P.reference / e;              // .cc:89
-                y[j] = make_float2((float)((double)x[j].x * gain), (float)((double)x[j].y * gain));   // .cc:97-100
+                e = agc_env_step(e, mag[j], P.a, P.b);            // .cc:82
+                const double gain = __ddiv_rn(P.reference, e);    // .cc:89
+                y[j] = agc_apply(x[j], gain);                     // .cc:97-100
                 ev[j] = (float)e;                                 // .cc:85
                 gv[j] = (float)gain;                              // .cc:92
             }
@@ -214,9 +239,9 @@ __global__ __launch_bounds__(1024) void agc_tile_kernel(const float2* __restrict
 #pragma unroll
     for (int j = 0; j < AGC_IE; ++j) {
         if (j < cnt) {
-            e = (e * P.a) + (mag[j] * P.b);                   // .cc:82
-            const double gain = P.reference / e;              // .cc:89
-            row[i0 + j] = make_float2((float)((double)x[j].x * gain), (float)((double)x[j].y * gain));   // .cc:97-100
+            e = agc_env_step(e, mag[j], P.a, P.b);            // .cc:82
+            const double gain = __ddiv_rn(P.reference, e);    // .cc:89
+            row[i0 + j] = agc_apply(x[j], gain);              // .cc:97-100
         }
     }
     if (env_state && base + i0 + cnt == n && cnt > 0) env_state[stream] = e;

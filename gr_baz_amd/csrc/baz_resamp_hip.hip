@@ -30,6 +30,12 @@ struct baz_resamp_ctx {
     float* d_taps = nullptr;
     float *s_in = nullptr, *s_out = nullptr;    // host-path staging (device)
     size_t s_in_cap = 0, s_out_cap = 0;         // complex samples
+    // two-input branch (per-sample ratio input): phase table of the walk, its result, ratio staging
+    uint32_t *d_ii = nullptr, *d_imu = nullptr;
+    size_t walk_cap = 0;                        // outputs
+    WalkResult* d_walk = nullptr;
+    float* s_rr = nullptr;
+    size_t s_rr_cap = 0;                        // floats
     std::mutex mtx;
 };
 
@@ -151,6 +157,46 @@ int64_t process_device_locked(baz_resamp_ctx* c, const void* d_in, uint64_t in_s
     return (int64_t)n;
 }
 
+// One general_work() of the TWO-input branch on device buffers (.cc:205-217): walk + table kernels, then the host
+// reads the walk's result (the counts are data dependent), i.e. this call synchronises the stream.  The pending
+// set_mu / set_resamp_ratio / adjustment flags are left pending: the reference only looks at them in the one-input
+// branch (.cc:165-189).
+int64_t process2_device_locked(baz_resamp_ctx* c, const void* d_in, uint64_t in_stride, uint64_t ninput,
+                               const void* d_ratio, void* d_out, uint64_t out_stride, uint32_t noutput, uint64_t* consumed)
+{
+    if (consumed) *consumed = 0;
+    if (noutput == 0 || ninput < RS_NTAPS) return 0;
+    if (ninput > 0xFFFFFFFFull) return BAZ_RESAMP_E_UNSUPPORTED;    // the phase table holds 32-bit input indices
+    if ((c->mu >> 64) != 0) return BAZ_RESAMP_E_INVALID;            // d_mu is a fraction between calls
+    if (noutput > c->walk_cap) {
+        if (c->d_ii) (void)hipFree(c->d_ii);
+        if (c->d_imu) (void)hipFree(c->d_imu);
+        c->d_ii = c->d_imu = nullptr; c->walk_cap = 0;
+        RS_TRY(hipMalloc((void**)&c->d_ii, (size_t)noutput * 4));
+        RS_TRY(hipMalloc((void**)&c->d_imu, (size_t)noutput * 4));
+        c->walk_cap = noutput;
+    }
+    if (!c->d_walk) RS_TRY(hipMalloc((void**)&c->d_walk, sizeof(WalkResult)));
+    hipLaunchKernelGGL(resamp_walk_kernel, dim3(1), dim3(256), 0, c->stream, static_cast<const float*>(d_ratio), ninput,
+                       noutput, (uint64_t)c->mu, c->d_ii, c->d_imu, c->d_walk);
+    RS_TRY(hipGetLastError());
+    const dim3 grid((noutput + RS_BLOCK - 1) / RS_BLOCK, c->nstreams);
+    hipLaunchKernelGGL(resamp_table_kernel, grid, dim3(RS_BLOCK), 0, c->stream, static_cast<const float2*>(d_in), in_stride,
+                       static_cast<float2*>(d_out), out_stride, c->d_ii, c->d_imu, c->d_walk, c->d_taps);
+    RS_TRY(hipGetLastError());
+    WalkResult w;
+    RS_TRY(hipMemcpyAsync(&w, c->d_walk, sizeof(w), hipMemcpyDeviceToHost, c->stream));
+    RS_TRY(hipStreamSynchronize(c->stream));
+    c->mu = (u128)w.frac;
+    if (w.last_bits) {                                              // d_mu_inc = the last ratio sample read (.cc:207,215)
+        float r;
+        std::memcpy(&r, &w.last_bits, sizeof(r));
+        c->mu_inc = to_fixed((long double)r, &c->exact);
+    }
+    if (consumed) *consumed = w.ii;
+    return (int64_t)w.n;
+}
+
 int ensure_staging(baz_resamp_ctx* c, size_t nin, size_t nout)
 {
     if (nin > c->s_in_cap) {
@@ -220,6 +266,10 @@ void baz_resamp_destroy(baz_resamp_ctx* c)
         if (c->d_taps) (void)hipFree(c->d_taps);
         if (c->s_in) (void)hipFree(c->s_in);
         if (c->s_out) (void)hipFree(c->s_out);
+        if (c->d_ii) (void)hipFree(c->d_ii);
+        if (c->d_imu) (void)hipFree(c->d_imu);
+        if (c->d_walk) (void)hipFree(c->d_walk);
+        if (c->s_rr) (void)hipFree(c->s_rr);
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     }
     delete c;
@@ -257,6 +307,43 @@ int64_t baz_resamp_process(baz_resamp_ctx* c, const float* in_ri, uint64_t in_st
         RS_TRY(hipMemcpyAsync(c->s_in + (size_t)s * nin * 2, in_ri + (size_t)s * in_stride * 2, (size_t)nin * 8,
                               hipMemcpyHostToDevice, c->stream));
     const int64_t n = process_device_locked(c, c->s_in, nin, nin, c->s_out, noutput, noutput, consumed);
+    if (n < 0) return n;
+    for (uint32_t s = 0; s < c->nstreams && n > 0; ++s)
+        RS_TRY(hipMemcpyAsync(out_ri + (size_t)s * out_stride * 2, c->s_out + (size_t)s * noutput * 2, (size_t)n * 8,
+                              hipMemcpyDeviceToHost, c->stream));
+    RS_TRY(hipStreamSynchronize(c->stream));
+    return n;
+}
+
+int64_t baz_resamp_process2_device(baz_resamp_ctx* c, const void* d_in, uint64_t in_stride, uint64_t ninput,
+                                   const void* d_ratio, void* d_out, uint64_t out_stride, uint32_t noutput,
+                                   uint64_t* consumed)
+{
+    if (!c || !d_in || !d_ratio || !d_out || in_stride < ninput || out_stride < noutput) return BAZ_RESAMP_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    DeviceGuard guard(c->device);
+    return process2_device_locked(c, d_in, in_stride, ninput, d_ratio, d_out, out_stride, noutput, consumed);
+}
+
+int64_t baz_resamp_process2(baz_resamp_ctx* c, const float* in_ri, uint64_t in_stride, uint64_t ninput,
+                            const float* ratio, float* out_ri, uint64_t out_stride, uint32_t noutput, uint64_t* consumed)
+{
+    if (!c || !in_ri || !ratio || !out_ri || in_stride < ninput || out_stride < noutput) return BAZ_RESAMP_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    DeviceGuard guard(c->device);
+    int r = ensure_staging(c, (size_t)ninput * c->nstreams, (size_t)noutput * c->nstreams);
+    if (r) return r;
+    if (ninput > c->s_rr_cap) {
+        if (c->s_rr) (void)hipFree(c->s_rr);
+        c->s_rr = nullptr; c->s_rr_cap = 0;
+        RS_TRY(hipMalloc((void**)&c->s_rr, (size_t)ninput * 4));
+        c->s_rr_cap = ninput;
+    }
+    for (uint32_t s = 0; s < c->nstreams; ++s)
+        RS_TRY(hipMemcpyAsync(c->s_in + (size_t)s * ninput * 2, in_ri + (size_t)s * in_stride * 2, (size_t)ninput * 8,
+                              hipMemcpyHostToDevice, c->stream));
+    RS_TRY(hipMemcpyAsync(c->s_rr, ratio, (size_t)ninput * 4, hipMemcpyHostToDevice, c->stream));
+    const int64_t n = process2_device_locked(c, c->s_in, ninput, ninput, c->s_rr, c->s_out, noutput, noutput, consumed);
     if (n < 0) return n;
     for (uint32_t s = 0; s < c->nstreams && n > 0; ++s)
         RS_TRY(hipMemcpyAsync(out_ri + (size_t)s * out_stride * 2, c->s_out + (size_t)s * noutput * 2, (size_t)n * 8,

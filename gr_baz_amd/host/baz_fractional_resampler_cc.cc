@@ -1,8 +1,8 @@
 /* -*- c++ -*- */
 /* Host side of the MI355X fractional resampler: buffer marshalling across include/baz_resamp_hip.h.  Mirrors
  * /root/reference/lib/baz_fractional_resampler_cc.cc:73-101 (make, constructor: block name, ports, ratio rules,
- * banner, relative rate), :141-149 (forecast), :152-203 (general_work, one-input branch; the arithmetic runs in the
- * HIP kernel) and :220-254 (accessors, deferred setters). */
+ * banner, relative rate, "msg" port), :109-139 (handle_msg), :141-149 (forecast), :152-217 (general_work, both
+ * branches; the arithmetic runs in the HIP kernels) and :220-254 (accessors, deferred setters). */
 #include <baz_fractional_resampler_cc.h>
 #include <baz_resamp_hip.h>
 
@@ -21,7 +21,7 @@ class fractional_resampler_cc_impl : public fractional_resampler_cc
 
 public:
     fractional_resampler_cc_impl(double phase_shift, double resamp_ratio, unsigned long long num, unsigned long long denom)
-        : block("fractional_resampler_cc", io_signature::make(1, 1, sizeof(gr_complex)),
+        : block("fractional_resampler_cc", io_signature::make2(1, 2, sizeof(gr_complex), sizeof(float)),   /* .cc:84 */
                 io_signature::make(1, 1, sizeof(gr_complex))),
           d_ctx(NULL)
     {
@@ -32,6 +32,9 @@ public:
             throw std::runtime_error(std::string("fractional_resampler_cc: cannot open the gfx950 engine: ") +
                                      baz_resamp_strerror(rc));
         set_relative_rate(1.0 / baz_resamp_ratio(d_ctx));   /* .cc:99 */
+
+        message_port_register_in(pmt::mp("msg"));           /* .cc:101-102 */
+        set_msg_handler(pmt::mp("msg"), [this](pmt::pmt_t msg) { this->handle_msg(msg); });
     }
     ~fractional_resampler_cc_impl() { baz_resamp_destroy(d_ctx); }
 
@@ -46,10 +49,18 @@ public:
     {
         if (noutput_items <= 0) return 0;
         uint64_t consumed = 0;
-        const int64_t produced = baz_resamp_process(d_ctx, static_cast<const float*>(input_items[0]),
-                                                    (uint64_t)ninput_items[0], (uint64_t)ninput_items[0],
-                                                    static_cast<float*>(output_items[0]), (uint64_t)noutput_items,
-                                                    (uint32_t)noutput_items, &consumed);
+        int64_t produced;
+        if (ninput_items.size() == 1) {           /* .cc:162-203 */
+            produced = baz_resamp_process(d_ctx, static_cast<const float*>(input_items[0]),
+                                          (uint64_t)ninput_items[0], (uint64_t)ninput_items[0],
+                                          static_cast<float*>(output_items[0]), (uint64_t)noutput_items,
+                                          (uint32_t)noutput_items, &consumed);
+        } else {                                  /* .cc:205-217: the second input carries the ratio, per sample */
+            const uint64_t nin = (uint64_t)(ninput_items[0] < ninput_items[1] ? ninput_items[0] : ninput_items[1]);
+            produced = baz_resamp_process2(d_ctx, static_cast<const float*>(input_items[0]), nin, nin,
+                                           static_cast<const float*>(input_items[1]), static_cast<float*>(output_items[0]),
+                                           (uint64_t)noutput_items, (uint32_t)noutput_items, &consumed);
+        }
         if (produced < 0) {
             fprintf(stderr, "[%s<%li>] device error: %s\n", name().c_str(), unique_id(), baz_resamp_strerror((int)produced));
             return -1;
@@ -67,6 +78,24 @@ public:
     void set_resamp_ratio(unsigned long long num, unsigned long long denom) { check(baz_resamp_set_ratio_rational(d_ctx, num, denom)); }
     void handle_ppb(long whole, double frac) { check(baz_resamp_set_ratio_ppb(d_ctx, whole, frac)); }
     void handle_adjust(double d) { check(baz_resamp_adjust(d_ctx, d)); }
+
+    /* the "msg" port's handler, .cc:109-139: a pair (long . double) is a ratio in parts per billion, a bare number a
+     * one-off phase adjustment in units of the ratio; anything else (or a value the engine rejects) is reported and
+     * dropped, like the reference's catch (...) */
+    void handle_msg(pmt::pmt_t msg)
+    {
+        try {
+            if (pmt::is_pair(msg)) {
+                const long i = pmt::to_long(pmt::car(msg));
+                const double frac = pmt::to_double(pmt::cdr(msg));
+                handle_ppb(i, frac);
+            } else {
+                handle_adjust(pmt::to_double(msg));
+            }
+        } catch (...) {
+            fprintf(stderr, "Failed to handle PMT\n");
+        }
+    }
 
 private:
     static void check(int rc)

@@ -3,13 +3,14 @@
  * same class name, make() signature and accessors as /root/reference/lib/baz_fractional_resampler_cc.h:30-60
  * (make(phase_shift, resamp_ratio, resamp_ratio_num = 0, resamp_ratio_denom = 0); mu(), resamp_ratio(), set_mu(),
  * set_resamp_ratio() x3).  The phase state lives in a baz_resamp_ctx (include/baz_resamp_hip.h); no arithmetic here.
- * Differences, both deliberate: (1) one input only -- the optional per-sample ratio input (io_signature make2(1, 2),
- * .cc:84) is a data-dependent serial chain and is not offered; (2) the PMT "msg" port (.cc:99-100) needs the GNU Radio
- * runtime: on a real host add the two lines back and route them to handle_ppb()/handle_adjust() below. */
+ * Both input forms of the reference are served: one input (make2(1, 2, ...), .cc:84), or a second float input that
+ * carries the resampling ratio per sample (.cc:205-217; a serial chain on the device, offered for completeness), and
+ * the PMT "msg" port (.cc:101-102, handler .cc:109-139). */
 #ifndef INCLUDED_BAZ_FRACTIONAL_RESAMPLER_CC_H
 #define INCLUDED_BAZ_FRACTIONAL_RESAMPLER_CC_H
 
 #include <gnuradio/block.h>
+#include <pmt/pmt.h>
 
 #ifndef BAZ_API
 #define BAZ_API
@@ -32,9 +33,10 @@ public:
     virtual void set_resamp_ratio(long double resamp_ratio) = 0;
     virtual void set_resamp_ratio(double resamp_ratio) = 0;
     virtual void set_resamp_ratio(unsigned long long resamp_ratio_num, unsigned long long resamp_ratio_denom) = 0;
-    /* the two cases of the reference's "msg" handler (.cc:109-139) */
+    /* the two cases of the reference's "msg" handler (.cc:109-139), and the handler itself */
     virtual void handle_ppb(long whole, double frac) = 0;
     virtual void handle_adjust(double d) = 0;
+    virtual void handle_msg(pmt::pmt_t msg) = 0;
 };
 
 }  // namespace baz

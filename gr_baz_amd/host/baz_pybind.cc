@@ -75,6 +75,27 @@ struct resamp_handle {
 };
 
 // one general_work() call the way the scheduler issues it: forecast()-sized input window, consume_each() reported
+// the same with the second input wired: rr = the per-sample ratio stream (.cc:205-217)
+py::tuple drive_resamp2(resamp_handle& h, py::array_t<std::complex<float>, py::array::c_style | py::array::forcecast> x,
+                        py::array_t<float, py::array::c_style | py::array::forcecast> rr, int noutput)
+{
+    py::buffer_info bi = x.request(), br = rr.request();
+    gr_vector_int nin;
+    nin.push_back((int)bi.size);
+    nin.push_back((int)br.size);
+    py::array_t<std::complex<float>> out((size_t)(noutput > 0 ? noutput : 0));
+    gr_vector_const_void_star in;
+    in.push_back(bi.ptr);
+    in.push_back(br.ptr);
+    gr_vector_void_star outs(1, out.mutable_data());
+    int produced;
+    {
+        py::gil_scoped_release nogil;
+        produced = h.blk->general_work(noutput, nin, in, outs);
+    }
+    return py::make_tuple(produced, out, h.blk->last_consumed());
+}
+
 py::tuple drive_resamp(resamp_handle& h, py::array_t<std::complex<float>, py::array::c_style | py::array::forcecast> x, int noutput)
 {
     py::buffer_info bi = x.request();
@@ -142,7 +163,18 @@ PYBIND11_MODULE(_baz_music, mod)
         .def("set_resamp_ratio", [](resamp_handle& h, unsigned long long n, unsigned long long d) { h.blk->set_resamp_ratio(n, d); })
         .def("handle_ppb", [](resamp_handle& h, long w, double f) { h.blk->handle_ppb(w, f); })
         .def("handle_adjust", [](resamp_handle& h, double d) { h.blk->handle_adjust(d); })
-        .def("general_work", &drive_resamp, py::arg("items"), py::arg("noutput_items"));
+        .def("general_work", &drive_resamp, py::arg("items"), py::arg("noutput_items"))
+        .def("general_work2", &drive_resamp2, py::arg("items"), py::arg("ratio"), py::arg("noutput_items"))
+        .def("input_streams", [](resamp_handle& h) {
+            return py::make_tuple(h.blk->input_signature()->min_streams(), h.blk->input_signature()->max_streams());
+        })
+        .def("has_msg_port", [](resamp_handle& h, const std::string& p) { return h.blk->has_msg_port(p); })
+        /* what a flowgraph's message source would deliver to the "msg" port: (whole . frac) ppb pair, or a double */
+        .def("post_msg_ppb", [](resamp_handle& h, long whole, double frac) {
+            h.blk->shim_post(pmt::mp("msg"), pmt::cons(pmt::from_long(whole), pmt::from_double(frac)));
+        })
+        .def("post_msg_double", [](resamp_handle& h, double d) { h.blk->shim_post(pmt::mp("msg"), pmt::from_double(d)); })
+        .def("post_msg_symbol", [](resamp_handle& h, const std::string& s) { h.blk->shim_post(pmt::mp("msg"), pmt::mp(s)); });
     // swig/baz_swig.i:964-966: GR_SWIG_BLOCK_MAGIC2(baz, fractional_resampler_cc) -> baz.fractional_resampler_cc(...)
     mod.def("fractional_resampler_cc",
             [](double phase_shift, double resamp_ratio, unsigned long long num, unsigned long long denom) {

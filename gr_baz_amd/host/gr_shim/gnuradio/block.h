@@ -1,11 +1,15 @@
 /* GNU Radio 3.7 API stand-in: the gr::block surface the fractional-resampler host block touches
- * (general_work / forecast / consume_each / set_relative_rate).  Used ONLY where GNU Radio is not installed. */
+ * (general_work / forecast / consume_each / set_relative_rate, message_port_register_in / set_msg_handler).  Used ONLY where GNU Radio is not installed. */
 #ifndef GR_BAZ_AMD_SHIM_BLOCK_H
 #define GR_BAZ_AMD_SHIM_BLOCK_H
 
 #include <gnuradio/io_signature.h>
 #include <gnuradio/types.h>
+#include <pmt/pmt.h>
 
+#include <functional>
+#include <map>
+#include <stdexcept>
 #include <string>
 
 namespace gr {
@@ -28,6 +32,23 @@ public:
     /* shim only: what the last general_work() passed to consume_each() (the real runtime advances the read pointers) */
     int last_consumed() const { return d_consumed; }
 
+    /* message ports (basic_block in the real runtime): registration and handler table */
+    void message_port_register_in(pmt::pmt_t port_id) { d_msg_handlers[pmt::symbol_to_string(port_id)]; }
+    template <class F> void set_msg_handler(pmt::pmt_t which_port, F handler)
+    {
+        const std::string port = pmt::symbol_to_string(which_port);
+        if (!d_msg_handlers.count(port)) throw std::runtime_error("set_msg_handler: port not registered: " + port);
+        d_msg_handlers[port] = handler;
+    }
+    bool has_msg_port(const std::string& port) const { return d_msg_handlers.count(port) != 0; }
+    /* shim only: deliver one message now (the real scheduler runs the handler between two general_work() calls) */
+    void shim_post(pmt::pmt_t which_port, pmt::pmt_t msg)
+    {
+        std::map<std::string, std::function<void(pmt::pmt_t)> >::iterator it = d_msg_handlers.find(pmt::symbol_to_string(which_port));
+        if (it == d_msg_handlers.end() || !it->second) throw std::runtime_error("shim_post: no handler on that port");
+        it->second(msg);
+    }
+
 protected:
     block() : d_unique_id(-1), d_consumed(0), d_relative_rate(1.0) {}
     block(const std::string& name, io_signature::sptr input_signature, io_signature::sptr output_signature)
@@ -47,6 +68,7 @@ private:
     long d_unique_id;
     int d_consumed;
     double d_relative_rate;
+    std::map<std::string, std::function<void(pmt::pmt_t)> > d_msg_handlers;
 };
 
 }  // namespace gr

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbaz_resamp_hip.so")
 
 SYMBOLS = ["baz_resamp_create", "baz_resamp_destroy", "baz_resamp_forecast", "baz_resamp_process",
-           "baz_resamp_process_device", "baz_resamp_set_mu", "baz_resamp_set_ratio", "baz_resamp_set_ratio_rational",
+           "baz_resamp_process_device", "baz_resamp_process2", "baz_resamp_process2_device", "baz_resamp_set_mu", "baz_resamp_set_ratio", "baz_resamp_set_ratio_rational",
            "baz_resamp_set_ratio_ppb", "baz_resamp_adjust", "baz_resamp_mu", "baz_resamp_ratio",
            "baz_resamp_phase_exact", "baz_resamp_taps", "baz_resamp_set_stream", "baz_resamp_sync",
            "baz_resamp_strerror"]
@@ -46,6 +46,10 @@ def lib():
     L.baz_resamp_process.argtypes = [_vp, _f32p, _u64, _u64, _f32p, _u64, ctypes.c_uint32, ctypes.POINTER(_u64)]
     L.baz_resamp_process_device.restype = ctypes.c_int64
     L.baz_resamp_process_device.argtypes = [_vp, _vp, _u64, _u64, _vp, _u64, ctypes.c_uint32, ctypes.POINTER(_u64)]
+    L.baz_resamp_process2.restype = ctypes.c_int64
+    L.baz_resamp_process2.argtypes = [_vp, _f32p, _u64, _u64, _f32p, _f32p, _u64, ctypes.c_uint32, ctypes.POINTER(_u64)]
+    L.baz_resamp_process2_device.restype = ctypes.c_int64
+    L.baz_resamp_process2_device.argtypes = [_vp, _vp, _u64, _u64, _vp, _vp, _u64, ctypes.c_uint32, ctypes.POINTER(_u64)]
     for nm in ("set_mu", "set_ratio", "adjust"):
         f = getattr(L, "baz_resamp_" + nm)
         f.restype = ctypes.c_int
@@ -100,8 +104,9 @@ class Resampler:
     def forecast(self, noutput):
         return int(lib().baz_resamp_forecast(self._h, noutput))
 
-    def work(self, x, noutput):
-        """x: (n,) or (nstreams, n) complex64 host window -> (out[..., produced], consumed); state carries over."""
+    def work(self, x, noutput, rr=None):
+        """x: (n,) or (nstreams, n) complex64 host window -> (out[..., produced], consumed); state carries over.
+        rr: optional (n,) float32 per-sample ratio input = the block's second input port (.cc:205-217)."""
         x = np.ascontiguousarray(x, dtype=np.complex64)
         one = x.ndim == 1
         if one:
@@ -111,8 +116,15 @@ class Resampler:
         n = x.shape[1]
         out = np.zeros((self.nstreams, noutput), np.complex64)
         consumed = _u64(0)
-        r = lib().baz_resamp_process(self._h, x.view(np.float32).ctypes.data_as(_f32p), n, n,
-                                     out.view(np.float32).ctypes.data_as(_f32p), noutput, noutput, ctypes.byref(consumed))
+        if rr is None:
+            r = lib().baz_resamp_process(self._h, x.view(np.float32).ctypes.data_as(_f32p), n, n,
+                                         out.view(np.float32).ctypes.data_as(_f32p), noutput, noutput, ctypes.byref(consumed))
+        else:
+            rr = np.ascontiguousarray(rr, dtype=np.float32)
+            if rr.shape != (n,):
+                raise ValueError("the ratio input needs one float per input sample")
+            r = lib().baz_resamp_process2(self._h, x.view(np.float32).ctypes.data_as(_f32p), n, n, rr.ctypes.data_as(_f32p),
+                                          out.view(np.float32).ctypes.data_as(_f32p), noutput, noutput, ctypes.byref(consumed))
         if r < 0:
             raise ResampError(r, "baz_resamp_process")
         out = out[:, :r]
@@ -124,6 +136,15 @@ class Resampler:
                                             ctypes.byref(consumed))
         if r < 0:
             raise ResampError(r, "baz_resamp_process_device")
+        return int(r), int(consumed.value)
+
+    def process2_device(self, d_in, in_stride, ninput, d_ratio, d_out, out_stride, noutput):
+        """Two-input branch on device buffers (synchronises the stream: the counts depend on the data)."""
+        consumed = _u64(0)
+        r = lib().baz_resamp_process2_device(self._h, _vp(d_in), in_stride, ninput, _vp(d_ratio), _vp(d_out), out_stride,
+                                             noutput, ctypes.byref(consumed))
+        if r < 0:
+            raise ResampError(r, "baz_resamp_process2_device")
         return int(r), int(consumed.value)
 
     def _chk(self, r, where):

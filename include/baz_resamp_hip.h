@@ -20,8 +20,9 @@
  * ratio >= 2^-11; for num/denom ratios (64-bit quotient) the two differ by < o * 2^-64 in mu, which moves imu only
  * when mu*128 sits within that distance of a rounding boundary.
  *
- * NOT provided: the two-input branch (.cc:205-217, per-sample ratio input): ii_{o+1} depends on the ratio sample read
- * at ii_o, a data-dependent serial chain; contexts are created with one input only.
+ * The two-input branch (.cc:205-217, per-sample ratio input) is served by baz_resamp_process2*: ii_{o+1} depends on
+ * the ratio sample read at ii_o, a data-dependent serial chain that one lane walks (see resamp_walk_kernel) -- offered
+ * for completeness of the block's surface, not for throughput.
  * Plain C types, no exceptions; 0 == OK, negative == error (codes shared with baz_music_hip.h).
  */
 #ifndef INCLUDED_BAZ_RESAMP_HIP_H
@@ -68,6 +69,19 @@ BAZ_RESAMP_API int64_t baz_resamp_process(baz_resamp_ctx* ctx, const float* in_r
 BAZ_RESAMP_API int64_t baz_resamp_process_device(baz_resamp_ctx* ctx, const void* d_in, uint64_t in_stride,
                                                  uint64_t ninput, void* d_out, uint64_t out_stride, uint32_t noutput,
                                                  uint64_t* consumed);
+
+/* The two-input branch of general_work() (.cc:205-217): `ratio` is the second input port, one float per INPUT sample
+ * (at least ninput of them), shared by the nstreams lock-stepped streams; after output o the ratio sample at the
+ * current input index becomes d_mu_inc.  Same return / *consumed convention; production also stops -- like at the end
+ * of the input -- at a ratio sample that is not a finite number in [2^-11, 2^31].  The pending set_mu / set_ratio /
+ * adjustment requests stay pending (the reference only honours them in the one-input branch).  The device form
+ * synchronises the context's stream before returning (the counts depend on the data). */
+BAZ_RESAMP_API int64_t baz_resamp_process2(baz_resamp_ctx* ctx, const float* in_ri, uint64_t in_stride, uint64_t ninput,
+                                           const float* ratio, float* out_ri, uint64_t out_stride, uint32_t noutput,
+                                           uint64_t* consumed);
+BAZ_RESAMP_API int64_t baz_resamp_process2_device(baz_resamp_ctx* ctx, const void* d_in, uint64_t in_stride,
+                                                  uint64_t ninput, const void* d_ratio, void* d_out,
+                                                  uint64_t out_stride, uint32_t noutput, uint64_t* consumed);
 
 /* Deferred setters with the reference's ordering (.cc:165-189): a new mu applies to the first output of the next
  * call, a new ratio from the first phase step of the next call on, the adjustment is added to that step once. */

@@ -91,8 +91,14 @@ def test_hip_agc_matches_golden(name, gpu_device):
         out, env, mul = run_calls(blk, g["x"], g["calls"])
         assert blk.count == int(g["calls"].sum())
     assert close(env, g["env"]) and close(mul, g["mul"]) and close(out, g["out"])
-    # in practice the float32 outputs are identical or 1 ulp apart
-    assert np.mean(env == g["env"]) > 0.99
+    # The per-sample arithmetic is the reference's operation for operation; only a tile's entry state comes out of the
+    # re-associated scan (a few ulp_f64 off): float32 outputs are the sequential loop's bit for bit, except a 1-ulp flip
+    # in < 1e-5 of the samples (measured 8e-7 at rate 1e-4, 6e-8 at 1e-3: profiles/r02_agc_exactness.txt)
+    for got, ref in ((np.ascontiguousarray(out).view(np.float32), np.ascontiguousarray(g["out"]).view(np.float32)),
+                     (env, g["env"]), (mul, g["mul"])):
+        fin = np.isfinite(ref)
+        u = np.abs(np.ascontiguousarray(got).view(np.int32).astype(np.int64) - np.ascontiguousarray(ref).view(np.int32).astype(np.int64))[fin]
+        assert u.size == 0 or (u.max() <= 1 and np.count_nonzero(u) <= max(1, 1e-5 * u.size))
 
 
 @pytest.mark.gpu

@@ -94,14 +94,16 @@ def test_config5_frontend_fused_ahead_of_music(gpu_device):
         for eng in (R, A, M):
             eng.set_stream(None)
     got_items = d_items.cpu().numpy().view(np.complex64)
-    # front-end stage: the items entering MUSIC equal the oracle chain's (resampler bit-exact, AGC <= 1-2 ulp)
-    assert np.all(np.abs(got_items - o_items) <= 1e-5 * np.abs(o_items).max())
-    # MUSIC stage on exactly the items the device produced (1-ulp input differences are amplified ~1/d near a peak,
-    # so the two stages are pinned separately rather than through each other)
+    # front-end stage: the items entering MUSIC are the oracle chain's float32 values -- the resampler bit for bit,
+    # the AGC too except where the scan's entry state (a few ulp_f64 from the sequential loop's) flips a rounding:
+    # never more than 1 ulp_f32, in < 1e-5 of the samples (measured: 0 here, 8e-7 of them at rate 1e-4 over 2M
+    # samples per stream, profiles/r02_agc_exactness.txt)
+    u = np.abs(got_items.view(np.int32).astype(np.int64) - o_items.view(np.int32).astype(np.int64))
+    assert u.max() <= 1 and np.count_nonzero(u) <= 1e-5 * u.size
+    # MUSIC stage on exactly the items the device produced
     a2, l2, s2 = mr.work_batch(got_items, table, m, n)
     assert_spectrum_close(spec.cpu().numpy(), s2)
     assert_doa_match(ang.cpu().numpy(), lvl.cpu().numpy(), a2, l2, res, s2.astype(np.float64))
-    # end to end: same DoA bins as the all-oracle chain (or a neighbouring bin of the same lobe)
-    db = np.abs(np.round(ang.cpu().numpy() * res / 360.0) - np.round(ao * res / 360.0))
-    assert np.all(np.minimum(db, res - db) <= 1)
-    assert np.all(np.abs(spec.cpu().numpy() - so) <= 5e-3 * so)
+    # END TO END against the all-oracle chain (one oracle resampler + AGC per antenna, oracle MUSIC) at north_star's 1e-5
+    assert_spectrum_close(spec.cpu().numpy(), so)
+    assert_doa_match(ang.cpu().numpy(), lvl.cpu().numpy(), ao, lo, res, st)
