@@ -603,7 +603,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     // lib/baz_music_doa.cc:45-50 (asserts, compiled out in Release) made real; n == m underflows .cc:93
     if (m == 0 || n == 0 || n >= m || nsamples == 0 || (nsamples % m) != 0 || resolution == 0 || !table_ri)
         return BAZ_MUSIC_E_INVALID;
-    if (m > BAZ_MUSIC_MAX_M || n > BAZ_MUSIC_MAX_N) return BAZ_MUSIC_E_UNSUPPORTED;
+    if (m > BAZ_MUSIC_MAX_M || n > BAZ_MUSIC_MAX_N) return BAZ_MUSIC_E_UNSUPPORTED;   // see baz_music_strerror()
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BAZ_MUSIC_E_NODEVICE;
@@ -789,7 +789,11 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
     const size_t per_item = (size_t)c->nsamples * 8 + (size_t)c->res * 4 + (size_t)c->n * 8;
     size_t chunk_bytes = c->chunk_bytes;
     if (!chunk_bytes) chunk_bytes = (is_pinned_host(in_ri) && (!spectrum || is_pinned_host(spectrum))) ? (32u << 20) : (64u << 20);
-    const uint32_t chunk = (uint32_t)std::min<size_t>(batch, std::max<size_t>(64, chunk_bytes / per_item));
+    // ... but a call is always cut into >= 4 chunks (of >= 64 items) so that the three stages overlap inside ONE work()
+    // call too: a 4,096-item cfg2 call used to be 1.4 chunks, i.e. copy-in, kernels and copy-out back to back.
+    const size_t by_bytes = std::max<size_t>(64, chunk_bytes / per_item);
+    const size_t by_count = std::max<size_t>(64, ((size_t)batch + 3) / 4);
+    const uint32_t chunk = (uint32_t)std::min<size_t>(batch, c->chunk_bytes ? by_bytes : std::min(by_bytes, by_count));
     const bool want_spec = spectrum != nullptr;
     int r = ensure_slots(c, chunk, want_spec);
     if (r) return r;
@@ -916,7 +920,9 @@ const char* baz_music_strerror(int code)
         case BAZ_MUSIC_E_INVALID: return "invalid argument";
         case BAZ_MUSIC_E_NOMEM: return "out of memory";
         case BAZ_MUSIC_E_HIP: return "HIP runtime error";
-        case BAZ_MUSIC_E_UNSUPPORTED: return "configuration not supported by the gfx950 kernels";
+        case BAZ_MUSIC_E_UNSUPPORTED:
+            return "configuration not supported by the gfx950 kernels (limits: m <= 16 antennas, n <= 15 emitters, "
+                   "resolution <= 1048576 bins; the reference itself has none, lib/baz_music_doa.cc:45-50)";
         case BAZ_MUSIC_E_NODEVICE: return "no usable gfx950 device";
         default: return "unknown error";
     }
