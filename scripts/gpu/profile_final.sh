@@ -7,11 +7,11 @@ TAG=${1:-r02z}; HEAD=${2:-unknown}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-extras"
-rocprofv3 --kernel-trace --stats -d $O/stats -o bench -- $B --steps 20 --warmup 3 > $O/stats_bench_line.json 2> $O/stats_err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $B --steps 20 --warmup 3 > $O/stats_bench_line.json 2> $O/stats_err.txt
 PM="--steps 3 --warmup 1 --ramp-seconds 0 --min-seconds 0"
-rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE -d $O/pmc_write -o bench -- $B $PM > /dev/null 2> $O/pmc_write_err.txt
-rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $O/pmc_fetch -o bench -- $B $PM > /dev/null 2> $O/pmc_fetch_err.txt
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_MFMA -d $O/pmc_sq -o bench -- $B $PM > /dev/null 2> $O/pmc_sq_err.txt
+rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_write -o bench -- $B $PM > /dev/null 2> $O/pmc_write_err.txt
+rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_fetch -o bench -- $B $PM > /dev/null 2> $O/pmc_fetch_err.txt
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $O/pmc_sq -o bench -- $B $PM > /dev/null 2> $O/pmc_sq_err.txt
 cd $R
 W=$(find $O/pmc_write -name '*counter_collection.csv' | head -1); F=$(find $O/pmc_fetch -name '*counter_collection.csv' | head -1); S=$(find $O/pmc_sq -name '*counter_collection.csv' | head -1)
 K=$(find $O/stats -name '*kernel_stats.csv' | head -1)
