@@ -293,6 +293,14 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MUSIC-DoA path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if world > ndev:
+        if os.environ.get("BAZ_BENCH_SHARE_DEVICES") != "1":
+            raise SystemExit("%d ranks but only %d GPU(s) visible (one process per GPU)" % (world, ndev))
+        # test hook: several ranks on one GPU (exercises the N > 1 code path on a 1-GPU box); EVERY rank switches the
+        # barrier / clock backend, RCCL cannot put two ranks on one device
+        local_rank %= ndev
+        os.environ["BAZ_BENCH_BACKEND"] = "gloo"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     active = sharding.init_process_group(use_gpu=True, local_rank=local_rank)
