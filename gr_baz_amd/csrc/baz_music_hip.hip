@@ -76,7 +76,7 @@ struct baz_music_ctx {
     double refine_below = 0.0;     // threshold on d = a^H Q a
     int refine_off = 0;            // lab (BAZ_MUSIC_NO_REFINE=1): projector form everywhere
     int lab_cov_old = 0;           // lab (BAZ_MUSIC_COV_OLD=1): the round-1 covariance kernel at m = 4
-    uint32_t cov4_resident_blocks = 256u * 6u;   // blocks of cov4_x4_kernel the device holds at once
+    uint32_t cov4_resident_blocks = 256u;        // grid of cov4_x4_kernel (persistent waves): one workgroup per CU
     int peak_mode = 0;      // 0: the reference's n strongest bins; 1 (opt-in extension): n strongest local maxima
     float* dPeakSpec = nullptr;   // internal spectrum when peak mode runs without the spectrum port
     size_t peak_spec_cap = 0;     // floats
@@ -250,7 +250,7 @@ int launch_cov_t(baz_music_ctx* c, const float* d_in, uint32_t batch, double2* d
 {
     if constexpr (M == 4) {
         if ((c->K % 256u) == 0 && !c->lab_cov_old) {   // dwordx4 stream + LDS transpose + 4x4x4 MFMA blocks
-            // persistent waves: exactly the blocks that are resident at once (no tail wave of blocks)
+            // persistent waves, one workgroup per CU (see baz_music_create)
             const uint32_t blocks = std::min<uint32_t>((batch + 3) / 4, c->cov4_resident_blocks);
             hipLaunchKernelGGL(cov4_x4_kernel, dim3(blocks), dim3(256), 0, c->stream, d_in, dR, batch, c->K);
             HIP_TRY(c, hipGetLastError());
@@ -647,10 +647,12 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (hipMalloc((void**)&c->dFB, (size_t)(c->fb_steps + 2) * c->fb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         if (hipMalloc((void**)&c->dTB, (size_t)(c->fb_steps + 2) * c->tb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         {
-            int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cov4_x4_kernel, 256, 0) == hipSuccess && per_cu > 0)
-                c->cov4_resident_blocks = (uint32_t)per_cu * (uint32_t)std::max(1, prop.multiProcessorCount);
-            else (void)hipGetLastError();
+            // ONE workgroup per CU (4 persistent waves, 8 KiB in flight each = 8 MB chip-wide): measured against 2 / 3 / 4 /
+            // 6 (the occupancy limit) / 8 per CU, the fewest concurrent input streams read fastest -- 0.370 vs 0.396 ms per
+            // 262,144 items inside the pipeline (profiles/r02_cov_grid.txt); more waves only queue more requests.
+            c->cov4_resident_blocks = (uint32_t)std::max(1, prop.multiProcessorCount);
+            if (const char* v = getenv("BAZ_MUSIC_COV_BLOCKS_PER_CU"))    // lab: grid of the covariance kernel
+                if (atoi(v) > 0) c->cov4_resident_blocks = (uint32_t)atoi(v) * (uint32_t)std::max(1, prop.multiProcessorCount);
         }
         if (hipMalloc((void**)&c->dRefined, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         if (hipMemset(c->dRefined, 0, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void cov_mfma2_kernel(const float* __restrict_
 //     scripts/ubench_hbm.hip: 5.5-6.0 TB/s for dword streams against 7.0 TB/s for dwordx4; cov_mfma_kernel<4> itself
 //     4.9-5.5 TB/s), and the 16x16x4 tiles spend half their flops on the zero blocks between the two items they hold.
 //     Here a wave streams ONE item at a time with global_load_dwordx4 (1 KiB = 32 time columns per instruction, 8
-//     instructions = 8 KiB always in flight per wave), and the MFMA operand layout -- one matrix row per lane, which a
+//     instructions = 8 KiB always in flight per wave; ONE workgroup per CU, see baz_music_create), and the MFMA operand layout -- one matrix row per lane, which a
 //     16-B load of 4 consecutive rows cannot supply -- is produced by a per-wave LDS transpose:
 //         lane l of a chunk holds rows 4(l&1)..+3 of column l>>1  ->  widened (exactly) to fp64  ->  T[row][col] in LDS
 //         operand P: lane (i = l&3, h = (l>>2)&1, w = (l>>3)&1, k = l>>4) reads T[4h+i][8k+4w .. +3]   (4 MFMA steps)
@@ -244,7 +244,10 @@ __global__ __launch_bounds__(256) void cov_mfma2_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void cov4_x4_kernel(const float* __restrict__ in, double2* __restrict__ R,
                                                       uint32_t batch, uint32_t K)
 {
-    constexpr int RSD = 36;                       // row stride of the transposed chunk, doubles (8-row x 32-col chunk)
+    // Row stride of the transposed chunk (8 rows x 32 columns of doubles).  34: the 16-B operand reads below then
+    // start at 4-bank slot (17*row + 4k + 2w) mod 16 -- 4 lanes per slot, the minimum for a 1-KiB wave read (36 puts
+    // 8 lanes on each of 8 slots).  Measured: no difference (0.396 ms either way); the LDS is not what bounds this kernel.
+    constexpr int RSD = 34;
     __shared__ double stage[4][2][8 * RSD];       // per wave, double-buffered
     __shared__ double gram[4][2][64];             // per wave: D1, D2
     const int lane = threadIdx.x & 63;

@@ -53,14 +53,17 @@ VARIANTS = {0: ("shipped: gated, row classes, sc0 sc1 nt", {}),
             4: ("nt stores", {"BAZ_MUSIC_SCAN_VARIANT": "4"}),
             5: ("sc0 sc1 stores", {"BAZ_MUSIC_SCAN_VARIANT": "5"}),
             6: ("no literal refinement", {"BAZ_MUSIC_NO_REFINE": "1"}),
-            7: ("round-1 covariance kernel (dword loads, 16x16x4)", {"BAZ_MUSIC_COV_OLD": "1"})}
+            7: ("round-1 covariance kernel (dword loads, 16x16x4)", {"BAZ_MUSIC_COV_OLD": "1"}),
+            9: ("covariance grid 1 block per CU", {"BAZ_MUSIC_COV_BLOCKS_PER_CU": "1"}),
+            10: ("covariance grid 2 blocks per CU", {"BAZ_MUSIC_COV_BLOCKS_PER_CU": "2"}),
+            11: ("covariance grid 6 blocks per CU", {"BAZ_MUSIC_COV_BLOCKS_PER_CU": "6"})}
 ORDER = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1,2,3,4,5,6,7".split(","))]
 
 
 def run(x, label):
     out = {}
     for v in ORDER:
-        for k in ("BAZ_MUSIC_SCAN_VARIANT", "BAZ_MUSIC_NO_ROWCLASS", "BAZ_MUSIC_NO_REFINE", "BAZ_MUSIC_COV_OLD"):
+        for k in ("BAZ_MUSIC_SCAN_VARIANT", "BAZ_MUSIC_NO_ROWCLASS", "BAZ_MUSIC_NO_REFINE", "BAZ_MUSIC_COV_OLD", "BAZ_MUSIC_COV_BLOCKS_PER_CU"):
             os.environ.pop(k, None)
         os.environ.update(VARIANTS[v][1])
         ctx = capi.Context(M, NE, N, RES, table)
