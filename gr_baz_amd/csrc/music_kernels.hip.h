@@ -1087,14 +1087,18 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
     const int wave4 = wave & 3;             // 256-thread blocks: lets the compiler fold `chunk < chunks-per-phase`
     v2f64 sreg0 = {0, 0}, sreg1 = {0, 0}, sreg2 = {0, 0}, sreg3 = {0, 0};
     static_assert(SPW <= 4, "a wave stages at most 4 chunks per phase");
+    // (lab: ABL & 128 skips the table loads altogether, ABL & 256 issues them non-temporal)
+#define BAZ_FB_LD(IDX) ((ABL & 256) ? __builtin_nontemporal_load(fb + (IDX)) : fb[(IDX)])
 #define BAZ_STAGE_LOAD(ST, P)                                                                    \
     do {   /* unconditional loads, index clamped into the phase */                               \
+        if constexpr (!(ABL & 128)) {                                                            \
         const int nch__ = 2 * ((KS - (P) * SCH < SCH) ? (KS - (P) * SCH) : SCH);                 \
         const size_t ch0__ = ((size_t)(ST) * KS + (size_t)(P) * SCH) * 2;                        \
-        sreg0 = fb[(ch0__ + (wave4 < nch__ ? wave4 : nch__ - 1)) * 64];                          \
-        if constexpr (SPW > 1) sreg1 = fb[(ch0__ + (wave4 + 4 < nch__ ? wave4 + 4 : nch__ - 1)) * 64];   \
-        if constexpr (SPW > 2) sreg2 = fb[(ch0__ + (wave4 + 8 < nch__ ? wave4 + 8 : nch__ - 1)) * 64];   \
-        if constexpr (SPW > 3) sreg3 = fb[(ch0__ + (wave4 + 12 < nch__ ? wave4 + 12 : nch__ - 1)) * 64]; \
+        sreg0 = BAZ_FB_LD((ch0__ + (wave4 < nch__ ? wave4 : nch__ - 1)) * 64);                   \
+        if constexpr (SPW > 1) sreg1 = BAZ_FB_LD((ch0__ + (wave4 + 4 < nch__ ? wave4 + 4 : nch__ - 1)) * 64);   \
+        if constexpr (SPW > 2) sreg2 = BAZ_FB_LD((ch0__ + (wave4 + 8 < nch__ ? wave4 + 8 : nch__ - 1)) * 64);   \
+        if constexpr (SPW > 3) sreg3 = BAZ_FB_LD((ch0__ + (wave4 + 12 < nch__ ? wave4 + 12 : nch__ - 1)) * 64); \
+        }                                                                                        \
     } while (0)
 #define BAZ_STAGE_STORE(BUF, P)                                                                  \
     do {                                                                                         \
@@ -1306,6 +1310,7 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
 }
 
 #undef BAZ_STAGE_LOAD
+#undef BAZ_FB_LD
 #undef BAZ_STAGE_STORE
 
 // Final top-n over the per-range candidate keys (one thread per item), ang / lvl outputs

@@ -55,22 +55,15 @@ int main()
     Args a{dQ, dFB + (size_t)2 * KS * 64, spec, cand, batch, res, nsteps};
 #define R(ABL, AUX, name) run<ABL, AUX>(name, a, 2, 4)
     R(0, 19, "full, sc0 sc1 nt");
-    R(0, 2, "full, nt");
-    R(0, 0, "full, plain");
-    R(1, 19, "no stores");
-    R(2, 19, "no top-n, sc0 sc1 nt");
-    R(2, 0, "no top-n, plain");
-    R(64, 19, "ungated top-n, sc0 sc1 nt");
-    R(8, 19, "no MFMA (VALU fma stand-in), sc0 sc1 nt");
-    R(8 | 2, 19, "no MFMA, no top-n, sc0 sc1 nt");
-    R(8 | 2, 0, "no MFMA, no top-n, plain");
+    R(0, 0, "full, plain stores");
+    R(256, 0, "full, plain stores, table loads nt");
+    R(256, 19, "full, sc0 sc1 nt stores, table loads nt");
     R(8 | 2 | 4, 19, "stores + staging + barriers only, sc0 sc1 nt");
-    R(8 | 2 | 4, 2, "stores + staging + barriers only, nt");
     R(8 | 2 | 4, 0, "stores + staging + barriers only, plain");
-    R(1 | 2 | 4, 19, "MFMA + staging only");
-    run<0, 19>("full, sc0 sc1 nt, no row classes", a, 2, 1);
-    run<8 | 2 | 4, 19>("stores + staging only, sc0 sc1 nt, no row classes", a, 2, 1);
-    run<0, 19>("full, sc0 sc1 nt, nsplit 1", a, 1, 4);
-    run<0, 19>("full, sc0 sc1 nt, nsplit 4", a, 4, 4);
+    R(8 | 2 | 4 | 128, 0, "stores + barriers only (no table loads), plain");
+    R(8 | 2 | 4 | 128, 19, "stores + barriers only (no table loads), sc0 sc1 nt");
+    R(8 | 2 | 4 | 256, 0, "stores + staging (nt loads) + barriers, plain");
+    R(2 | 256, 0, "no top-n, plain stores, table loads nt");
+    R(2, 19, "no top-n, sc0 sc1 nt");
     return 0;
 }

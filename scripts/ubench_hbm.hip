@@ -87,6 +87,42 @@ __global__ __launch_bounds__(256) void write_rows(char* __restrict__ base, uint3
     }
 }
 
+// the scan's ROW-CLASS pattern (round 2): block = 4 waves x 16 rows of ONE class (rows nclass apart), every store a
+// 256-B aligned window [256*st - 4*sh, +256) of its row (res = 3600 floats, nclass = 4, sh = 16*class floats)
+template <int POLICY, bool BUFFER>
+__global__ __launch_bounds__(256) void write_rows_class(char* __restrict__ base, uint32_t rows, uint32_t nsplit, uint32_t spin)
+{
+    const uint32_t res = 3600, nclass = 4, pitch = 14400;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const uint32_t rpc = rows / nclass;
+    const uint32_t split = blockIdx.x % nsplit;
+    const uint32_t p0 = ((blockIdx.x / nsplit) * 4 + wave) * 16;
+    const uint32_t cls = p0 / rpc, j0 = p0 - cls * rpc;
+    const uint32_t sh = (res * cls) & 63u;
+    const uint32_t nsteps = (res + sh + 63) >> 6;
+    const uint32_t s0 = (uint32_t)(((uint64_t)nsteps * split) / nsplit), s1 = (uint32_t)(((uint64_t)nsteps * (split + 1)) / nsplit);
+    const uint32_t item0 = nclass * j0 + cls;
+    v4f v = {1.0f, 2.0f, 3.0f, (float)lane};
+    char* wbase = base + (size_t)item0 * pitch - 4 * sh;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wbase, 0, 0x7FFFFFFF, 0x00020000);
+    for (uint32_t st = s0; st < s1; ++st) {
+        for (uint32_t k = 0; k < spin; ++k) v[0] = __builtin_fmaf(v[0], 1.0000001f, 0.5f);
+        const uint32_t bin = st * 64 + 4 * c - sh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t off = (uint32_t)(g + 4 * r) * nclass * pitch + 16u * c;
+            if (bin < res) {
+                if constexpr (BUFFER)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rs, (int)off, (int)(st * 256u),
+                                                           POLICY == 2 ? (1 | 2 | 16) : (POLICY == 1 ? 2 : 0));
+                else if constexpr (POLICY == 1) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(wbase + off + st * 256u));
+                else *reinterpret_cast<v4f*>(wbase + off + st * 256u) = v;
+            }
+        }
+    }
+}
+
 template <int POLICY>
 __global__ __launch_bounds__(256) void mixed(const v4f* __restrict__ src, size_t nr16, v4f* __restrict__ dst, size_t nw16, float* sink)
 {
@@ -165,6 +201,20 @@ int main()
             snprintf(nm, sizeof nm, "write_rows pitch 14336 plain      nsplit %u spin %u", nsplit, spin);
             timeit(nm, (double)rows * pitchB, [&] { hipLaunchKernelGGL(write_rows<0>, dim3(blocks), dim3(256), 0, 0, dst, rows, pitchB, 56, nsplit, spin); });
         }
+    }
+    for (uint32_t spin : {0u, 64u}) {
+        const uint32_t blocks = (rows / 64) * 2;
+        char nm[160];
+        snprintf(nm, sizeof nm, "write_rows_class (scan pattern) plain  global_store  spin %u", spin);
+        timeit(nm, (double)rows * pitchA, [&] { hipLaunchKernelGGL((write_rows_class<0, false>), dim3(blocks), dim3(256), 0, 0, dst, rows, 2, spin); });
+        snprintf(nm, sizeof nm, "write_rows_class (scan pattern) plain  buffer_store  spin %u", spin);
+        timeit(nm, (double)rows * pitchA, [&] { hipLaunchKernelGGL((write_rows_class<0, true>), dim3(blocks), dim3(256), 0, 0, dst, rows, 2, spin); });
+        snprintf(nm, sizeof nm, "write_rows_class (scan pattern) nt     global_store  spin %u", spin);
+        timeit(nm, (double)rows * pitchA, [&] { hipLaunchKernelGGL((write_rows_class<1, false>), dim3(blocks), dim3(256), 0, 0, dst, rows, 2, spin); });
+        snprintf(nm, sizeof nm, "write_rows_class (scan pattern) nt     buffer_store  spin %u", spin);
+        timeit(nm, (double)rows * pitchA, [&] { hipLaunchKernelGGL((write_rows_class<1, true>), dim3(blocks), dim3(256), 0, 0, dst, rows, 2, spin); });
+        snprintf(nm, sizeof nm, "write_rows_class (scan pattern) sc0 sc1 nt buffer_store spin %u", spin);
+        timeit(nm, (double)rows * pitchA, [&] { hipLaunchKernelGGL((write_rows_class<2, true>), dim3(blocks), dim3(256), 0, 0, dst, rows, 2, spin); });
     }
     for (int gsz : {4096, 16384}) {
         char nm[128];
