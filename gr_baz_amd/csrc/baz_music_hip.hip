@@ -322,15 +322,22 @@ struct ScanGeom {
     uint32_t groups, nsplit, blocks, rows_per_class;
 };
 
+int g_lab_nsplit = getenv("BAZ_MUSIC_NSPLIT") ? atoi(getenv("BAZ_MUSIC_NSPLIT")) : 0;   // lab: force the range split
+
 ScanGeom scan_geometry(uint32_t batch, uint32_t nsteps, uint32_t nclass)
 {
     ScanGeom G;
     G.rows_per_class = round_up((batch + nclass - 1) / nclass, 64);
     G.groups = nclass * (G.rows_per_class / 16);
     const uint32_t live_groups = (batch + 15) / 16;
-    const uint32_t want_tasks = 256u * 4u * 8u * 4u;
+    // Wave tasks wanted = 2 x the waves the chip holds at once (256 CUs x 4 SIMDs x 4): enough to balance the tail,
+    // and no more -- every extra range restarts the top-n lists (the gate fires until they fill), writes another
+    // candidate list per item and multiplies the row streams written at once: 262,144 cfg2 items ran the scan in 0.716 /
+    // 0.758 / 0.826 ms at 1 / 2 / 4 ranges (round 1 asked for 8 waves/SIMD worth = 32,768 tasks, i.e. 2 ranges there).
+    const uint32_t want_tasks = 256u * 4u * 4u * 2u;
     uint32_t ns = (want_tasks + live_groups - 1) / live_groups;
     G.nsplit = std::max<uint32_t>(1u, std::min<uint32_t>(ns, std::min<uint32_t>(nsteps, 64u)));
+    if (g_lab_nsplit > 0) G.nsplit = std::min<uint32_t>((uint32_t)g_lab_nsplit, std::min<uint32_t>(nsteps, 64u));   // lab
     G.blocks = (G.groups / 4) * G.nsplit;
     return G;
 }
@@ -423,7 +430,7 @@ size_t cand_entries(const baz_music_ctx* c, uint32_t nb)
 // tail chunk of baz_music_process then never re-allocates in the middle of the pipeline.
 size_t cand_entries_upto(const baz_music_ctx* c, uint32_t batch)
 {
-    const size_t want_tasks = 256u * 4u * 8u * 4u;   // scan_geometry()
+    const size_t want_tasks = 256u * 4u * 4u * 2u;   // scan_geometry()
     const size_t cap_split = std::min<size_t>(64u, std::max<uint32_t>(1u, c->fb_steps));
     const size_t worst = std::min<size_t>((size_t)batch * cap_split, 16u * want_tasks + (size_t)batch);
     return std::max(worst, (size_t)batch) * topn_list_len(c->n);

@@ -57,6 +57,7 @@ VARIANTS = {0: ("shipped: gated, row classes, sc0 sc1 nt", {}),
             9: ("covariance grid 1 block per CU", {"BAZ_MUSIC_COV_BLOCKS_PER_CU": "1"}),
             10: ("covariance grid 2 blocks per CU", {"BAZ_MUSIC_COV_BLOCKS_PER_CU": "2"}),
             11: ("covariance grid 6 blocks per CU", {"BAZ_MUSIC_COV_BLOCKS_PER_CU": "6"})}
+# (the range split is read once per process: BAZ_MUSIC_NSPLIT=1 python tests/lab/r02_scan_gate.py ... to compare)
 ORDER = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1,2,3,4,5,6,7".split(","))]
 
 
