@@ -76,6 +76,7 @@ struct baz_music_ctx {
     double refine_below = 0.0;     // threshold on d = a^H Q a
     int refine_off = 0;            // lab (BAZ_MUSIC_NO_REFINE=1): projector form everywhere
     int lab_cov_old = 0;           // lab (BAZ_MUSIC_COV_OLD=1): the round-1 covariance kernel at m = 4
+    int force_nsplit = 0;          // tests / lab (BAZ_MUSIC_NSPLIT=k): bin ranges per row in the scan, 0 = by batch size
     uint32_t cov4_resident_blocks = 256u;        // grid of cov4_x4_kernel (persistent waves): one workgroup per CU
     int peak_mode = 0;      // 0: the reference's n strongest bins; 1 (opt-in extension): n strongest local maxima
     float* dPeakSpec = nullptr;   // internal spectrum when peak mode runs without the spectrum port
@@ -322,9 +323,7 @@ struct ScanGeom {
     uint32_t groups, nsplit, blocks, rows_per_class;
 };
 
-int g_lab_nsplit = getenv("BAZ_MUSIC_NSPLIT") ? atoi(getenv("BAZ_MUSIC_NSPLIT")) : 0;   // lab: force the range split
-
-ScanGeom scan_geometry(uint32_t batch, uint32_t nsteps, uint32_t nclass)
+ScanGeom scan_geometry(uint32_t batch, uint32_t nsteps, uint32_t nclass, int force_nsplit)
 {
     ScanGeom G;
     G.rows_per_class = round_up((batch + nclass - 1) / nclass, 64);
@@ -337,7 +336,7 @@ ScanGeom scan_geometry(uint32_t batch, uint32_t nsteps, uint32_t nclass)
     const uint32_t want_tasks = 256u * 4u * 4u * 2u;
     uint32_t ns = (want_tasks + live_groups - 1) / live_groups;
     G.nsplit = std::max<uint32_t>(1u, std::min<uint32_t>(ns, std::min<uint32_t>(nsteps, 64u)));
-    if (g_lab_nsplit > 0) G.nsplit = std::min<uint32_t>((uint32_t)g_lab_nsplit, std::min<uint32_t>(nsteps, 64u));   // lab
+    if (force_nsplit > 0) G.nsplit = std::min<uint32_t>((uint32_t)force_nsplit, std::min<uint32_t>(nsteps, 64u));   // tests / lab
     G.blocks = (G.groups / 4) * G.nsplit;
     return G;
 }
@@ -356,7 +355,7 @@ template <int M, int NMAX>
 int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t batch, float* d_ang,
                   float* d_lvl, float* d_spec)
 {
-    const ScanGeom G = scan_geometry(batch, c->fb_steps, c->nclass);
+    const ScanGeom G = scan_geometry(batch, c->fb_steps, c->nclass, c->force_nsplit);
     double* cand = c->dCand;
     if ((size_t)batch * G.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;   // reserve_candidates() sized it
     const bool spec = d_spec != nullptr;
@@ -396,7 +395,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
 template <int NMAX>
 int launch_merge_t(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl, float* d_spec)
 {
-    const ScanGeom G = scan_geometry(batch, c->fb_steps, c->nclass);
+    const ScanGeom G = scan_geometry(batch, c->fb_steps, c->nclass, c->force_nsplit);
     hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream, c->dCand,
                        d_spec, d_ang, d_lvl, batch, c->res, c->n, G.nsplit, c->keep_mask);
     HIP_TRY(c, hipGetLastError());
@@ -421,7 +420,7 @@ uint32_t topn_list_len(uint32_t n) { return n <= 2 ? 2u : (n <= 4 ? 4u : (n <= 8
 // candidate keys one scan launch over `nb` items produces (mirrors launch_scan_t's geometry)
 size_t cand_entries(const baz_music_ctx* c, uint32_t nb)
 {
-    return (size_t)nb * scan_geometry(nb, c->fb_steps, c->nclass).nsplit * topn_list_len(c->n);
+    return (size_t)nb * scan_geometry(nb, c->fb_steps, c->nclass, c->force_nsplit).nsplit * topn_list_len(c->n);
 }
 
 // nb * nsplit(nb) is not monotonic in nb (nsplit = ceil(want_tasks / groups) while that is <= 64 and <= nsteps), so
@@ -433,7 +432,8 @@ size_t cand_entries_upto(const baz_music_ctx* c, uint32_t batch)
     const size_t want_tasks = 256u * 4u * 4u * 2u;   // scan_geometry()
     const size_t cap_split = std::min<size_t>(64u, std::max<uint32_t>(1u, c->fb_steps));
     const size_t worst = std::min<size_t>((size_t)batch * cap_split, 16u * want_tasks + (size_t)batch);
-    return std::max(worst, (size_t)batch) * topn_list_len(c->n);
+    const size_t forced = c->force_nsplit > 0 ? (size_t)batch * std::min<size_t>((size_t)c->force_nsplit, cap_split) : 0;
+    return std::max(std::max(worst, forced), (size_t)batch) * topn_list_len(c->n);
 }
 
 int reserve_candidates(baz_music_ctx* c, uint32_t batch)
@@ -651,6 +651,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (const char* v = getenv("BAZ_MUSIC_NO_ROWCLASS")) { if (atoi(v)) c->nclass = 1; }   // lab: round-1 row order
         if (const char* v = getenv("BAZ_MUSIC_NO_REFINE")) c->refine_off = atoi(v);              // lab
         if (const char* v = getenv("BAZ_MUSIC_COV_OLD")) c->lab_cov_old = atoi(v);               // lab
+        if (const char* v = getenv("BAZ_MUSIC_NSPLIT")) c->force_nsplit = std::max(0, atoi(v));  // tests / lab
         if (hipMalloc((void**)&c->dFB, (size_t)(c->fb_steps + 2) * c->fb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         if (hipMalloc((void**)&c->dTB, (size_t)(c->fb_steps + 2) * c->tb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         {

@@ -267,6 +267,34 @@ def test_full_size_properties(cfg, batch, distinct, gpu_device):
     assert bool((lvl[:, :-1] >= lvl[:, 1:]).all())
 
 
+# ------------------------------------------------------------------ bin ranges per row in the scan
+@pytest.mark.parametrize("name", ["cfg1_m4_n2_N256_r360", "cfg2_m4_n2_N1024_r3600", "m7_n4_N700_r500", "m12_n9_N1200_r720",
+                                  "odd_m3_n1_N300_r357"])
+def test_outputs_do_not_depend_on_the_range_split_of_the_scan(name, gpu_device, monkeypatch):
+    """The scan cuts a row's bins into 1..64 ranges by batch size (one range at the bench size, several for small
+    batches) and topn_merge_kernel folds the per-range lists: every split must give the same bits, with and without the
+    spectrum port, and match the golden vectors."""
+    g = load_golden(name)
+    outs = []
+    for split in ("1", "3", "0"):                     # 0 = by batch size
+        monkeypatch.setenv("BAZ_MUSIC_NSPLIT", split)
+        with _capi().Context(g["m"], g["n"], g["nsamples"], g["res"], g["table"]) as ctx:
+            a, l, s = device_run(ctx, g["items"], gpu_device)
+            a2, l2, _ = device_run(ctx, g["items"], gpu_device, want_spec=False)
+            a3, _, _ = device_run(ctx, g["items"], gpu_device, want_lvl=False, want_spec=False)
+        outs.append((a, l, s, a2, l2, a3))
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):
+            assert np.array_equal(x, y)
+    a, l, s, a2, l2, a3 = outs[0]
+    assert_spectrum_close(s, g["spectrum"])
+    assert_doa_match(a, l, g["ang"], g["lvl"], g["res"], g["strength64"])
+    assert np.array_equal(a, a2) and np.array_equal(a, a3)
+    bins = np.round(a * g["res"] / 360.0).astype(int) % g["res"]
+    used = l > 0
+    assert np.array_equal(l[used], np.take_along_axis(s, bins, axis=1)[used])      # lvl[i] == spectrum[bin_i]
+
+
 # ------------------------------------------------------------------ near-null items: literal-form refinement
 @pytest.mark.parametrize("m,n,K,res,batch,snr,seed", [
     (4, 3, 7, 1440, 257, 60.0, 11), (7, 6, 300, 360, 257, 60.0, 12), (4, 2, 256, 3600, 300, 80.0, 13),
