@@ -401,8 +401,11 @@ def main():
                 traffic_stale = True
         cov_s = stage[capi.STAGE_COV][0] / max(stage[capi.STAGE_COV][1], 1) * 1e-3
         cov_tf = 8.0 * M * NSAMPLES * batch / cov_s / 1e12 if cov_s > 0 else 0.0
-        x4 = "cov4_x4" in cov_name
-        cov_mfma = {"kernel": cov_name, "useful_tflops": cov_tf, "fp64_matrix_peak_tflops": FP64_MFMA_PEAK_TF,
+        x4 = "cov4_" in cov_name
+        fused = "cov4_evd" in cov_name
+        cov_mfma = {"kernel": cov_name,
+                    "kernel_also_does": "the batched 4x4 Hermitian EVD of the same items (fp64 VALU at low wave priority, "
+                                        "no HBM traffic): the rates below divide by the WHOLE kernel's time" if fused else None, "useful_tflops": cov_tf, "fp64_matrix_peak_tflops": FP64_MFMA_PEAK_TF,
                     "frac_of_peak": cov_tf / FP64_MFMA_PEAK_TF, "issued_over_useful": 4.0 / 3.0 if x4 else 2.0,
                     "hbm_read_GBs": 8.0 * NSAMPLES * batch / cov_s / 1e9 if cov_s > 0 else 0.0,
                     "hbm_read_frac_of_8TBs": 8.0 * NSAMPLES * batch / cov_s / 1e9 / HBM_PEAK_GBS if cov_s > 0 else 0.0,
@@ -428,7 +431,7 @@ def main():
                        "algorithmic_bytes_per_item": bpi,
                        "pipeline_hbm_fraction_of_8TBs": value / world * bpi / 8e12,
                        "stage_ms_per_launch_separate_pass": {nm: stage[s][0] / max(stage[s][1], 1)
-                                               for s, nm in enumerate(("cov", "evd_proj", "scan_mfma", "topn_merge"))},
+                                               for s, nm in enumerate(("cov (+ evd when fused)", "evd_proj", "scan_mfma", "topn_merge"))},
                        # the one dense contraction (north_star): useful fp64 flops 8*m*N per item against the fp64
                        # matrix peak; rocprofv3 MFMA-busy for the same kernel is in profiles/r02_bench_pmc_summary.txt
                        "covariance_mfma": cov_mfma},

@@ -77,6 +77,8 @@ struct baz_music_ctx {
     int refine_off = 0;            // lab (BAZ_MUSIC_NO_REFINE=1): projector form everywhere
     int lab_cov_old = 0;           // lab (BAZ_MUSIC_COV_OLD=1): the round-1 covariance kernel at m = 4
     int force_nsplit = 0;          // tests / lab (BAZ_MUSIC_NSPLIT=k): bin ranges per row in the scan, 0 = by batch size
+    int fused_covevd = 0;          // m = 4, K % 256 == 0: covariance + EVD in one kernel (BAZ_MUSIC_FUSE=0: lab, two kernels)
+    uint32_t covevd_blocks = 512u; // grid of cov4_evd_kernel: the workgroups resident at once (2 per CU)
     uint32_t cov4_resident_blocks = 256u;        // grid of cov4_x4_kernel (persistent waves): one workgroup per CU
     int peak_mode = 0;      // 0: the reference's n strongest bins; 1 (opt-in extension): n strongest local maxima
     float* dPeakSpec = nullptr;   // internal spectrum when peak mode runs without the spectrum port
@@ -299,6 +301,19 @@ int launch_evd_t(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ
         const uint32_t blocks = (batch + IPW - 1) / IPW;
         hipLaunchKernelGGL((evd_proj_lds_kernel<M>), dim3(blocks), dim3(64), 0, c->stream, dR, dQ, batch, c->n, qstride, dG);
     }
+    HIP_TRY(c, hipGetLastError());
+    return BAZ_MUSIC_OK;
+}
+
+// m = 4, K % 256 == 0: covariance and EVD in one kernel (cov4_evd_kernel); d_R_dbg optionally receives R (test tap)
+int launch_covevd(baz_music_ctx* c, const float* d_in, uint32_t batch, double* dQ, uint32_t qstride, double* dG,
+                  double2* d_R_dbg = nullptr)
+{
+    ProfScope ps(c, BAZ_MUSIC_STAGE_COV);
+    const uint32_t ntasks = (batch + 63) / 64;
+    const uint32_t blocks = std::min<uint32_t>((ntasks + 3) / 4, c->covevd_blocks);
+    hipLaunchKernelGGL(cov4_evd_kernel, dim3(blocks), dim3(256), 0, c->stream, d_in, dQ, dG, d_R_dbg, batch, c->K, c->n,
+                       qstride);
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
 }
@@ -574,10 +589,15 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
     r = reserve_candidates(c, batch);
     if (r) return r;
     const uint32_t qstride = baz_music_q_stride(batch);
-    r = launch_cov(c, static_cast<const float*>(d_in), batch, c->dR);
-    if (r) return r;
-    r = launch_evd(c, c->dR, batch, c->dQ, qstride, c->dG);
-    if (r) return r;
+    if (c->fused_covevd) {
+        r = launch_covevd(c, static_cast<const float*>(d_in), batch, c->dQ, qstride, c->dG);
+        if (r) return r;
+    } else {
+        r = launch_cov(c, static_cast<const float*>(d_in), batch, c->dR);
+        if (r) return r;
+        r = launch_evd(c, c->dR, batch, c->dQ, qstride, c->dG);
+        if (r) return r;
+    }
     float* spec = static_cast<float*>(d_spec);
     if (c->peak_mode && !spec) {   // the peak picker reads the spectrum: keep a private one when port 2 is not wired
         const size_t need = (size_t)batch * c->res;
@@ -652,6 +672,15 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (const char* v = getenv("BAZ_MUSIC_NO_REFINE")) c->refine_off = atoi(v);              // lab
         if (const char* v = getenv("BAZ_MUSIC_COV_OLD")) c->lab_cov_old = atoi(v);               // lab
         if (const char* v = getenv("BAZ_MUSIC_NSPLIT")) c->force_nsplit = std::max(0, atoi(v));  // tests / lab
+        {   // covariance + EVD fused (cov4_evd_kernel) wherever the dwordx4 covariance applies
+            int fuse = 1;
+            if (const char* v = getenv("BAZ_MUSIC_FUSE")) fuse = atoi(v);                        // lab: 0 = two kernels
+            c->fused_covevd = (fuse > 0 && m == 4 && (c->K % 256u) == 0 && !c->lab_cov_old) ? 1 : 0;
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cov4_evd_kernel, 256, 0) == hipSuccess && per_cu > 0)
+                c->covevd_blocks = (uint32_t)per_cu * (uint32_t)std::max(1, prop.multiProcessorCount);
+            else (void)hipGetLastError();
+        }
         if (hipMalloc((void**)&c->dFB, (size_t)(c->fb_steps + 2) * c->fb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         if (hipMalloc((void**)&c->dTB, (size_t)(c->fb_steps + 2) * c->tb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         {
@@ -674,6 +703,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     snprintf(buf, sizeof(buf), m <= 8 ? "bazmusic::cov_mfma_kernel<%u>" : "bazmusic::cov_mfma2_kernel<%u>", m);
     c->stage_name[BAZ_MUSIC_STAGE_COV] = buf;
     if (m == 4 && (c->K % 256u) == 0 && !c->lab_cov_old) c->stage_name[BAZ_MUSIC_STAGE_COV] = "bazmusic::cov4_x4_kernel";
+    if (c->fused_covevd) c->stage_name[BAZ_MUSIC_STAGE_COV] = "bazmusic::cov4_evd_kernel";
     snprintf(buf, sizeof(buf), m <= 4 ? "bazmusic::evd_proj_kernel<%u>" : "bazmusic::evd_proj_lds_kernel<%u>", m);
     c->stage_name[BAZ_MUSIC_STAGE_EVD] = buf;
     snprintf(buf, sizeof(buf), "bazmusic::scan_mfma_kernel<%u,", m);
@@ -893,6 +923,12 @@ int baz_music_debug_cov(baz_music_ctx* c, const void* d_in, uint32_t batch, void
     if (!c || !d_in || !d_R || batch == 0) return BAZ_MUSIC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
+    if (c->fused_covevd) {   // the product's covariance lives inside the fused kernel: run THAT with its R tap
+        int r = ensure_workspace(c, batch);
+        if (r) return r;
+        return launch_covevd(c, static_cast<const float*>(d_in), batch, c->dQ, baz_music_q_stride(batch), c->dG,
+                             static_cast<double2*>(d_R));
+    }
     return launch_cov(c, static_cast<const float*>(d_in), batch, static_cast<double2*>(d_R));
 }
 
@@ -904,6 +940,7 @@ int baz_music_debug_q(baz_music_ctx* c, const void* d_in, uint32_t batch, void* 
     int r = ensure_workspace(c, batch);
     if (r) return r;
     const uint32_t qstride = baz_music_q_stride(batch);
+    if (c->fused_covevd) return launch_covevd(c, static_cast<const float*>(d_in), batch, static_cast<double*>(d_Q), qstride, c->dG);
     r = launch_cov(c, static_cast<const float*>(d_in), batch, c->dR);
     if (r) return r;
     return launch_evd(c, c->dR, batch, static_cast<double*>(d_Q), qstride, c->dG);

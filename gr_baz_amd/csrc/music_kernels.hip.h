@@ -429,10 +429,7 @@ __device__ __forceinline__ void jacobi_sweep(Herm<M>& h, const bool active)
 
 // The per-lane EVD + projector of one item (m <= 4, register resident, statically indexed).  getR(i, j) returns
 // R_ij as double2; every lane of the wave must call this (wave-uniform early exit of the sweeps).
-// (A fused covariance + EVD kernel built on this function -- 64 items per wave, R parked in LDS -- took exactly the
-// sum of the two kernels, 0.436 vs 0.353 + 0.078 ms per 262,144 cfg2 items: the Jacobi's ~220 VGPRs leave one
-// streaming wave per SIMD, which cannot feed the HBM pipe and share issue slots with the other wave's sweeps.
-// profiles/r02_fused_covevd_negative.txt; removed.)
+// Shared by evd_proj_kernel and the fused cov4_evd_kernel, which produce the same bits.
 template <int M, class GetR>
 __device__ __forceinline__ void evd_project_lane(GetR getR, const bool valid, const uint32_t item, const uint32_t n,
                                                  const uint32_t qstride, double* __restrict__ Qs, double* __restrict__ Gs)
@@ -534,6 +531,121 @@ __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict_
     const uint32_t itc = valid ? item : (batch - 1);
     const double2* Rp = R + (size_t)itc * MM;
     evd_project_lane<M>([&](int i, int j) { return Rp[i * M + j]; }, valid, item, n, qstride, Qs, Gs);
+}
+
+// -------------------------------------------------------------------------------------
+// 2a. Covariance AND EVD in one kernel for m = 4, K % 256 == 0: a wave streams 64 consecutive items through the
+//     covariance of cov4_x4_kernel (1c), parks each R (upper triangle, 16 doubles) in LDS, then runs the lane-per-item
+//     Jacobi of evd_project_lane on the 64 of them and writes Q (and G).  R never touches HBM and the EVD's ~0.065 ms
+//     of pure fp64 VALU work per 262,144 items is meant to run in the issue slots the HBM-bound covariance leaves idle.
+//     The first version of this kernel took exactly the sum of its parts (profiles/r02_fused_covevd_negative.txt): the
+//     Jacobi's ~210 VGPRs allow two waves per SIMD, and a wave in its EVD phase -- dependent fp64 VALU, always ready
+//     to issue -- halves the issue rate of the one wave left to feed the HBM pipe.  Hence the priorities: a streaming
+//     wave runs at s_setprio 3, an EVD phase at 0, so the Jacobi only takes the slots the stream leaves.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cov4_evd_kernel(const float* __restrict__ in, double* __restrict__ Qs,
+                                                       double* __restrict__ Gs, double2* __restrict__ Rdbg,
+                                                       uint32_t batch, uint32_t K, uint32_t n, uint32_t qstride)
+{
+    constexpr int RSD = 34;                       // see cov4_x4_kernel
+    constexpr int RING = 8;                       // chunk loads in flight per wave (8 KiB)
+    __shared__ double stage[4][2][8 * RSD];       // per wave, double-buffered
+    __shared__ double gram[4][2][64];             // per wave: D1, D2
+    __shared__ double rtab[4][16][64];            // per wave: R of 64 items, [slot][item]: 4 diagonals, 6 x (re, im)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t chunks = K >> 5;               // 1-KiB chunks per item (multiple of 8)
+    const int wcol = lane >> 1, wrow = 4 * (lane & 1);
+    const int ri = lane & 3, rh = (lane >> 2) & 1, rw = (lane >> 3) & 1, rk = lane >> 4;
+    const int p_off = (4 * rh + ri) * RSD + 8 * rk + 4 * rw;
+    const int q_off = (4 * (1 - rh) + ri) * RSD + 8 * rk + 4 * rw;
+    double* const g1 = gram[wave][0];
+    double* const g2 = gram[wave][1];
+    double(*const rt)[64] = rtab[wave];
+    const double dK = (double)K;
+    const uint32_t ntasks = (batch + 63) >> 6;
+    const uint32_t tstride = gridDim.x * 4;
+    // slot of the upper-triangle entry this lane (< 16: a = lane>>2, b = lane&3) produces: diagonal a -> a;
+    // pair (a < b) -> 4 + 2p (re), 5 + 2p (im), p = index of (a, b) in (0,1)(0,2)(0,3)(1,2)(1,3)(2,3)
+    const int ea = (lane >> 2) & 3, eb = lane & 3;
+    const int pidx = (ea == 0) ? eb - 1 : (ea == 1 ? eb + 1 : 5);
+
+    for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += tstride) {
+        __builtin_amdgcn_s_setprio(3);
+        const uint32_t item0 = task * 64;
+        const uint32_t nit = (batch - item0 < 64u) ? batch - item0 : 64u;
+        // the stream of this task: nit items x chunks, contiguous in HBM; ring slot u holds the chunks q = u (mod 8)
+        const v4f32* __restrict__ src = reinterpret_cast<const v4f32*>(in + (size_t)item0 * K * 8) + lane;
+        const uint32_t total = nit * chunks;                 // multiple of 8
+        v4f32 pf[RING];
+#pragma unroll
+        for (int u = 0; u < RING; ++u) pf[u] = __builtin_nontemporal_load(src + (size_t)u * 64);
+        uint32_t q = 0;                                      // chunk index inside the task
+        for (uint32_t it = 0; it < nit; ++it) {
+            double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0;
+            for (uint32_t cg = 0; cg < chunks; cg += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    double* __restrict__ T = stage[wave][u & 1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) T[(wrow + j) * RSD + wcol] = (double)pf[u][j];   // exact widening (.cc:77)
+                    // re-arm the slot only after its values are consumed (see cov4_x4_kernel); past the end of the
+                    // task the loads repeat its last chunk, so that they stay unconditional
+                    asm volatile("" ::: "memory");
+                    const uint32_t qn = q + u + RING;
+                    pf[u] = __builtin_nontemporal_load(src + (size_t)(qn < total ? qn : total - 1) * 64);
+                    wave_lds_fence();
+                    const v4f64 P = *reinterpret_cast<const v4f64*>(T + p_off);
+                    const v4f64 Q = *reinterpret_cast<const v4f64*>(T + q_off);
+                    a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(P[0], P[0], a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f64_4x4x4f64(P[0], Q[0], a2, 0, 0, 0);
+                    b1 = __builtin_amdgcn_mfma_f64_4x4x4f64(P[1], P[1], b1, 0, 0, 0);
+                    b2 = __builtin_amdgcn_mfma_f64_4x4x4f64(P[1], Q[1], b2, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(P[2], P[2], a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f64_4x4x4f64(P[2], Q[2], a2, 0, 0, 0);
+                    b1 = __builtin_amdgcn_mfma_f64_4x4x4f64(P[3], P[3], b1, 0, 0, 0);
+                    b2 = __builtin_amdgcn_mfma_f64_4x4x4f64(P[3], Q[3], b2, 0, 0, 0);
+                    wave_lds_fence();
+                }
+                q += 8;
+            }
+            // Gram blocks -> R (see cov4_x4_kernel), upper triangle into the wave's table
+            g1[lane] = a1 + b1;
+            g2[lane] = a2 + b2;
+            wave_lds_fence();
+            if (lane < 16) {
+                auto G = [&](int x, int y) -> double {
+                    if ((x >> 2) == (y >> 2)) {
+                        const int hh = x >> 2, o = (y & 3) + 4 * hh + 16 * (x & 3);
+                        return g1[o] + g1[o + 8];
+                    }
+                    if (x > y) { const int t = x; x = y; y = t; }
+                    const int o = (y - 4) + 16 * x;
+                    return g2[o] + g2[o + 8];
+                };
+                const double re = (G(2 * ea, 2 * eb) + G(2 * ea + 1, 2 * eb + 1)) / dK;     // .cc:85
+                const double im = (G(2 * ea + 1, 2 * eb) - G(2 * ea, 2 * eb + 1)) / dK;
+                if (ea == eb) rt[ea][it] = re;
+                else if (ea < eb) { rt[4 + 2 * pidx][it] = re; rt[5 + 2 * pidx][it] = im; }
+                if (Rdbg) Rdbg[(size_t)(item0 + it) * 16 + lane] = make_double2(re, im);
+            }
+            wave_lds_fence();
+        }
+        // EVD of the task's items, one per lane (lanes beyond nit redo the last item and write nothing), at low priority
+        __builtin_amdgcn_s_setprio(0);
+        {
+            const int li = ((uint32_t)lane < nit) ? lane : (int)nit - 1;
+            auto getR = [&](int i, int j) -> double2 {
+                if (i == j) return make_double2(rt[i][li], 0.0);
+                const int lo = i < j ? i : j, hi2 = i < j ? j : i;
+                const int p = (lo == 0) ? hi2 - 1 : (lo == 1 ? hi2 + 1 : 5);
+                const double re = rt[4 + 2 * p][li], im = rt[5 + 2 * p][li];
+                return make_double2(re, i < j ? im : -im);
+            };
+            evd_project_lane<4>(getR, (uint32_t)lane < nit, item0 + lane, n, qstride, Qs, Gs);
+        }
+        wave_lds_fence();
+    }
 }
 
 // -------------------------------------------------------------------------------------

@@ -56,7 +56,8 @@ VARIANTS = {0: ("shipped: gated, row classes, sc0 sc1 nt", {}),
             7: ("round-1 covariance kernel (dword loads, 16x16x4)", {"BAZ_MUSIC_COV_OLD": "1"}),
             9: ("covariance grid 1 block per CU", {"BAZ_MUSIC_COV_BLOCKS_PER_CU": "1"}),
             10: ("covariance grid 2 blocks per CU", {"BAZ_MUSIC_COV_BLOCKS_PER_CU": "2"}),
-            11: ("covariance grid 6 blocks per CU", {"BAZ_MUSIC_COV_BLOCKS_PER_CU": "6"})}
+            11: ("covariance grid 6 blocks per CU", {"BAZ_MUSIC_COV_BLOCKS_PER_CU": "6"}),
+            15: ("cov4_x4 + evd_proj as two kernels (no fusion)", {"BAZ_MUSIC_FUSE": "0"})}
 # (the range split is read once per process: BAZ_MUSIC_NSPLIT=1 python tests/lab/r02_scan_gate.py ... to compare)
 ORDER = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1,2,3,4,5,6,7".split(","))]
 
@@ -64,7 +65,7 @@ ORDER = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1,
 def run(x, label):
     out = {}
     for v in ORDER:
-        for k in ("BAZ_MUSIC_SCAN_VARIANT", "BAZ_MUSIC_NO_ROWCLASS", "BAZ_MUSIC_NO_REFINE", "BAZ_MUSIC_COV_OLD", "BAZ_MUSIC_COV_BLOCKS_PER_CU"):
+        for k in ("BAZ_MUSIC_SCAN_VARIANT", "BAZ_MUSIC_NO_ROWCLASS", "BAZ_MUSIC_NO_REFINE", "BAZ_MUSIC_COV_OLD", "BAZ_MUSIC_COV_BLOCKS_PER_CU", "BAZ_MUSIC_FUSE"):
             os.environ.pop(k, None)
         os.environ.update(VARIANTS[v][1])
         ctx = capi.Context(M, NE, N, RES, table)

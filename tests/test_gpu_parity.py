@@ -267,6 +267,26 @@ def test_full_size_properties(cfg, batch, distinct, gpu_device):
     assert bool((lvl[:, :-1] >= lvl[:, 1:]).all())
 
 
+# ------------------------------------------------------------------ fused covariance + EVD (m = 4, K % 256 == 0)
+def test_fused_covariance_evd_kernel_equals_the_two_kernel_form(gpu_device, monkeypatch):
+    """cfg2 runs covariance and EVD in ONE kernel (cov4_evd_kernel: R stays in LDS, the Jacobi runs at low wave priority
+    under the input stream); BAZ_MUSIC_FUSE=0 runs cov4_x4_kernel + evd_proj_kernel.  Same arithmetic: same bits, for a
+    batch that is not a multiple of the 64-item wave task, and both match the golden vectors."""
+    g = load_golden("cfg2_m4_n2_N1024_r3600")
+    items = np.concatenate([g["items"]] * 5)[:131]                  # 2 full wave tasks + a 3-item tail
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("BAZ_MUSIC_FUSE", fuse)
+        with _capi().Context(g["m"], g["n"], g["nsamples"], g["res"], g["table"]) as ctx:
+            assert ("cov4_evd_kernel" in ctx.stage_name(0)) == (fuse == "1")
+            outs.append(device_run(ctx, items, gpu_device))
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+    B = g["items"].shape[0]
+    assert_spectrum_close(outs[0][2][:B], g["spectrum"])
+    assert_doa_match(outs[0][0][:B], outs[0][1][:B], g["ang"], g["lvl"], g["res"], g["strength64"])
+
+
 # ------------------------------------------------------------------ bin ranges per row in the scan
 @pytest.mark.parametrize("name", ["cfg1_m4_n2_N256_r360", "cfg2_m4_n2_N1024_r3600", "m7_n4_N700_r500", "m12_n9_N1200_r720",
                                   "odd_m3_n1_N300_r357"])
