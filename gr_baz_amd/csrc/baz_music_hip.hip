@@ -72,7 +72,9 @@ struct baz_music_ctx {
     double* dG = nullptr;          // noise eigenvectors, item-minor like dQ (cap * m*m * 2 doubles)
     double2* dTB = nullptr;        // raw steering table as fp64 MFMA B-operand image (build_TB), padded like dFB
     size_t tb_step_elems = 0;      // double2 elements per step of TB (2 * ceil(2m/4) * 64)
-    unsigned long long* dRefined = nullptr;   // statistic: (item, bin) values recomputed by the last call
+    unsigned long long* dRefined = nullptr;   // statistic: (item, bin) values recomputed, [2]: double-buffered by API call
+    int stat_parity = 0;                      // the scan adds to dRefined[stat_parity]; the merge clears the other one
+    bool stat_next_clean = true;              // false after a call that failed before its merge ran
     double refine_below = 0.0;     // threshold on d = a^H Q a
     int refine_off = 0;            // lab (BAZ_MUSIC_NO_REFINE=1): projector form everywhere
     int lab_cov_old = 0;           // lab (BAZ_MUSIC_COV_OLD=1): the round-1 covariance kernel at m = 4
@@ -379,7 +381,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
     rf.Gs = c->refine_off ? nullptr : c->dG;
     rf.TB = c->dTB + c->tb_step_elems;
     rf.below = c->refine_below;
-    rf.count = c->dRefined;
+    rf.count = c->dRefined + c->stat_parity;
     const double2* fb0 = c->dFB + c->fb_step_elems;   // step 0 (a padded step lies in front)
 #define BAZ_SCAN_ARGS dQ, fb0, d_spec, cand, batch, c->res, qstride, G.nsplit, c->nclass, G.rows_per_class, c->keep_mask, c->n, rf
 #define BAZ_SCAN_LAUNCH(SPEC, VEC4, ABLV, AUXV)                                                                    \
@@ -412,7 +414,7 @@ int launch_merge_t(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl,
 {
     const ScanGeom G = scan_geometry(batch, c->fb_steps, c->nclass, c->force_nsplit);
     hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream, c->dCand,
-                       d_spec, d_ang, d_lvl, batch, c->res, c->n, G.nsplit, c->keep_mask);
+                       d_spec, d_ang, d_lvl, batch, c->res, c->n, G.nsplit, c->keep_mask, c->dRefined + (c->stat_parity ^ 1));
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
 }
@@ -581,6 +583,17 @@ bool is_pinned_host(const void* p)
 // sub-batch i+1 with the scan of sub-batch i on two extra streams was measured and is SLOWER -- 0.53 ms ->
 // 0.60 / 0.70 / 1.05 ms at 2 / 4 / 8 sub-batches, profiles/r01_two_stream_pipeline_negative.txt: the
 // cross-stream event dependencies cost more than the overlap buys.)
+// Start the statistic of one API call: flip to the counter the previous call's merge kernel cleared (a memset only
+// after a call that failed before its merge).
+int begin_statistic(baz_music_ctx* c)
+{
+    c->stat_parity ^= 1;
+    if (!c->stat_next_clean)
+        HIP_TRY(c, hipMemsetAsync(c->dRefined + c->stat_parity, 0, sizeof(unsigned long long), c->stream));
+    c->stat_next_clean = false;
+    return BAZ_MUSIC_OK;
+}
+
 int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void* d_ang, void* d_lvl,
                           void* d_spec)
 {
@@ -614,6 +627,7 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
     if (r) return r;
     r = launch_merge(c, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), spec);
     if (r) return r;
+    c->stat_next_clean = true;     // the merge cleared the next call's statistic counter
     if (c->peak_mode) return launch_peaks(c, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), spec);
     return BAZ_MUSIC_OK;
 }
@@ -691,8 +705,8 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
             if (const char* v = getenv("BAZ_MUSIC_COV_BLOCKS_PER_CU"))    // lab: grid of the covariance kernel
                 if (atoi(v) > 0) c->cov4_resident_blocks = (uint32_t)atoi(v) * (uint32_t)std::max(1, prop.multiProcessorCount);
         }
-        if (hipMalloc((void**)&c->dRefined, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
-        if (hipMemset(c->dRefined, 0, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
+        if (hipMalloc((void**)&c->dRefined, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+        if (hipMemset(c->dRefined, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         r = upload_table(c, table_ri);
     } while (0);
     if (r != BAZ_MUSIC_OK) {
@@ -785,8 +799,8 @@ int baz_music_process_device(baz_music_ctx* c, const void* d_in, uint32_t batch,
     if (batch == 0) return BAZ_MUSIC_OK;
     std::lock_guard<std::mutex> lk(c->mtx);   // .cc:101
     DeviceGuard guard(c->device);
-    HIP_TRY(c, hipMemsetAsync(c->dRefined, 0, sizeof(unsigned long long), c->stream));
-    return process_device_locked(c, d_in, batch, d_ang, d_lvl, d_spec);
+    int r = begin_statistic(c);
+    return r ? r : process_device_locked(c, d_in, batch, d_ang, d_lvl, d_spec);
 }
 
 int baz_music_process_device_on(baz_music_ctx* c, void* caller_stream, const void* d_in, uint32_t batch, void* d_ang,
@@ -804,8 +818,8 @@ int baz_music_process_device_on(baz_music_ctx* c, void* caller_stream, const voi
         HIP_TRY(c, hipEventRecord(c->ev_in, cs));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_in, 0));
     }
-    HIP_TRY(c, hipMemsetAsync(c->dRefined, 0, sizeof(unsigned long long), c->stream));
-    int r = process_device_locked(c, d_in, batch, d_ang, d_lvl, d_spec);
+    int r = begin_statistic(c);
+    if (r == BAZ_MUSIC_OK) r = process_device_locked(c, d_in, batch, d_ang, d_lvl, d_spec);
     if (foreign) {   // also after a failed launch: whatever was enqueued is ordered before the caller's next work
         hipError_t e = hipEventRecord(c->ev_out, c->stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(cs, c->ev_out, 0);
@@ -844,7 +858,7 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
 
     int rc = BAZ_MUSIC_OK;
     uint32_t idx = 0;
-    HIP_TRY(c, hipMemsetAsync(c->dRefined, 0, sizeof(unsigned long long), c->stream));   // statistic of this call (all chunks)
+    rc = begin_statistic(c);                  // statistic of this call (all its chunks add to the same counter)
     // A failing HIP call must not return from inside the loop: copies already queued still target the caller's
     // buffers, so every exit goes through the drain below.
 #define HIP_STEP(call)                                                     \
@@ -1008,7 +1022,7 @@ int64_t baz_music_refined_items(baz_music_ctx* c)
     if (!c->dRefined) return 0;
     unsigned long long n = 0;
     if (hipStreamSynchronize(c->stream) != hipSuccess ||
-        hipMemcpy(&n, c->dRefined, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        hipMemcpy(&n, c->dRefined + c->stat_parity, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int64_t)n;
 }
 

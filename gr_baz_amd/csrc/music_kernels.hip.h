@@ -1436,9 +1436,12 @@ __global__ __launch_bounds__(256) void topn_merge_kernel(const double* __restric
                                                           const float* __restrict__ spec,
                                                           float* __restrict__ ang, float* __restrict__ lvl,
                                                           uint32_t batch, uint32_t res, uint32_t n, uint32_t nsplit,
-                                                          uint32_t keep_mask)
+                                                          uint32_t keep_mask, unsigned long long* __restrict__ next_stat)
 {
     const uint32_t it = blockIdx.x * 256 + threadIdx.x;
+    // the refinement statistic is double-buffered by call: this launch clears the counter the NEXT call's scan adds to
+    // (a hipMemsetAsync per call was a 5-us kernel of its own between two launches)
+    if (it == 0 && next_stat) *next_stat = 0ull;
     if (it >= batch) return;
     double key[NMAX];
 #pragma unroll
