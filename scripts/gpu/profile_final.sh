@@ -21,5 +21,6 @@ python scripts/pmc_traffic.py "$W" "$F" $O/scan_pmc_traffic.json $HEAD > $O/pmc_
 cp $O/scan_pmc_traffic.json profiles/r02_scan_pmc_traffic.json      # so that the bench run below reports it
 python bench.py --steps 20 --warmup 3 > $O/bench_line.json 2> $O/bench_err.txt
 python tests/lab/refine_rate.py > $O/refine_rate.txt 2>&1
+python scripts/cfg5_pipeline.py 16384 20 > $O/cfg5_pipeline.txt 2>&1
 head -12 $O/bench_kernel_stats.csv; cat $O/pmc_traffic_out.txt | tail -22; python -c "
 import json; d=json.load(open('$O/bench_line.json')); print(d['value'], d['ms_per_step'], d['rounds']); print(d['roofline'])"
