@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libbaz_music_hip.so")
 OK = 0
 E_INVALID, E_NOMEM, E_HIP, E_UNSUPPORTED, E_NODEVICE = -1, -2, -3, -4, -5
 STAGE_COV, STAGE_EVD, STAGE_SCAN, STAGE_MERGE, NUM_STAGES = 0, 1, 2, 3, 4
-MAX_M, MAX_N = 16, 15
+MAX_M, MAX_N = 64, 63     # BAZ_MUSIC_MAX_M / _MAX_N (specialised kernels up to m = 16, run-time-m kernels above)
 
 # every symbol include/baz_music_hip.h declares (tests/test_abi.py checks the .so exports them all)
 SYMBOLS = [

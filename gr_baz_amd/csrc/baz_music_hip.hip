@@ -6,6 +6,7 @@
 // baz_music_create() fails with BAZ_MUSIC_E_NODEVICE / BAZ_MUSIC_E_HIP.
 #include "../../include/baz_music_hip.h"
 #include "music_kernels.hip.h"
+#include "music_wide_kernels.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -79,6 +80,12 @@ struct baz_music_ctx {
     int refine_off = 0;            // lab (BAZ_MUSIC_NO_REFINE=1): projector form everywhere
     int lab_cov_old = 0;           // lab (BAZ_MUSIC_COV_OLD=1): the round-1 covariance kernel at m = 4
     int force_nsplit = 0;          // tests / lab (BAZ_MUSIC_NSPLIT=k): bin ranges per row in the scan, 0 = by batch size
+    // wide arrays (17 <= m <= BAZ_MUSIC_MAX_M): the run-time-m kernels of music_wide_kernels.hip.h
+    bool wide = false;
+    float2* dTA = nullptr;         // steering table transposed, [m][res] complex64
+    double2* dGw = nullptr;        // noise eigenvectors, [items][m - n][m]
+    double* dWS = nullptr;         // fp64 strengths, [items][res] (the top-n's input)
+    uint32_t wide_cap = 0;         // items the three buffers above (and dR) hold
     int fused_covevd = 0;          // m = 4, K % 256 == 0: covariance + EVD in one kernel (BAZ_MUSIC_FUSE=0: lab, two kernels)
     uint32_t covevd_blocks = 512u; // grid of cov4_evd_kernel: the workgroups resident at once (2 per CU)
     uint32_t cov4_resident_blocks = 256u;        // grid of cov4_x4_kernel (persistent waves): one workgroup per CU
@@ -501,8 +508,105 @@ int launch_scan(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t b
 #undef BAZ_CALL
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wide arrays (m > BAZ_MUSIC_FAST_M): the run-time-m kernels of music_wide_kernels.hip.h, one workgroup per item.
+// ---------------------------------------------------------------------------------------------------------------
+size_t wide_evd_lds(uint32_t m)
+{
+    const size_t ld = m + 1, np = (m + (m & 1u)) / 2;
+    return 2 * (size_t)m * ld * sizeof(double2) + np * 6 * sizeof(double) + bazwide::WB * sizeof(double) + 2 * np * sizeof(int) +
+           m * sizeof(int);
+}
+
+// items per pass: bounds the fp64 strength scratch (res doubles per item) to ~256 MiB
+uint32_t wide_pass_items(const baz_music_ctx* c)
+{
+    const size_t per_item = (size_t)c->res * sizeof(double);
+    return (uint32_t)std::max<size_t>(1, std::min<size_t>(8192, ((size_t)256 << 20) / per_item));
+}
+
+int ensure_wide_workspace(baz_music_ctx* c, uint32_t items)
+{
+    if (items <= c->wide_cap) return BAZ_MUSIC_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->dR) { (void)hipFree(c->dR); c->dR = nullptr; }
+    if (c->dGw) { (void)hipFree(c->dGw); c->dGw = nullptr; }
+    if (c->dWS) { (void)hipFree(c->dWS); c->dWS = nullptr; }
+    c->wide_cap = 0;
+    const size_t mm = (size_t)c->m * c->m;
+    HIP_TRY(c, hipMalloc((void**)&c->dR, (size_t)items * mm * sizeof(double2)));
+    HIP_TRY(c, hipMalloc((void**)&c->dGw, (size_t)items * (c->m - c->n) * c->m * sizeof(double2)));
+    HIP_TRY(c, hipMalloc((void**)&c->dWS, (size_t)items * c->res * sizeof(double)));
+    c->wide_cap = items;
+    return BAZ_MUSIC_OK;
+}
+
+int launch_cov_wide(baz_music_ctx* c, const float* d_in, uint32_t nb, double2* dR)
+{
+    ProfScope ps(c, BAZ_MUSIC_STAGE_COV);
+    hipLaunchKernelGGL(bazwide::cov_wide_kernel, dim3(nb), dim3(bazwide::WB), (size_t)bazwide::COV_TC * c->m * sizeof(float2),
+                       c->stream, reinterpret_cast<const float2*>(d_in), dR, c->m, c->K);
+    HIP_TRY(c, hipGetLastError());
+    return BAZ_MUSIC_OK;
+}
+
+int process_wide_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void* d_ang, void* d_lvl, void* d_spec)
+{
+    const uint32_t pass = std::min(batch, wide_pass_items(c));
+    int r = ensure_wide_workspace(c, pass);
+    if (r) return r;
+    const float* in = static_cast<const float*>(d_in);
+    float* ang = static_cast<float*>(d_ang);
+    float* lvl = static_cast<float*>(d_lvl);
+    float* spec = static_cast<float*>(d_spec);
+    const uint32_t nn = c->m - c->n;
+    for (uint32_t off = 0; off < batch; off += pass) {
+        const uint32_t nb = std::min(pass, batch - off);
+        r = launch_cov_wide(c, in + (size_t)off * c->nsamples * 2, nb, c->dR);
+        if (r) return r;
+        {
+            ProfScope ps(c, BAZ_MUSIC_STAGE_EVD);
+            hipLaunchKernelGGL(bazwide::evd_wide_kernel, dim3(nb), dim3(bazwide::WB), wide_evd_lds(c->m), c->stream, c->dR,
+                               c->dGw, c->m, c->n);
+            HIP_TRY(c, hipGetLastError());
+        }
+        {
+            ProfScope ps(c, BAZ_MUSIC_STAGE_SCAN);
+            // enough workgroups for a small batch: split the bins of an item over several
+            const uint32_t max_y = (c->res + bazwide::WB - 1) / bazwide::WB;
+            const uint32_t ny = std::max(1u, std::min(max_y, (2048u + nb - 1) / nb));
+            const uint32_t bpb = round_up((c->res + ny - 1) / ny, bazwide::WB);
+            hipLaunchKernelGGL(bazwide::scan_wide_kernel, dim3(nb, (c->res + bpb - 1) / bpb), dim3(bazwide::WB),
+                               (size_t)nn * c->m * sizeof(double2), c->stream, c->dGw, c->dTA, c->dWS,
+                               spec ? spec + (size_t)off * c->res : nullptr, c->m, c->n, c->res, bpb);
+            HIP_TRY(c, hipGetLastError());
+        }
+        {
+            ProfScope ps(c, BAZ_MUSIC_STAGE_MERGE);
+            hipLaunchKernelGGL(bazwide::topn_wide_kernel, dim3(nb), dim3(bazwide::WB), 0, c->stream, c->dWS,
+                               ang + (size_t)off * c->n, lvl ? lvl + (size_t)off * c->n : nullptr, c->res, c->n);
+            HIP_TRY(c, hipGetLastError());
+        }
+    }
+    return BAZ_MUSIC_OK;
+}
+
+int upload_table_wide(baz_music_ctx* c, const float* table_ri)
+{
+    std::vector<float> ta((size_t)c->m * c->res * 2);
+    for (uint32_t b = 0; b < c->res; ++b)
+        for (uint32_t i = 0; i < c->m; ++i) {
+            ta[2 * ((size_t)i * c->res + b)] = table_ri[2 * ((size_t)b * c->m + i)];
+            ta[2 * ((size_t)i * c->res + b) + 1] = table_ri[2 * ((size_t)b * c->m + i) + 1];
+        }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // no batch in flight reads the old table
+    HIP_TRY(c, hipMemcpy(c->dTA, ta.data(), ta.size() * sizeof(float), hipMemcpyHostToDevice));
+    return BAZ_MUSIC_OK;
+}
+
 int upload_table(baz_music_ctx* c, const float* table_ri)
 {
+    if (c->wide) return upload_table_wide(c, table_ri);
     std::vector<double> F;
     build_F(table_ri, c->m, c->res, F);
     std::vector<double> FB;
@@ -597,6 +701,11 @@ int begin_statistic(baz_music_ctx* c)
 int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void* d_ang, void* d_lvl,
                           void* d_spec)
 {
+    if (c->wide) {
+        const int rw = process_wide_locked(c, d_in, batch, d_ang, d_lvl, d_spec);
+        if (rw == BAZ_MUSIC_OK) c->stat_next_clean = true;    // (no scan statistic on this path: the counters stay 0)
+        return rw;
+    }
     int r = ensure_workspace(c, batch);
     if (r) return r;
     r = reserve_candidates(c, batch);
@@ -645,6 +754,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     if (m == 0 || n == 0 || n >= m || nsamples == 0 || (nsamples % m) != 0 || resolution == 0 || !table_ri)
         return BAZ_MUSIC_E_INVALID;
     if (m > BAZ_MUSIC_MAX_M || n > BAZ_MUSIC_MAX_N) return BAZ_MUSIC_E_UNSUPPORTED;   // see baz_music_strerror()
+    const bool wide = m > BAZ_MUSIC_FAST_M;
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BAZ_MUSIC_E_NODEVICE;
@@ -668,6 +778,21 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     do {
         if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         c->stream = c->own_stream;
+        c->wide = wide;
+        if (wide) {   // run-time-m kernels: only the transposed table and the statistic counters (which stay 0)
+            if (resolution > (1u << 20)) { r = BAZ_MUSIC_E_UNSUPPORTED; break; }
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(bazwide::evd_wide_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_evd_lds(m)) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(bazwide::scan_wide_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)(m - n) * m * sizeof(double2))) != hipSuccess) {
+                r = BAZ_MUSIC_E_HIP; break;
+            }
+            if (hipMalloc((void**)&c->dTA, (size_t)m * resolution * sizeof(float2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+            if (hipMalloc((void**)&c->dRefined, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+            if (hipMemset(c->dRefined, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
+            r = upload_table(c, table_ri);
+            break;
+        }
         c->fb_steps = (resolution + 63) / 64;
         // bin field of the top-n key: 16 bits up to 65,536 bins (d truncated by <= 2^-36), else 20 bits
         if (resolution > (1u << 20)) { r = BAZ_MUSIC_E_UNSUPPORTED; break; }
@@ -713,6 +838,14 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         baz_music_destroy(c);
         return r;
     }
+    if (wide) {
+        c->stage_name[BAZ_MUSIC_STAGE_COV] = "bazwide::cov_wide_kernel";
+        c->stage_name[BAZ_MUSIC_STAGE_EVD] = "bazwide::evd_wide_kernel";
+        c->stage_name[BAZ_MUSIC_STAGE_SCAN] = "bazwide::scan_wide_kernel";
+        c->stage_name[BAZ_MUSIC_STAGE_MERGE] = "bazwide::topn_wide_kernel";
+        *out = c;
+        return BAZ_MUSIC_OK;
+    }
     char buf[128];
     snprintf(buf, sizeof(buf), m <= 8 ? "bazmusic::cov_mfma_kernel<%u>" : "bazmusic::cov_mfma2_kernel<%u>", m);
     c->stage_name[BAZ_MUSIC_STAGE_COV] = buf;
@@ -744,6 +877,9 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->dTB) (void)hipFree(c->dTB);
         if (c->dRefined) (void)hipFree(c->dRefined);
         if (c->dPeakSpec) (void)hipFree(c->dPeakSpec);
+        if (c->dTA) (void)hipFree(c->dTA);
+        if (c->dGw) (void)hipFree(c->dGw);
+        if (c->dWS) (void)hipFree(c->dWS);
         free_slots(c);
         if (c->ev_in) (void)hipEventDestroy(c->ev_in);
         if (c->ev_out) (void)hipEventDestroy(c->ev_out);
@@ -786,6 +922,7 @@ int baz_music_reserve(baz_music_ctx* c, uint32_t max_batch)
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->wide) return ensure_wide_workspace(c, std::min(max_batch, wide_pass_items(c)));
     int r = ensure_workspace(c, max_batch);
     return r ? r : reserve_candidates(c, max_batch);
 }
@@ -851,10 +988,12 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
     const bool want_spec = spectrum != nullptr;
     int r = ensure_slots(c, chunk, want_spec);
     if (r) return r;
-    r = ensure_workspace(c, chunk);
-    if (r) return r;
-    r = reserve_candidates(c, chunk);
-    if (r) return r;
+    if (!c->wide) {
+        r = ensure_workspace(c, chunk);
+        if (r) return r;
+        r = reserve_candidates(c, chunk);
+        if (r) return r;
+    }
 
     int rc = BAZ_MUSIC_OK;
     uint32_t idx = 0;
@@ -937,6 +1076,7 @@ int baz_music_debug_cov(baz_music_ctx* c, const void* d_in, uint32_t batch, void
     if (!c || !d_in || !d_R || batch == 0) return BAZ_MUSIC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
+    if (c->wide) return launch_cov_wide(c, static_cast<const float*>(d_in), batch, static_cast<double2*>(d_R));
     if (c->fused_covevd) {   // the product's covariance lives inside the fused kernel: run THAT with its R tap
         int r = ensure_workspace(c, batch);
         if (r) return r;
@@ -951,6 +1091,7 @@ int baz_music_debug_q(baz_music_ctx* c, const void* d_in, uint32_t batch, void* 
     if (!c || !d_in || !d_Q || batch == 0) return BAZ_MUSIC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
+    if (c->wide) return BAZ_MUSIC_E_UNSUPPORTED;   // the wide path forms no projector (literal form straight from G)
     int r = ensure_workspace(c, batch);
     if (r) return r;
     const uint32_t qstride = baz_music_q_stride(batch);
@@ -965,6 +1106,7 @@ int baz_music_debug_evd(baz_music_ctx* c, const void* d_R, uint32_t batch, void*
     if (!c || !d_R || !d_Q || batch == 0) return BAZ_MUSIC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
+    if (c->wide) return BAZ_MUSIC_E_UNSUPPORTED;
     return launch_evd(c, static_cast<const double2*>(d_R), batch, static_cast<double*>(d_Q), baz_music_q_stride(batch), nullptr);
 }
 
@@ -982,8 +1124,9 @@ const char* baz_music_strerror(int code)
         case BAZ_MUSIC_E_NOMEM: return "out of memory";
         case BAZ_MUSIC_E_HIP: return "HIP runtime error";
         case BAZ_MUSIC_E_UNSUPPORTED:
-            return "configuration not supported by the gfx950 kernels (limits: m <= 16 antennas, n <= 15 emitters, "
-                   "resolution <= 1048576 bins; the reference itself has none, lib/baz_music_doa.cc:45-50)";
+            return "configuration not supported by the gfx950 kernels (limits: m <= 64 antennas -- specialised kernels up "
+                   "to 16, run-time-m kernels from 17 to 64 --, n < m emitters, resolution <= 1048576 bins, the local-maximum "
+                   "picker only up to 16 antennas; the reference itself has none, lib/baz_music_doa.cc:45-50)";
         case BAZ_MUSIC_E_NODEVICE: return "no usable gfx950 device";
         default: return "unknown error";
     }
@@ -1010,6 +1153,7 @@ int baz_music_set_peak_mode(baz_music_ctx* c, int mode)
 {
     if (!c || (mode != 0 && mode != 1)) return BAZ_MUSIC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mtx);
+    if (mode && c->wide) return BAZ_MUSIC_E_UNSUPPORTED;   // the opt-in picker exists for the specialised kernels only
     c->peak_mode = mode;
     return BAZ_MUSIC_OK;
 }

@@ -50,8 +50,9 @@ enum {
     BAZ_MUSIC_E_NODEVICE = -5     /* no gfx950 device / device_id out of range */
 };
 
-#define BAZ_MUSIC_MAX_M 16u       /* antennas handled by the gfx950 kernels (config 5 uses 16) */
-#define BAZ_MUSIC_MAX_N 15u       /* expected emitters (n < m) */
+#define BAZ_MUSIC_MAX_M 64u       /* antennas handled by the gfx950 kernels */
+#define BAZ_MUSIC_FAST_M 16u      /* ... by the kernels specialised per m (config 5 uses 16); 17..64 run the run-time-m path */
+#define BAZ_MUSIC_MAX_N 63u       /* expected emitters (n < m) */
 
 /* Stage indices for baz_music_stage_ms / baz_music_stage_name. */
 enum { BAZ_MUSIC_STAGE_COV = 0, BAZ_MUSIC_STAGE_EVD = 1, BAZ_MUSIC_STAGE_SCAN = 2, BAZ_MUSIC_STAGE_MERGE = 3,

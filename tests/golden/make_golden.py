@@ -116,9 +116,26 @@ def resamp_fixtures():
                    [(1, 2, 1.5, 0), (2, 1, 0.125, 0), (3, 3, 0.75, 0), (4, 4, 3, 2), (4, 3, -0.25, 0)], 4004)
 
 
+def wide_fixtures():
+    """more than 16 antennas: the run-time-m kernels (gr_baz_amd/csrc/music_wide_kernels.hip.h)"""
+    fixture("wide_m17_n2_N816_r360", 17, 2, 17 * 48, 360, mo.array_geometry(17), 3, 20.0, 2101)
+    fixture("wide_m24_n5_N1536_r500", 24, 5, 24 * 64, 500, mo.array_geometry(24), 2, 25.0, 2102,
+            angles=(20.0, 95.0, 170.0, 245.0, 320.0))
+    fixture("wide_m32_n2_N2048_r720", 32, 2, 2048, 720, mo.array_geometry(32), 2, 20.0, 2103)
+    fixture("wide_m33_n32_N2112_r90", 33, 32, 33 * 64, 90, mo.array_geometry(33), 2, 30.0, 2104,
+            angles=tuple(np.linspace(3.0, 351.0, 32)))
+    fixture("wide_m64_n3_N4096_r256", 64, 3, 4096, 256, mo.array_geometry(64), 1, 20.0, 2105, angles=(40.3, 121.7, 250.0))
+
+
 def main():
     if "--resamp-only" in sys.argv:
         resamp_fixtures()
+        return
+    if "--wide-only" in sys.argv:
+        if not mr.have_ref():
+            mr.build()
+        print("LAPACK zheev backend:", mr.ref_use_lapack(True))
+        wide_fixtures()
         return
     if not mr.have_ref():
         mr.build()
@@ -152,6 +169,7 @@ def main():
             angles=(10.0, 50.0, 90.0, 130.0, 170.0, 210.0, 250.0, 290.0, 330.0))
     fixture("m10_n3_N1000_r1001", 10, 3, 1000, 1001, mo.array_geometry(10), 3, 20.0, 2011, angles=(70.0, 190.0, 300.5))
     fixture("m9_n1_N630_r250", 9, 1, 630, 250, mo.array_geometry(9), 3, 15.0, 2012, angles=(222.0,))
+    wide_fixtures()
     # baz_agc_cc: defaults of lib/baz_agc_cc.h:41 and a fast loop; stateful call sequences
     # that straddle the 4096-sample chunk of the HIP scan
     agc_fixture("agc_default_rate1e-4", 1e-4, 1.0, (12000,), 3001)

@@ -68,9 +68,9 @@ def test_create_rejects_null_and_unsupported():
     L = capi.lib()
     h = ctypes.c_void_p()
     assert L.baz_music_create(ctypes.byref(h), 4, 2, 8, 4, None, -1) == capi.E_INVALID
-    tab = np.zeros(17 * 2 * 4, np.float32)
-    r = L.baz_music_create(ctypes.byref(h), 17, 2, 34, 4, tab.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), -1)
-    assert r == capi.E_UNSUPPORTED     # m > BAZ_MUSIC_MAX_M: no silent CPU fallback
+    tab = np.zeros(65 * 2 * 4, np.float32)
+    r = L.baz_music_create(ctypes.byref(h), 65, 2, 130, 4, tab.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), -1)
+    assert r == capi.E_UNSUPPORTED     # m > BAZ_MUSIC_MAX_M (64): no silent CPU fallback
     assert L.baz_music_process(None, None, 0, None, None, None) == capi.E_INVALID
     assert L.baz_music_set_table(None, None) == capi.E_INVALID
     L.baz_music_destroy(None)          # harmless

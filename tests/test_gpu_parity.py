@@ -137,6 +137,66 @@ def test_hip_matches_oracle_on_odd_shapes(m, n, N, res, batch, gpu_device):
     assert np.array_equal(a2, ang) and np.array_equal(l2, lvl) and np.array_equal(s2, spec)
 
 
+@pytest.mark.parametrize("m,n,N,res,batch", [
+    (17, 2, 17 * 40, 360, 9),       # the first antenna count past the specialised kernels; odd m (phantom index)
+    (20, 19, 20 * 64, 91, 5),       # n = m-1: one noise vector, 19 list entries
+    (31, 4, 31 * 48, 1000, 4),
+    (32, 2, 32 * 128, 3600, 6),
+    (48, 7, 48 * 96, 500, 3),
+    (64, 2, 64 * 64, 720, 3),       # BAZ_MUSIC_MAX_M: 137 KB of LDS per item
+])
+def test_wide_arrays_match_the_oracle(m, n, N, res, batch, gpu_device):
+    """17..64 antennas (music_wide_kernels.hip.h): device path, host path and stage tap against the oracle."""
+    arr = mo.array_geometry(m)
+    table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
+    angles = tuple(np.linspace(17.0, 311.0, n))
+    items = mo.synth_items(batch, m, N, arr, mo.FREQUENCY, mo.SPACING, angles_deg=angles, snr_db=20.0,
+                           seed=100 * m + n)
+    ao, lo, so, st = mo.music_doa_work_batch(items, table, m, n)
+    torch = _torch()
+    with _capi().Context(m, n, N, res, table) as ctx:
+        ang, lvl, spec = device_run(ctx, items, gpu_device)
+        a1, _, _ = device_run(ctx, items, gpu_device, want_lvl=False, want_spec=False)
+        a2, l2, s2 = ctx.process(items)
+        x = torch.from_numpy(np.ascontiguousarray(items).view(np.float32)).to(gpu_device)
+        R = torch.zeros(batch, m * m, 2, dtype=torch.float64, device=gpu_device)
+        ctx.debug_cov(x.data_ptr(), batch, R.data_ptr())
+        ctx.sync()
+        assert ctx.refined_items() == 0
+    assert_spectrum_close(spec, so)
+    assert_doa_match(ang, lvl, ao, lo, res, st)
+    assert np.array_equal(a1, ang)
+    assert np.array_equal(a2, ang) and np.array_equal(l2, lvl) and np.array_equal(s2, spec)
+    xs = items.astype(np.complex128).reshape(batch, N // m, m).transpose(0, 2, 1)
+    Rn = (xs @ xs.conj().transpose(0, 2, 1)) / float(N // m)
+    Rg = R.cpu().numpy()
+    Rg = (Rg[..., 0] + 1j * Rg[..., 1]).reshape(batch, m, m)
+    assert np.abs(Rg - Rn).max() <= 1e-13 * np.abs(Rn).max()
+    assert np.array_equal(Rg, Rg.conj().transpose(0, 2, 1))          # exactly Hermitian
+
+
+def test_wide_arrays_top_n_and_non_finite_items(gpu_device):
+    """the wide path's own top-n: exact ties keep the earlier bin, an item with a NaN sample yields (0, 0) pairs and
+    a NaN spectrum, its neighbours are untouched"""
+    m, n, N, res = 18, 3, 18 * 32, 120
+    arr = mo.array_geometry(m)
+    table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
+    table[60:] = table[:60]                              # every strength occurs twice: bins b and b + 60
+    items = mo.synth_items(4, m, N, arr, mo.FREQUENCY, mo.SPACING, angles_deg=(33.0, 100.0, 170.0), snr_db=20.0, seed=77)
+    items[2, 5] = np.nan
+    with _capi().Context(m, n, N, res, table) as ctx:
+        ang, lvl, spec = device_run(ctx, items, gpu_device)
+    assert np.all(np.isnan(spec[2])) and np.all(ang[2] == 0.0) and np.all(lvl[2] == 0.0)
+    for it in (0, 1, 3):
+        assert np.array_equal(spec[it, :60], spec[it, 60:])
+        bins = np.rint(ang[it] * res / 360.0).astype(int)
+        assert bins[1] == bins[0] + 60 and bins[2] < 60      # strongest bin, its twin (the LATER bin second), then the next value
+        assert np.array_equal(lvl[it], spec[it][bins])
+    clean = np.delete(items, 2, axis=0)
+    ao, lo, so, st = mo.music_doa_work_batch(clean, table, m, n)
+    assert_spectrum_close(np.delete(spec, 2, axis=0), so)
+
+
 def test_optional_ports(gpu_device):
     """output_items.size() in {1,2,3} (lib/baz_music_doa.cc:97-99,147-154; lvl NULL must not crash)."""
     c = mo.make_config("cfg1", 50, seed=3)
