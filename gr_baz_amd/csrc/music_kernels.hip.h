@@ -536,12 +536,14 @@ __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict_
 // -------------------------------------------------------------------------------------
 // 2a. Covariance AND EVD in one kernel for m = 4, K % 256 == 0: a wave streams 64 consecutive items through the
 //     covariance of cov4_x4_kernel (1c), parks each R (upper triangle, 16 doubles) in LDS, then runs the lane-per-item
-//     Jacobi of evd_project_lane on the 64 of them and writes Q (and G).  R never touches HBM and the EVD's ~0.065 ms
-//     of pure fp64 VALU work per 262,144 items is meant to run in the issue slots the HBM-bound covariance leaves idle.
-//     The first version of this kernel took exactly the sum of its parts (profiles/r02_fused_covevd_negative.txt): the
-//     Jacobi's ~210 VGPRs allow two waves per SIMD, and a wave in its EVD phase -- dependent fp64 VALU, always ready
-//     to issue -- halves the issue rate of the one wave left to feed the HBM pipe.  Hence the priorities: a streaming
-//     wave runs at s_setprio 3, an EVD phase at 0, so the Jacobi only takes the slots the stream leaves.
+//     Jacobi of evd_project_lane on the 64 of them and writes Q (and G).  R never touches HBM, and nothing is written
+//     while the wave streams: the stand-alone covariance lost 0.06 ms to its 67 MB of 256-B R stores interleaved with
+//     the read stream (its arithmetic is free at 2 waves/SIMD), see profiles/r02_fused_covevd_priorities.txt.
+//     The EVD is NOT hidden: every wave streams at the same rate, so all of them reach their EVD phase together --
+//     2 x (153 us of stream + 40 us of rotations) per 262,144 items.  Staggered phases and a rotation-per-item state
+//     machine were measured slower (the rotations' fp64 VALU work and the stream's fp64 MFMAs share the DP pipe).
+//     A streaming wave runs at s_setprio 3, an EVD phase at 0 (worth 0.04 ms against equal priorities once the waves
+//     drift apart).
 // -------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cov4_evd_kernel(const float* __restrict__ in, double* __restrict__ Qs,
                                                        double* __restrict__ Gs, double2* __restrict__ Rdbg,

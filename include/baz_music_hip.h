@@ -119,7 +119,8 @@ BAZ_MUSIC_API const char* baz_music_stage_name(baz_music_ctx* ctx, int stage);
  *   cov : d_in -> d_R      batch * m*m complex128 (row-major R[i][j], (re,im) doubles)   .cc:82-85
  *   evd : d_R  -> d_Q      m*m doubles per item, item-minor: d_Q[e*q_stride + item]; the
  *                          real coefficients of the noise-subspace projector G G^H         .cc:88-93
- * q_stride is returned by baz_music_q_stride() for the given batch. */
+ * q_stride is returned by baz_music_q_stride() for the given batch.  Past BAZ_MUSIC_FAST_M antennas no projector is
+ * formed (the literal form runs straight from the noise eigenvectors): `evd` and `q` return BAZ_MUSIC_E_UNSUPPORTED. */
 BAZ_MUSIC_API int baz_music_debug_cov(baz_music_ctx* ctx, const void* d_in, uint32_t batch, void* d_R);
 BAZ_MUSIC_API int baz_music_debug_evd(baz_music_ctx* ctx, const void* d_R, uint32_t batch, void* d_Q);
 /*   q   : d_in -> d_Q      the two stages back to back, exactly as process_device() runs them for this
@@ -141,7 +142,8 @@ BAZ_MUSIC_API const char* baz_music_version(void);
 /* OPT-IN extension, not reference behaviour: mode 1 makes ang/lvl the n strongest LOCAL MAXIMA
  * of the pseudo-spectrum (bin b with s[b] > s[b-1] and s[b] >= s[b+1] on the circle) instead of the reference's n
  * strongest bins (lib/baz_music_doa.cc:129-141, which usually are neighbours on one lobe).  Same output format,
- * descending strength, (0, 0) for missing peaks.  Mode 0 (default) is the reference. */
+ * descending strength, (0, 0) for missing peaks.  Mode 0 (default) is the reference.  Mode 1 is offered up to
+ * BAZ_MUSIC_FAST_M antennas (BAZ_MUSIC_E_UNSUPPORTED beyond). */
 BAZ_MUSIC_API int baz_music_set_peak_mode(baz_music_ctx* ctx, int mode);
 /* Statistic: how many (item, bin) values of the LAST process call were recomputed in the reference's literal form
  * ||G^H a||^2 because the projector form a^H Q a put them at or below ~m 1e-8 max||a||^2 (near-nulls of the noise
