@@ -86,6 +86,8 @@ struct baz_music_ctx {
     double2* dGw = nullptr;        // noise eigenvectors, [items][m - n][m]
     double* dWS = nullptr;         // fp64 strengths, [items][res] (the top-n's input)
     uint32_t wide_cap = 0;         // items the three buffers above (and dR) hold
+    uint8_t* dRedo = nullptr;      // [cap] items evd_sub_kernel hands back to the Jacobi
+    int sub_evd = 1;               // signal subspace by orthogonal iteration where n <= 3 (lab: BAZ_MUSIC_SUB_EVD=0)
     int fused_covevd = 0;          // m = 4, K % 256 == 0: covariance + EVD in one kernel (BAZ_MUSIC_FUSE=0: lab, two kernels)
     uint32_t covevd_blocks = 512u; // grid of cov4_evd_kernel: the workgroups resident at once (2 per CU)
     uint32_t cov4_resident_blocks = 256u;        // grid of cov4_x4_kernel (persistent waves): one workgroup per CU
@@ -207,10 +209,13 @@ int ensure_workspace(baz_music_ctx* c, uint32_t batch)
     if (c->dR) { (void)hipFree(c->dR); c->dR = nullptr; }
     if (c->dQ) { (void)hipFree(c->dQ); c->dQ = nullptr; }
     if (c->dG) { (void)hipFree(c->dG); c->dG = nullptr; }
+    if (c->dRedo) { (void)hipFree(c->dRedo); c->dRedo = nullptr; }
     c->cap = 0;
     HIP_TRY(c, hipMalloc((void**)&c->dR, (size_t)cap * mm * sizeof(double2)));
     HIP_TRY(c, hipMalloc((void**)&c->dQ, (size_t)cap * mm * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->dG, (size_t)cap * mm * 2 * sizeof(double)));
+    if (c->dRedo) { (void)hipFree(c->dRedo); c->dRedo = nullptr; }
+    HIP_TRY(c, hipMalloc((void**)&c->dRedo, (size_t)cap));
     c->cap = cap;
     return BAZ_MUSIC_OK;
 }
@@ -308,7 +313,19 @@ int launch_evd_t(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ
     } else {                  // M lanes per item, matrices in LDS
         constexpr uint32_t IPW = 64 / M;
         const uint32_t blocks = (batch + IPW - 1) / IPW;
-        hipLaunchKernelGGL((evd_proj_lds_kernel<M>), dim3(blocks), dim3(64), 0, c->stream, dR, dQ, batch, c->n, qstride, dG);
+        // few emitters: the signal subspace by orthogonal iteration (evd_sub_kernel), then the Jacobi only for the items
+        // it hands back (gap too small, zero / non-finite R)
+        const uint8_t* only = nullptr;
+        if (c->sub_evd && c->n <= 3 && 2 * c->n <= (uint32_t)M && c->dRedo && batch <= c->cap) {
+            constexpr uint32_t GS = M <= 8 ? 8 : 16, IPS = 64 / GS;
+            const uint32_t sblocks = (batch + IPS - 1) / IPS;
+            if (c->n == 1) hipLaunchKernelGGL((evd_sub_kernel<M, 1>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQ, batch, qstride, dG, c->dRedo);
+            else if (c->n == 2) hipLaunchKernelGGL((evd_sub_kernel<M, 2>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQ, batch, qstride, dG, c->dRedo);
+            else if constexpr (M >= 6) hipLaunchKernelGGL((evd_sub_kernel<M, 3>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQ, batch, qstride, dG, c->dRedo);
+            HIP_TRY(c, hipGetLastError());
+            only = c->dRedo;
+        }
+        hipLaunchKernelGGL((evd_proj_lds_kernel<M>), dim3(blocks), dim3(64), 0, c->stream, dR, dQ, batch, c->n, qstride, dG, only);
     }
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
@@ -810,6 +827,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (const char* v = getenv("BAZ_MUSIC_NO_ROWCLASS")) { if (atoi(v)) c->nclass = 1; }   // lab: round-1 row order
         if (const char* v = getenv("BAZ_MUSIC_NO_REFINE")) c->refine_off = atoi(v);              // lab
         if (const char* v = getenv("BAZ_MUSIC_COV_OLD")) c->lab_cov_old = atoi(v);               // lab
+        if (const char* v = getenv("BAZ_MUSIC_SUB_EVD")) c->sub_evd = atoi(v);                   // lab / tests
         if (const char* v = getenv("BAZ_MUSIC_NSPLIT")) c->force_nsplit = std::max(0, atoi(v));  // tests / lab
         {   // covariance + EVD fused (cov4_evd_kernel) wherever the dwordx4 covariance applies
             int fuse = 1;
@@ -874,6 +892,7 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->dR) (void)hipFree(c->dR);
         if (c->dQ) (void)hipFree(c->dQ);
         if (c->dG) (void)hipFree(c->dG);
+        if (c->dRedo) (void)hipFree(c->dRedo);
         if (c->dTB) (void)hipFree(c->dTB);
         if (c->dRefined) (void)hipFree(c->dRefined);
         if (c->dPeakSpec) (void)hipFree(c->dPeakSpec);

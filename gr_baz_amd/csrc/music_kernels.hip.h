@@ -688,7 +688,8 @@ template <int M>
 __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restrict__ R,
                                                            double* __restrict__ Qs,
                                                            uint32_t batch, uint32_t n, uint32_t qstride,
-                                                           double* __restrict__ Gs)
+                                                           double* __restrict__ Gs,
+                                                           const uint8_t* __restrict__ only = nullptr)
 {
     constexpr int MM = M * M;
     constexpr int IPW = 64 / M;           // items per wave
@@ -709,8 +710,11 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
     const bool lane_used = slot < IPW;
     const int sl = lane_used ? slot : 0;
     const uint32_t item = blockIdx.x * IPW + sl;
-    const bool valid = lane_used && item < batch;
     const uint32_t itc = (item < batch) ? item : (batch - 1);
+    // `only` (the pass behind evd_sub_kernel): just the items that kernel handed back; a wave with none of them leaves
+    const bool wanted = !only || only[itc] != 0;
+    if (only && !__any(wanted && lane_used && item < batch)) return;
+    const bool valid = lane_used && item < batch && wanted;
     double2(*A)[M + 1] = sA[sl];
 
     double2 Vrow[ME];
@@ -922,6 +926,256 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
                 Qs[(size_t)(j * M + l) * qstride + item] = 2.0 * re + poison;
                 Qs[(size_t)(l * M + j) * qstride + item] = -2.0 * im + poison;
             }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// 2c. The projector WITHOUT the full eigen-decomposition, for m >= 5 and few emitters (n = P <= 3, 2P <= m).
+//
+//     MUSIC needs only the noise-subspace projector I - S S^H, S = the eigenvectors of the n LARGEST eigenvalues
+//     (.cc:88-93 keeps the other m-n columns of eig_sym), and with n of m = 2 of 16 that invariant subspace is found far
+//     faster by orthogonal (subspace) iteration than all 16 eigenpairs by Jacobi:
+//         Y <- orth(R Y)      convergence: sin(angle to the invariant subspace) shrinks by lambda_{n+1} / lambda_n per step
+//     (5-6 steps at 20 dB SNR, 8 at 10 dB, 15 at 0 dB for config 5's shape; ~450 instructions per step against ~43,000
+//     for the Jacobi of a 16x16 matrix: config 5's EVD 0.98 -> see DESIGN.md).  An item is DONE when the change
+//     || (I - Y Y^H) Y' ||_F of its basis is <= 4e-15 sqrt(n) (projector within ~1e-15 of the eigh-based one, measured);
+//     it then freezes (exact) while wave-mates continue, so results never depend on which items share a wave.  An item
+//     that does not get there -- a gap lambda_n ~ lambda_{n+1} (fewer emitters than n, noise only, zero input), a
+//     non-finite R -- is handed back through `redo` and takes the Jacobi (evd_proj_lds_kernel with only = redo): the
+//     choice is a function of the item alone.
+//     Layout: GS = 8 or 16 lanes per item (lane j = row j of R and of Y; lanes >= m idle), all reductions over the
+//     group are XOR butterflies on DPP (mirror / half-mirror / quad permutes: every lane of the group ends with the
+//     SAME bits, each step adds the same two operands in both partners), Y is published through LDS for the R Y product.
+//     G (the noise eigenvectors' stand-in for the scan's literal form -- any orthonormal basis of the noise subspace
+//     gives the same ||G^H a||^2): the last m-n columns of the Householder completion H_0 .. H_{P-1} of S.
+// -------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)b, CTRL, 0xF, 0xF, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+template <int GS>
+__device__ __forceinline__ double group_allsum(double v)
+{
+    if constexpr (GS == 16) v += dpp_f64<0x140>(v);     // row_mirror       lane ^ 15
+    v += dpp_f64<0x141>(v);                             // row_half_mirror  lane ^ 7
+    v += dpp_f64<0x1B>(v);                              // quad_perm [3,2,1,0]  lane ^ 3
+    v += dpp_f64<0xB1>(v);                              // quad_perm [1,0,3,2]  lane ^ 1
+    return v;
+}
+
+template <int GS>
+__device__ __forceinline__ double group_allmax(double v)
+{
+    if constexpr (GS == 16) v = fmax(v, dpp_f64<0x140>(v));
+    v = fmax(v, dpp_f64<0x141>(v));
+    v = fmax(v, dpp_f64<0x1B>(v));
+    v = fmax(v, dpp_f64<0xB1>(v));
+    return v;
+}
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 cmulc(double2 a, double2 b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a conj(b)
+
+template <int M, int P>
+__global__ __launch_bounds__(64) void evd_sub_kernel(const double2* __restrict__ R, double* __restrict__ Qs, uint32_t batch,
+                                                      uint32_t qstride, double* __restrict__ Gs, uint8_t* __restrict__ redo)
+{
+    static_assert(M >= 5 && M <= 16 && P >= 1 && 2 * P <= M, "few emitters on the LDS-EVD antenna counts");
+    constexpr int GS = M <= 8 ? 8 : 16, IPW = 64 / GS, MM = M * M;
+    // give up where the Jacobi is cheaper: ~35 steps' worth at m <= 8, ~95 at m = 16
+    constexpr int MAX_IT = M <= 8 ? 28 : 64;
+    constexpr double BAIL2 = M <= 8 ? 0.09 : 0.36;        // (estimated rate)^2 beyond which MAX_IT cannot be met
+    constexpr double TOL2 = 1.6e-29 * P;                  // (4e-15 sqrt(P))^2
+    __shared__ double2 sY[IPW][P][GS];
+    const int lane = threadIdx.x, g = lane / GS, j = lane - g * GS;
+    const uint32_t item = blockIdx.x * IPW + g;
+    const bool item_ok = item < batch, row = j < M;
+    const uint32_t itc = item_ok ? item : batch - 1;
+    const int jc = row ? j : 0;
+
+    double2 Rrow[M];
+    double psum = 0.0, dj = 0.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        double2 v = R[(size_t)itc * MM + jc * M + k];
+        if (!row) v = make_double2(0.0, 0.0);
+        psum += v.x + v.y;
+        if (k == jc) { v.y = 0.0; dj = fabs(v.x); }
+        Rrow[k] = v;
+    }
+    const double poison = group_allsum<GS>(psum * 0.0);   // NaN iff R holds a NaN / Inf: such an item goes to the Jacobi
+    const double dmax = group_allmax<GS>(dj);
+    int ex = 0;
+    (void)frexp(dmax, &ex);
+    const double scl = (dmax > 0.0 && dmax < __builtin_huge_val()) ? ldexp(1.0, -ex) : 1.0;   // as evd_proj_kernel
+#pragma unroll
+    for (int k = 0; k < M; ++k) { Rrow[k].x *= scl; Rrow[k].y *= scl; }
+
+    // modified Gram-Schmidt, each projection twice; ok = every norm was a positive finite number
+    auto orth = [&](double2 (&z)[P], double2 (&yn)[P]) -> bool {
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+                for (int c2 = 0; c2 < c; ++c2) {
+                    const double2 t = cmulc(z[c], yn[c2]);            // conj(yn) z, this row's term
+                    const double hr = group_allsum<GS>(t.x), hi = group_allsum<GS>(t.y);
+                    z[c].x -= hr * yn[c2].x - hi * yn[c2].y;
+                    z[c].y -= hr * yn[c2].y + hi * yn[c2].x;
+                }
+            const double n2 = group_allsum<GS>(z[c].x * z[c].x + z[c].y * z[c].y);
+            const bool good = n2 > 0.0 && n2 < __builtin_huge_val();
+            ok = ok && good;
+            const double inv = good ? 1.0 / sqrt(n2) : 0.0;
+            yn[c] = make_double2(z[c].x * inv, z[c].y * inv);
+        }
+        return ok;
+    };
+
+    double2 y[P], z[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) z[c] = Rrow[c];            // one step from the first P unit vectors
+    bool ok = orth(z, y) && !(poison != poison);
+    bool conv = false;
+    double d2prev = __builtin_huge_val();
+    for (int it = 0; it < MAX_IT; ++it) {
+        wave_lds_fence();
+#pragma unroll
+        for (int c = 0; c < P; ++c) sY[g][c][j] = y[c];
+        wave_lds_fence();
+#pragma unroll
+        for (int c = 0; c < P; ++c) z[c] = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < M; ++k)
+#pragma unroll
+            for (int c = 0; c < P; ++c) {
+                const double2 yk = sY[g][c][k];
+                z[c].x += Rrow[k].x * yk.x - Rrow[k].y * yk.y;
+                z[c].y += Rrow[k].x * yk.y + Rrow[k].y * yk.x;
+            }
+        double2 yn[P];
+        const bool ok2 = orth(z, yn);
+        // D = Y' - Y (Y^H Y'): the part of the new basis outside the old subspace
+        double dloc = 0.0;
+#pragma unroll
+        for (int b = 0; b < P; ++b) {
+            double2 d = yn[b];
+#pragma unroll
+            for (int a = 0; a < P; ++a) {
+                const double2 t = cmulc(yn[b], y[a]);                 // conj(y_a) yn_b
+                const double cr = group_allsum<GS>(t.x), ci = group_allsum<GS>(t.y);
+                d.x -= y[a].x * cr - y[a].y * ci;
+                d.y -= y[a].x * ci + y[a].y * cr;
+            }
+            dloc += d.x * d.x + d.y * d.y;
+        }
+        const double d2 = group_allsum<GS>(dloc);
+        if (!conv && ok) {                                  // (a frozen or failed item keeps its y)
+            ok = ok2 && (d2 == d2);
+#pragma unroll
+            for (int c = 0; c < P; ++c) y[c] = yn[c];
+            if (ok && d2 <= TOL2) conv = true;
+            else if (it >= 2 && d2 > 100.0 * TOL2 && d2 > BAIL2 * d2prev) ok = false;   // too slow: the Jacobi is cheaper
+            d2prev = d2;
+        }
+        if (__all(conv || !ok || !item_ok)) break;
+    }
+    if (item_ok && j == 0) redo[item] = conv ? 0 : 1;
+    if (!__any(conv && item_ok)) return;
+
+    // ---- outputs of the converged items ----
+    wave_lds_fence();
+#pragma unroll
+    for (int c = 0; c < P; ++c) sY[g][c][j] = y[c];
+    wave_lds_fence();
+    const bool emit = conv && item_ok && row;
+    if (emit) {   // row j of Q = I - S S^H (upper part), packed as evd_proj_kernel does
+        for (int l = j; l < M; ++l) {
+            double re = 0.0, im = 0.0;
+#pragma unroll
+            for (int c = 0; c < P; ++c) {
+                const double2 vl = sY[g][c][l];
+                re += y[c].x * vl.x + y[c].y * vl.y;
+                im += y[c].y * vl.x - y[c].x * vl.y;
+            }
+            re = ((l == j) ? 1.0 : 0.0) - re; im = -im;
+            if (l == j) {
+                Qs[(size_t)(j * M + j) * qstride + item] = re;
+            } else {
+                Qs[(size_t)(j * M + l) * qstride + item] = 2.0 * re;
+                Qs[(size_t)(l * M + j) * qstride + item] = -2.0 * im;
+            }
+        }
+    }
+    if (!Gs) return;
+    // ---- Householder completion: S = H_0 .. H_{P-1} [I_P; 0] D  ->  columns P..M-1 of H_0 .. H_{P-1} span the noise space
+    double2 v[P];
+    double tau[P];
+    double2 w[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) w[c] = y[c];
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+        // x = w[c] on rows >= c; v = x - alpha e_c, alpha = -phase(x_c) ||x||
+        const bool in = row && j >= c;
+        const double2 x = in ? w[c] : make_double2(0.0, 0.0);
+        const double nx2 = group_allsum<GS>(x.x * x.x + x.y * x.y);
+        const double xcr = group_allsum<GS>(j == c ? x.x : 0.0), xci = group_allsum<GS>(j == c ? x.y : 0.0);
+        const double nx = sqrt(nx2), ax = sqrt(xcr * xcr + xci * xci);
+        const double pr = ax > 0.0 ? xcr / ax : 1.0, pi = ax > 0.0 ? xci / ax : 0.0;
+        v[c] = x;
+        if (j == c) { v[c].x += pr * nx; v[c].y += pi * nx; }
+        const double nv2 = group_allsum<GS>(v[c].x * v[c].x + v[c].y * v[c].y);
+        tau[c] = nv2 > 0.0 ? 2.0 / nv2 : 0.0;
+#pragma unroll
+        for (int b = c + 1; b < P; ++b) {                  // w_b <- H_c w_b
+            const double2 t = cmulc(w[b], v[c]);           // conj(v) w_b, this row's term
+            const double sr = group_allsum<GS>(t.x) * tau[c], si = group_allsum<GS>(t.y) * tau[c];
+            w[b].x -= v[c].x * sr - v[c].y * si;
+            w[b].y -= v[c].x * si + v[c].y * sr;
+        }
+    }
+    // beta[c][c2] = v_c^H v_c2 (c < c2)
+    double2 beta[P][P];
+#pragma unroll
+    for (int c = 0; c < P; ++c)
+#pragma unroll
+        for (int c2 = c + 1; c2 < P; ++c2) {
+            const double2 t = cmulc(v[c2], v[c]);
+            beta[c][c2] = make_double2(group_allsum<GS>(t.x), group_allsum<GS>(t.y));
+        }
+    wave_lds_fence();
+#pragma unroll
+    for (int c = 0; c < P; ++c) sY[g][c][j] = v[c];
+    wave_lds_fence();
+    if (emit) {
+        for (int k = P; k < M; ++k) {                      // g_k = H_0 .. H_{P-1} e_k = e_k - sum_c coef_c v_c
+            double2 coef[P];
+            double2 gk = make_double2(j == k ? 1.0 : 0.0, 0.0);
+#pragma unroll
+            for (int c = P - 1; c >= 0; --c) {
+                const double2 vk = sY[g][c][k];
+                double2 s = make_double2(vk.x, -vk.y);     // v_c^H e_k
+#pragma unroll
+                for (int c2 = c + 1; c2 < P; ++c2) {       // - coef_c2 (v_c^H v_c2)
+                    const double2 t = cmul(coef[c2], beta[c][c2]);
+                    s.x -= t.x; s.y -= t.y;
+                }
+                coef[c] = make_double2(tau[c] * s.x, tau[c] * s.y);
+                const double2 t = cmul(coef[c], v[c]);
+                gk.x -= t.x; gk.y -= t.y;
+            }
+            const int r = k - P;
+            Gs[(size_t)((r * M + j) * 2) * qstride + item] = gk.x;
+            Gs[(size_t)((r * M + j) * 2 + 1) * qstride + item] = gk.y;
         }
     }
 }
