@@ -427,16 +427,25 @@ __device__ __forceinline__ void jacobi_sweep(Herm<M>& h, const bool active)
         for (int q = p + 1; q < M; ++q) jacobi_rotate<M>(h, p, q, active);
 }
 
-// The per-lane EVD + projector of one item (m <= 4, register resident, statically indexed).  getR(i, j) returns
-// R_ij as double2; every lane of the wave must call this (wave-uniform early exit of the sweeps).
-// Shared by evd_proj_kernel and the fused cov4_evd_kernel, which produce the same bits.
+// The per-lane EVD + projector of one item (m <= 4, register resident, statically indexed), in pieces:
+//     evd_begin (scale, load)  ->  { evd_check ; jacobi_sweep } per sweep  ->  evd_finish (ranks, G, Q)
+// evd_project_lane runs them.  Every lane of the wave must take part (the early exit is wave-uniform).  Shared by evd_proj_kernel and the fused cov4_evd_kernel,
+// which produce the same bits.
+constexpr int EVD_MAX_SWEEPS = 16;
+
+template <int M>
+struct EvdState {
+    Herm<M> h;
+    double poison;     // NaN iff some entry of R is NaN or +-Inf, else +-0
+    bool done;         // this lane's item has converged: its rotations are exact identities from now on
+};
+
+// getR(i, j) returns R_ij as double2
 template <int M, class GetR>
-__device__ __forceinline__ void evd_project_lane(GetR getR, const bool valid, const uint32_t item, const uint32_t n,
-                                                 const uint32_t qstride, double* __restrict__ Qs, double* __restrict__ Gs)
+__device__ __forceinline__ void evd_begin(GetR getR, EvdState<M>& st)
 {
     static_assert(M <= 4, "register-resident, statically indexed (m >= 5 uses evd_proj_lds_kernel)");
-    constexpr int MAX_SWEEPS = 16;
-    Herm<M> h;
+    Herm<M>& h = st.h;
     // The projector is invariant under R -> s R (s > 0): scale by an exact power of two so that the
     // largest diagonal entry lies in [0.5,1) (R is PSD, so every |R_ij| <= that).  LAPACK's zheev
     // (behind the reference's eig_sym, .cc:90) likewise rescales out-of-range matrices.
@@ -458,23 +467,34 @@ __device__ __forceinline__ void evd_project_lane(GetR getR, const bool valid, co
             h.Vr[i][j] = (i == j) ? 1.0 : 0.0;
             h.Vi[i][j] = 0.0;
         }
-
-    for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
-        double off = 0.0, dia = 0.0;
-#pragma unroll
-        for (int i = 0; i < M; ++i) {
-            dia += h.D[i] * h.D[i];
-#pragma unroll
-            for (int j = i + 1; j < M; ++j) off += h.Ur[i][j] * h.Ur[i][j] + h.Ui[i][j] * h.Ui[i][j];
-        }
-        const bool done = !(off > 1e-33 * dia);   // also true for NaN input -> bounded loop either way
-        if (__all(done)) break;
-        jacobi_sweep<M>(h, !done);
-    }
     // A covariance with NaN/Inf entries has no eigen-decomposition (the reference's eig_sym fails there): poison the
     // projector so that the item's spectrum is NaN and no bin is ever inserted (.cc:131) -> (0, 0) outputs.
-    const double poison = psum * 0.0;             // NaN iff some entry is NaN or +-Inf, else +-0
+    st.poison = psum * 0.0;
+    st.done = false;
+}
 
+// Convergence test at the head of a sweep: sets st.done, returns true when every lane of the wave is done.
+template <int M>
+__device__ __forceinline__ bool evd_check(EvdState<M>& st)
+{
+    const Herm<M>& h = st.h;
+    double off = 0.0, dia = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        dia += h.D[i] * h.D[i];
+#pragma unroll
+        for (int j = i + 1; j < M; ++j) off += h.Ur[i][j] * h.Ur[i][j] + h.Ui[i][j] * h.Ui[i][j];
+    }
+    st.done = !(off > 1e-33 * dia);               // also true for NaN input -> bounded loop either way
+    return __all(st.done);
+}
+
+template <int M>
+__device__ __forceinline__ void evd_finish(const EvdState<M>& st, const bool valid, const uint32_t item, const uint32_t n,
+                                           const uint32_t qstride, double* __restrict__ Qs, double* __restrict__ Gs)
+{
+    const Herm<M>& h = st.h;
+    const double poison = st.poison;
     // ascending rank of each eigenvalue (ties -> lower column first), noise = rank < m-n
     double wk[M];
 #pragma unroll
@@ -517,6 +537,23 @@ __device__ __forceinline__ void evd_project_lane(GetR getR, const bool valid, co
                 }
             }
         }
+}
+
+// (An orthogonal-iteration form of this function for n <= m/2 -- the m <= 4 counterpart of evd_sub_kernel, section 2c --
+// was built and measured: 7 steps of ~380 instructions instead of ~4,900 at cfg2 / 20 dB, yet only 1.127 -> 1.120 ms per
+// step, because its inner products are dependent fp64 chains where the rotations have 4-way ILP, and 1.3 % slower at
+// 0 dB where the iteration is abandoned after 3 steps.  Not shipped; profiles/r02_subspace_iteration.txt.)
+template <int M, class GetR>
+__device__ __forceinline__ void evd_project_lane(GetR getR, const bool valid, const uint32_t item, const uint32_t n,
+                                                 const uint32_t qstride, double* __restrict__ Qs, double* __restrict__ Gs)
+{
+    EvdState<M> st;
+    evd_begin<M>(getR, st);
+    for (int sweep = 0; sweep < EVD_MAX_SWEEPS; ++sweep) {
+        if (evd_check<M>(st)) break;
+        jacobi_sweep<M>(st.h, !st.done);
+    }
+    evd_finish<M>(st, valid, item, n, qstride, Qs, Gs);
 }
 
 template <int M>

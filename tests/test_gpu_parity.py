@@ -347,6 +347,61 @@ def test_fused_covariance_evd_kernel_equals_the_two_kernel_form(gpu_device, monk
     assert_doa_match(outs[0][0][:B], outs[0][1][:B], g["ang"], g["lvl"], g["res"], g["strength64"])
 
 
+# ------------------------------------------------------------------ signal subspace by orthogonal iteration (m >= 5, n <= 3)
+@pytest.mark.parametrize("m,n,K,res", [(8, 2, 64, 360), (16, 2, 64, 360), (6, 3, 50, 200), (9, 1, 40, 180), (16, 3, 48, 500),
+                                        (5, 2, 32, 90), (13, 2, 30, 77)])
+def test_signal_subspace_iteration_and_its_hand_back(m, n, K, res, gpu_device, monkeypatch):
+    """evd_sub_kernel finds the projector from the n dominant eigenvectors by orthogonal iteration and hands items with a
+    small gap lambda_n / lambda_(n+1) back to the Jacobi.  A batch that mixes easy items (30 / 20 dB), slow ones (0 and
+    -10 dB), items with FEWER emitters than n (gap ~ 1), a noise-only item and an all-zero item must give the projector
+    of the Jacobi-only build to 1e-12, the oracle's spectra to 1e-5, and bits that do not depend on the item's
+    neighbours in the wave."""
+    N = m * K
+    arr = mo.array_geometry(m)
+    table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
+    ang_n = tuple(np.linspace(25.0, 290.0, n))
+    parts = [mo.synth_items(6, m, N, arr, mo.FREQUENCY, mo.SPACING, angles_deg=ang_n, snr_db=snr, seed=900 + 7 * i + m)
+             for i, snr in enumerate((30.0, 20.0, 0.0, -10.0))]
+    parts.append(mo.synth_items(5, m, N, arr, mo.FREQUENCY, mo.SPACING, angles_deg=ang_n[:max(n - 1, 0)] or (), snr_db=20.0,
+                                seed=950 + m))                                  # fewer emitters than n (noise only at n = 1)
+    parts.append(np.zeros((1, N), np.complex64))
+    items = np.concatenate(parts)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(items.shape[0])
+    B = items.shape[0]
+    torch = _torch()
+
+    def taps(ctx, its):
+        x = torch.from_numpy(np.ascontiguousarray(its).view(np.float32)).to(gpu_device)
+        qs = _capi().lib().baz_music_q_stride(its.shape[0])
+        Q = torch.zeros(m * m, qs, dtype=torch.float64, device=gpu_device)
+        ctx.debug_q(x.data_ptr(), its.shape[0], Q.data_ptr())
+        ctx.sync()
+        return Q.cpu().numpy()[:, :its.shape[0]]
+
+    res_by_mode = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BAZ_MUSIC_SUB_EVD", mode)
+        with _capi().Context(m, n, N, res, table) as ctx:
+            out = device_run(ctx, items, gpu_device)
+            outp = device_run(ctx, items[perm], gpu_device)
+            one = [device_run(ctx, items[i:i + 1], gpu_device) for i in (0, 13, B - 1)]
+            Q = taps(ctx, items)
+        res_by_mode[mode] = (out, outp, one, Q)
+    out, outp, one, Q1 = res_by_mode["1"]
+    Q0 = res_by_mode["0"][3]
+    assert np.abs(Q1 - Q0).max() < 1e-12                      # same projector either way (basis-invariant)
+    for x, y in zip(out, outp):                               # an item's bits do not depend on its wave-mates
+        assert np.array_equal(x[perm], y)
+    for k, i in enumerate((0, 13, B - 1)):
+        for x, y in zip(out, one[k]):
+            assert np.array_equal(x[i:i + 1], y)
+    ao, lo, so, st = mo.music_doa_work_batch(items[:-1], table, m, n)       # (the zero item: eigh's basis is arbitrary)
+    assert_spectrum_close(out[2][:-1], so)
+    assert_doa_match(out[0][:-1], out[1][:-1], ao, lo, res, st)
+    assert np.array_equal(out[2][-1], res_by_mode["0"][0][2][-1])            # zero item: handed back -> the Jacobi's answer
+
+
 # ------------------------------------------------------------------ bin ranges per row in the scan
 @pytest.mark.parametrize("name", ["cfg1_m4_n2_N256_r360", "cfg2_m4_n2_N1024_r3600", "m7_n4_N700_r500", "m12_n9_N1200_r720",
                                   "odd_m3_n1_N300_r357"])
