@@ -268,7 +268,9 @@ def extra_cfg5(torch, np, capi, synth, dev, stream, nitems, seconds):
             "complex_samples_per_s_per_antenna": T_out / ms * 1e3,
             "engine_ms": {"resampler": eng[0], "agc_interleave": eng[1], "music": eng[2]},
             "music_stage_ms": dict(zip(("cov", "evd", "scan", "merge"), st)),
-            "bound": "fp64 VALU issue (16x16 Jacobi EVD) + hbm (front-end)",
+            "bound": "hbm (front-end: resampler + AGC) + fp64 matrix (scan); the EVD is the n = 2 signal subspace by "
+                     "orthogonal iteration (evd_sub_kernel), Jacobi only for items it hands back",
+            "scan_fp64_tflops": 2.0 * m * m * res * nitems / (st[2] * 1e-3) / 1e12 if st[2] > 0 else None,
             "resampler_GBs": (in_b + rs_b) / eng[0] / 1e6, "agc_GBs": (rs_b + 2 * nitems * N * 8) / eng[1] / 1e6,
             "chain_bytes_per_step": chain_bytes, "chain_hbm_fraction_of_8TBs": chain_bytes / (ms * 1e-3) / 8e12}
 
