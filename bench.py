@@ -406,13 +406,14 @@ def main():
         x4 = "cov4_" in cov_name
         fused = "cov4_evd" in cov_name
         cov_mfma = {"kernel": cov_name,
-                    "kernel_also_does": "the batched 4x4 Hermitian EVD of the same items (fp64 VALU at low wave priority, "
-                                        "no HBM traffic): the rates below divide by the WHOLE kernel's time" if fused else None, "useful_tflops": cov_tf, "fp64_matrix_peak_tflops": FP64_MFMA_PEAK_TF,
+                    "kernel_also_does": "the batched 4x4 Hermitian EVD of the same items: ~0.08 ms of fp64 VALU phases during "
+                                        "which HBM idles (DESIGN.md 5.2a); the rates below divide by the WHOLE kernel's "
+                                        "time, the stream alone runs at ~7 TB/s" if fused else None, "useful_tflops": cov_tf, "fp64_matrix_peak_tflops": FP64_MFMA_PEAK_TF,
                     "frac_of_peak": cov_tf / FP64_MFMA_PEAK_TF, "issued_over_useful": 4.0 / 3.0 if x4 else 2.0,
                     "hbm_read_GBs": 8.0 * NSAMPLES * batch / cov_s / 1e9 if cov_s > 0 else 0.0,
                     "hbm_read_frac_of_8TBs": 8.0 * NSAMPLES * batch / cov_s / 1e9 / HBM_PEAK_GBS if cov_s > 0 else 0.0,
                     "note": ("v_mfma_f64_4x4x4_4b blocks: X0X0^T, X0X1^T, X1X1^T + one transposed duplicate per pair of "
-                             "instructions; dwordx4 input stream; the kernel is HBM-read bound") if x4 else
+                             "instructions; dwordx4 input stream; HBM-read bound while it streams") if x4 else
                             ("16x16x4 fp64 MFMA tiles hold 2 items block-diagonally at m=4 (half the issued flops are "
                              "structural zeros); the kernel is HBM-read bound")}
         per_round = [t / args.steps * 1e3 for t in rounds]
