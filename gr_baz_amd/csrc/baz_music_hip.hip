@@ -85,6 +85,9 @@ struct baz_music_ctx {
     float2* dTA = nullptr;         // steering table transposed, [m][res] complex64
     double2* dGw = nullptr;        // noise eigenvectors, [items][m - n][m]
     double* dWS = nullptr;         // fp64 strengths, [items][res] (the top-n's input)
+    double2* dSw = nullptr;        // signal eigenvectors, [items][n][m] (the scan's short form where 2n <= m)
+    double* dA2 = nullptr;         // ||a||^2 per bin
+    int wide_literal_only = 0;     // lab (BAZ_MUSIC_WIDE_LITERAL=1): no short form in scan_wide_kernel
     uint32_t wide_cap = 0;         // items the three buffers above (and dR) hold
     uint8_t* dRedo = nullptr;      // [cap] items evd_sub_kernel hands back to the Jacobi
     int sub_evd = 1;               // signal subspace by orthogonal iteration where n <= 3 (lab: BAZ_MUSIC_SUB_EVD=0)
@@ -549,11 +552,15 @@ int ensure_wide_workspace(baz_music_ctx* c, uint32_t items)
     if (c->dR) { (void)hipFree(c->dR); c->dR = nullptr; }
     if (c->dGw) { (void)hipFree(c->dGw); c->dGw = nullptr; }
     if (c->dWS) { (void)hipFree(c->dWS); c->dWS = nullptr; }
+    if (c->dSw) { (void)hipFree(c->dSw); c->dSw = nullptr; }
     c->wide_cap = 0;
     const size_t mm = (size_t)c->m * c->m;
     HIP_TRY(c, hipMalloc((void**)&c->dR, (size_t)items * mm * sizeof(double2)));
     HIP_TRY(c, hipMalloc((void**)&c->dGw, (size_t)items * (c->m - c->n) * c->m * sizeof(double2)));
     HIP_TRY(c, hipMalloc((void**)&c->dWS, (size_t)items * c->res * sizeof(double)));
+    HIP_TRY(c, hipMalloc((void**)&c->dSw, (size_t)items * c->n * c->m * sizeof(double2)));
+    if (c->dRedo) { (void)hipFree(c->dRedo); c->dRedo = nullptr; }
+    HIP_TRY(c, hipMalloc((void**)&c->dRedo, (size_t)items));
     c->wide_cap = items;
     return BAZ_MUSIC_OK;
 }
@@ -583,8 +590,17 @@ int process_wide_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void
         if (r) return r;
         {
             ProfScope ps(c, BAZ_MUSIC_STAGE_EVD);
+            const uint8_t* only = nullptr;
+            if (c->sub_evd && c->n <= 3) {     // few emitters: signal subspace by orthogonal iteration, Jacobi for what it hands back
+                const size_t lds = ((size_t)c->m * (c->m + 1) + (size_t)c->n * 64) * sizeof(double2);
+                if (c->n == 1) hipLaunchKernelGGL(bazwide::sub_wide_kernel<1>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
+                else if (c->n == 2) hipLaunchKernelGGL(bazwide::sub_wide_kernel<2>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
+                else hipLaunchKernelGGL(bazwide::sub_wide_kernel<3>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
+                HIP_TRY(c, hipGetLastError());
+                only = c->dRedo;
+            }
             hipLaunchKernelGGL(bazwide::evd_wide_kernel, dim3(nb), dim3(bazwide::WB), wide_evd_lds(c->m), c->stream, c->dR,
-                               c->dGw, c->m, c->n);
+                               c->dGw, c->dSw, c->m, c->n, only);
             HIP_TRY(c, hipGetLastError());
         }
         {
@@ -593,8 +609,10 @@ int process_wide_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void
             const uint32_t max_y = (c->res + bazwide::WB - 1) / bazwide::WB;
             const uint32_t ny = std::max(1u, std::min(max_y, (2048u + nb - 1) / nb));
             const uint32_t bpb = round_up((c->res + ny - 1) / ny, bazwide::WB);
+            const bool short_form = 2 * c->n <= c->m && !c->wide_literal_only;     // few emitters: ||a||^2 - ||S^H a||^2 away from the nulls
             hipLaunchKernelGGL(bazwide::scan_wide_kernel, dim3(nb, (c->res + bpb - 1) / bpb), dim3(bazwide::WB),
-                               (size_t)nn * c->m * sizeof(double2), c->stream, c->dGw, c->dTA, c->dWS,
+                               (size_t)(nn + (short_form ? c->n : 0u)) * c->m * sizeof(double2), c->stream, c->dGw,
+                               short_form ? c->dSw : nullptr, c->dTA, c->dA2, c->refine_below, c->dWS,
                                spec ? spec + (size_t)off * c->res : nullptr, c->m, c->n, c->res, bpb);
             HIP_TRY(c, hipGetLastError());
         }
@@ -616,8 +634,21 @@ int upload_table_wide(baz_music_ctx* c, const float* table_ri)
             ta[2 * ((size_t)i * c->res + b)] = table_ri[2 * ((size_t)b * c->m + i)];
             ta[2 * ((size_t)i * c->res + b) + 1] = table_ri[2 * ((size_t)b * c->m + i) + 1];
         }
+    std::vector<double> a2(c->res);
+    double amax2 = 0.0;
+    for (uint32_t b = 0; b < c->res; ++b) {
+        double v = 0.0;
+        for (uint32_t i = 0; i < c->m; ++i) {
+            const double re = table_ri[2 * ((size_t)b * c->m + i)], im = table_ri[2 * ((size_t)b * c->m + i) + 1];
+            v += re * re + im * im;
+        }
+        a2[b] = v;
+        if (v > amax2 && v < 1e300) amax2 = v;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // no batch in flight reads the old table
     HIP_TRY(c, hipMemcpy(c->dTA, ta.data(), ta.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->dA2, a2.data(), a2.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->refine_below = amax2 * (double)c->m * 1e-8;        // the threshold of the specialised kernels' refinement
     return BAZ_MUSIC_OK;
 }
 
@@ -801,10 +832,21 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(bazwide::evd_wide_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_evd_lds(m)) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(bazwide::scan_wide_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)(m - n) * m * sizeof(double2))) != hipSuccess) {
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)m * m * sizeof(double2))) != hipSuccess) {
                 r = BAZ_MUSIC_E_HIP; break;
             }
+            {
+                const int sub_lds = (int)(((size_t)m * (m + 1) + (size_t)std::min(n, 3u) * 64) * sizeof(double2));
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(bazwide::sub_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, sub_lds) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(bazwide::sub_wide_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, sub_lds) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(bazwide::sub_wide_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, sub_lds) != hipSuccess) {
+                    r = BAZ_MUSIC_E_HIP; break;
+                }
+            }
+            if (const char* v = getenv("BAZ_MUSIC_SUB_EVD")) c->sub_evd = atoi(v);                   // lab / tests
             if (hipMalloc((void**)&c->dTA, (size_t)m * resolution * sizeof(float2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+            if (hipMalloc((void**)&c->dA2, (size_t)resolution * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+            if (const char* v = getenv("BAZ_MUSIC_WIDE_LITERAL")) c->wide_literal_only = atoi(v);   // lab / tests
             if (hipMalloc((void**)&c->dRefined, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMemset(c->dRefined, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
             r = upload_table(c, table_ri);
@@ -899,6 +941,8 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->dTA) (void)hipFree(c->dTA);
         if (c->dGw) (void)hipFree(c->dGw);
         if (c->dWS) (void)hipFree(c->dWS);
+        if (c->dSw) (void)hipFree(c->dSw);
+        if (c->dA2) (void)hipFree(c->dA2);
         free_slots(c);
         if (c->ev_in) (void)hipEventDestroy(c->ev_in);
         if (c->ev_out) (void)hipEventDestroy(c->ev_out);

@@ -7,12 +7,16 @@
 // evaluated directly (no projector, hence no refinement pass either).
 //     cov_wide_kernel    .cc:74-85    R = x x^H / K                       (exact fp32 products, fp64 sums)
 //     evd_wide_kernel    .cc:88-93    Hermitian Jacobi in tournament rounds -> the m-n noise eigenvectors G
-//     scan_wide_kernel   .cc:104-121  strength = 1 / norm(G^H a)^2 per bin, in the reference's operation order
+//     sub_wide_kernel    (few emitters) the signal subspace by orthogonal iteration; the Jacobi only for what it hands back
+//     scan_wide_kernel   .cc:104-121  strength = 1 / norm(G^H a)^2 per bin: ||a||^2 - ||S^H a||^2 where that is accurate,
+//                                     the reference's literal form near the nulls
 //     topn_wide_kernel   .cc:95,129-160  n strongest bins on the fp64 strengths, earlier bin first on ties
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "music_kernels.hip.h"     // dpp_f64, cmul / cmulc
 
 namespace bazwide {
 
@@ -87,11 +91,13 @@ __device__ __forceinline__ double block_sum(double v, double* red)
     return r;
 }
 
-__global__ __launch_bounds__(WB) void evd_wide_kernel(const double2* __restrict__ R, double2* __restrict__ G, uint32_t m,
-                                                      uint32_t n)
+__global__ __launch_bounds__(WB) void evd_wide_kernel(const double2* __restrict__ R, double2* __restrict__ G,
+                                                      double2* __restrict__ Ssig, uint32_t m, uint32_t n,
+                                                      const uint8_t* __restrict__ only)
 {
     extern __shared__ double2 sm2[];
     const uint32_t item = blockIdx.x, tid = threadIdx.x;
+    if (only && !only[item]) return;                     // behind sub_wide_kernel: just the items it handed back
     const uint32_t ld = m + 1, me = m + (m & 1u), np = me / 2;
     double2* A = sm2;                                    // [m][ld]
     double2* V = A + (size_t)m * ld;                     // [m][ld]
@@ -231,6 +237,213 @@ __global__ __launch_bounds__(WB) void evd_wide_kernel(const double2* __restrict_
         const double2 v = V[i * ld + sel[k]];
         G[((size_t)item * nn + k) * m + i] = make_double2(v.x + poison, v.y + poison);
     }
+    if (Ssig)      // the signal eigenvectors (rank >= m - n), for the scan's short form
+        for (uint32_t e = tid; e < n * m; e += WB) {
+            const uint32_t k = e / m, i = e - k * m;
+            const double2 v = V[i * ld + sel[nn + k]];
+            Ssig[((size_t)item * n + k) * m + i] = make_double2(v.x + poison, v.y + poison);
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2b. The noise basis WITHOUT the eigen-decomposition for few emitters (P = n <= 3): the signal subspace by orthogonal
+//     iteration, exactly the scheme of bazmusic::evd_sub_kernel (music_kernels.hip.h, section 2c) with m at run time:
+//     one wave per item, lane j = row j (m <= 64), R in LDS, all reductions XOR butterflies over the 64 lanes (DPP inside
+//     a row of 16, then lane ^ 16 and lane ^ 32: every lane ends with the same bits).  Items that do not converge are
+//     flagged in `redo` and take evd_wide_kernel (launched with only = redo).  At m = 64 a step is ~64 LDS reads and ~600
+//     instructions per lane against ~40 x 63 workgroup-synchronised rounds of the Jacobi.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_allsum(double v)
+{
+    using bazmusic::dpp_f64;
+    v += dpp_f64<0x140>(v);                // row_mirror       lane ^ 15
+    v += dpp_f64<0x141>(v);                // row_half_mirror  lane ^ 7
+    v += dpp_f64<0x1B>(v);                 // quad_perm [3,2,1,0]
+    v += dpp_f64<0xB1>(v);                 // quad_perm [1,0,3,2]
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+__device__ __forceinline__ double wave_allmax(double v)
+{
+    using bazmusic::dpp_f64;
+    v = fmax(v, dpp_f64<0x140>(v));
+    v = fmax(v, dpp_f64<0x141>(v));
+    v = fmax(v, dpp_f64<0x1B>(v));
+    v = fmax(v, dpp_f64<0xB1>(v));
+    v = fmax(v, __shfl_xor(v, 16));
+    v = fmax(v, __shfl_xor(v, 32));
+    return v;
+}
+
+template <int P>
+__global__ __launch_bounds__(64) void sub_wide_kernel(const double2* __restrict__ R, double2* __restrict__ G,
+                                                      double2* __restrict__ Ssig, uint8_t* __restrict__ redo, uint32_t m)
+{
+    using bazmusic::cmul;
+    using bazmusic::cmulc;
+    constexpr int MAX_IT = 64;
+    constexpr double BAIL2 = 0.36, TOL2 = 1.6e-29 * P;     // as evd_sub_kernel for m > 8
+    extern __shared__ double2 sw[];
+    const uint32_t item = blockIdx.x;
+    const int j = threadIdx.x;
+    const uint32_t ld = m + 1;
+    double2* sR = sw;                                      // [m][ld]: row j is read by lane j only
+    double2* sY = sR + (size_t)m * ld;                     // [P][64]
+    const bool row = (uint32_t)j < m;
+
+    double psum = 0.0, dj = 0.0;
+    if (row) {
+        for (uint32_t k = 0; k < m; ++k) {
+            double2 v = R[((size_t)item * m + j) * m + k];
+            psum += v.x + v.y;
+            if (k == (uint32_t)j) { v.y = 0.0; dj = fabs(v.x); }
+            sR[j * ld + k] = v;
+        }
+    }
+    const double poison = wave_allsum(psum * 0.0);
+    const double dmax = wave_allmax(dj);
+    int ex = 0;
+    (void)frexp(dmax, &ex);
+    const double scl = (dmax > 0.0 && dmax < __builtin_huge_val()) ? ldexp(1.0, -ex) : 1.0;
+    if (row)
+        for (uint32_t k = 0; k < m; ++k) { double2 v = sR[j * ld + k]; v.x *= scl; v.y *= scl; sR[j * ld + k] = v; }
+
+    auto orth = [&](double2 (&z)[P], double2 (&yn)[P]) -> bool {
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+                for (int c2 = 0; c2 < c; ++c2) {
+                    const double2 t = cmulc(z[c], yn[c2]);
+                    const double hr = wave_allsum(t.x), hi = wave_allsum(t.y);
+                    z[c].x -= hr * yn[c2].x - hi * yn[c2].y;
+                    z[c].y -= hr * yn[c2].y + hi * yn[c2].x;
+                }
+            const double n2 = wave_allsum(z[c].x * z[c].x + z[c].y * z[c].y);
+            const bool good = n2 > 0.0 && n2 < __builtin_huge_val();
+            ok = ok && good;
+            const double inv = good ? 1.0 / sqrt(n2) : 0.0;
+            yn[c] = make_double2(z[c].x * inv, z[c].y * inv);
+        }
+        return ok;
+    };
+
+    double2 y[P], z[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) z[c] = row ? sR[j * ld + c] : make_double2(0.0, 0.0);
+    bool ok = orth(z, y) && !(poison != poison);
+    bool conv = false;
+    double d2prev = __builtin_huge_val();
+    for (int it = 0; it < MAX_IT && ok && !conv; ++it) {   // (one item per wave: the conditions are wave-uniform)
+        bazmusic::wave_lds_fence();
+#pragma unroll
+        for (int c = 0; c < P; ++c) sY[c * 64 + j] = y[c];
+        bazmusic::wave_lds_fence();
+#pragma unroll
+        for (int c = 0; c < P; ++c) z[c] = make_double2(0.0, 0.0);
+        if (row) {
+            for (uint32_t k = 0; k < m; ++k) {
+                const double2 r = sR[j * ld + k];
+#pragma unroll
+                for (int c = 0; c < P; ++c) {
+                    const double2 yk = sY[c * 64 + k];
+                    z[c].x += r.x * yk.x - r.y * yk.y;
+                    z[c].y += r.x * yk.y + r.y * yk.x;
+                }
+            }
+        }
+        double2 yn[P];
+        const bool ok2 = orth(z, yn);
+        double dloc = 0.0;
+#pragma unroll
+        for (int b = 0; b < P; ++b) {
+            double2 d = yn[b];
+#pragma unroll
+            for (int a = 0; a < P; ++a) {
+                const double2 t = cmulc(yn[b], y[a]);
+                const double cr = wave_allsum(t.x), ci = wave_allsum(t.y);
+                d.x -= y[a].x * cr - y[a].y * ci;
+                d.y -= y[a].x * ci + y[a].y * cr;
+            }
+            dloc += d.x * d.x + d.y * d.y;
+        }
+        const double d2 = wave_allsum(dloc);
+        ok = ok2 && (d2 == d2);
+#pragma unroll
+        for (int c = 0; c < P; ++c) y[c] = yn[c];
+        if (ok && d2 <= TOL2) conv = true;
+        else if (it >= 2 && d2 > 100.0 * TOL2 && d2 > BAIL2 * d2prev) ok = false;
+        d2prev = d2;
+    }
+    if (j == 0) redo[item] = conv ? 0 : 1;
+    if (!conv) return;
+    if (Ssig && row) {
+#pragma unroll
+        for (int c = 0; c < P; ++c) Ssig[((size_t)item * P + c) * m + j] = y[c];
+    }
+
+    // Householder completion of S (see evd_sub_kernel): G rows = columns P .. m-1 of H_0 .. H_{P-1}
+    double2 v[P], w[P];
+    double tau[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) w[c] = y[c];
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+        const bool in = row && j >= c;
+        const double2 x = in ? w[c] : make_double2(0.0, 0.0);
+        const double nx2 = wave_allsum(x.x * x.x + x.y * x.y);
+        const double xcr = wave_allsum(j == c ? x.x : 0.0), xci = wave_allsum(j == c ? x.y : 0.0);
+        const double nx = sqrt(nx2), ax = sqrt(xcr * xcr + xci * xci);
+        const double pr = ax > 0.0 ? xcr / ax : 1.0, pi = ax > 0.0 ? xci / ax : 0.0;
+        v[c] = x;
+        if (j == c) { v[c].x += pr * nx; v[c].y += pi * nx; }
+        const double nv2 = wave_allsum(v[c].x * v[c].x + v[c].y * v[c].y);
+        tau[c] = nv2 > 0.0 ? 2.0 / nv2 : 0.0;
+#pragma unroll
+        for (int b = c + 1; b < P; ++b) {
+            const double2 t = cmulc(w[b], v[c]);
+            const double sr = wave_allsum(t.x) * tau[c], si = wave_allsum(t.y) * tau[c];
+            w[b].x -= v[c].x * sr - v[c].y * si;
+            w[b].y -= v[c].x * si + v[c].y * sr;
+        }
+    }
+    double2 beta[P][P];
+#pragma unroll
+    for (int c = 0; c < P; ++c)
+#pragma unroll
+        for (int c2 = c + 1; c2 < P; ++c2) {
+            const double2 t = cmulc(v[c2], v[c]);
+            beta[c][c2] = make_double2(wave_allsum(t.x), wave_allsum(t.y));
+        }
+    bazmusic::wave_lds_fence();
+#pragma unroll
+    for (int c = 0; c < P; ++c) sY[c * 64 + j] = v[c];
+    bazmusic::wave_lds_fence();
+    if (row) {
+        const uint32_t nn = m - P;
+        for (uint32_t k = P; k < m; ++k) {
+            double2 coef[P];
+            double2 gk = make_double2((uint32_t)j == k ? 1.0 : 0.0, 0.0);
+#pragma unroll
+            for (int c = P - 1; c >= 0; --c) {
+                const double2 vk = sY[c * 64 + k];
+                double2 s = make_double2(vk.x, -vk.y);
+#pragma unroll
+                for (int c2 = c + 1; c2 < P; ++c2) {
+                    const double2 t = cmul(coef[c2], beta[c][c2]);
+                    s.x -= t.x; s.y -= t.y;
+                }
+                coef[c] = make_double2(tau[c] * s.x, tau[c] * s.y);
+                const double2 t = cmul(coef[c], v[c]);
+                gk.x -= t.x; gk.y -= t.y;
+            }
+            G[((size_t)item * nn + (k - P)) * m + j] = gk;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -239,38 +452,56 @@ __global__ __launch_bounds__(WB) void evd_wide_kernel(const double2* __restrict_
 //    ss = sum_k |c_k|^2, strength = 1 / pow(sqrt(ss), 2) (.cc:115-119), all fp64 like the reference; the fp64 strengths
 //    go to S (for the top-n), their fp32 casts to the spectrum port (.cc:120-121) when it is wired.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WB) void scan_wide_kernel(const double2* __restrict__ G, const float2* __restrict__ TA,
-                                                       double* __restrict__ S, float* __restrict__ spec, uint32_t m,
-                                                       uint32_t n, uint32_t res, uint32_t bins_per_block)
+__global__ __launch_bounds__(WB) void scan_wide_kernel(const double2* __restrict__ G, const double2* __restrict__ Ssig,
+                                                       const float2* __restrict__ TA, const double* __restrict__ A2,
+                                                       double below, double* __restrict__ S, float* __restrict__ spec,
+                                                       uint32_t m, uint32_t n, uint32_t res, uint32_t bins_per_block)
 {
-    extern __shared__ double2 sg[];            // [(m - n)][m]
+    extern __shared__ double2 sg[];            // [(m - n)][m] noise basis, then [n][m] signal basis (when Ssig)
     const uint32_t item = blockIdx.x, tid = threadIdx.x, nn = m - n;
+    double2* ssig = sg + (size_t)nn * m;
     for (uint32_t e = tid; e < nn * m; e += WB) sg[e] = G[(size_t)item * nn * m + e];
+    if (Ssig)
+        for (uint32_t e = tid; e < n * m; e += WB) ssig[e] = Ssig[(size_t)item * n * m + e];
     __syncthreads();
     const uint32_t b0 = blockIdx.y * bins_per_block;
     const uint32_t b1 = (b0 + bins_per_block < res) ? b0 + bins_per_block : res;
     constexpr int KC = 8;
     for (uint32_t b = b0 + tid; b < b1; b += WB) {
-        double ss = 0.0;
-        for (uint32_t k0 = 0; k0 < nn; k0 += KC) {
-            double cr[KC], ci[KC];
+        // sum_k |v_k^H a|^2 over the `cnt` vectors at `base`
+        auto proj = [&](const double2* base, uint32_t cnt) -> double {
+            double ss = 0.0;
+            for (uint32_t k0 = 0; k0 < cnt; k0 += KC) {
+                double cr[KC], ci[KC];
 #pragma unroll
-            for (int u = 0; u < KC; ++u) { cr[u] = 0.0; ci[u] = 0.0; }
-            for (uint32_t i = 0; i < m; ++i) {
-                const float2 af = TA[(size_t)i * res + b];
-                const double ar = (double)af.x, ai = (double)af.y;     // .cc:110-112 widens the fp32 table
+                for (int u = 0; u < KC; ++u) { cr[u] = 0.0; ci[u] = 0.0; }
+                for (uint32_t i = 0; i < m; ++i) {
+                    const float2 af = TA[(size_t)i * res + b];
+                    const double ar = (double)af.x, ai = (double)af.y;     // .cc:110-112 widens the fp32 table
 #pragma unroll
-                for (int u = 0; u < KC; ++u) {
-                    const uint32_t k = (k0 + u < nn) ? k0 + u : nn - 1;   // (clamped rows are not added below)
-                    const double2 g = sg[k * m + i];
-                    cr[u] += g.x * ar + g.y * ai;          // conj(g) a
-                    ci[u] += g.x * ai - g.y * ar;
+                    for (int u = 0; u < KC; ++u) {
+                        const uint32_t k = (k0 + u < cnt) ? k0 + u : cnt - 1;   // (clamped rows are not added below)
+                        const double2 g = base[k * m + i];
+                        cr[u] += g.x * ar + g.y * ai;          // conj(g) a
+                        ci[u] += g.x * ai - g.y * ar;
+                    }
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < KC; ++u)
-                if (k0 + u < nn) ss += cr[u] * cr[u] + ci[u] * ci[u];
+                for (int u = 0; u < KC; ++u)
+                    if (k0 + u < cnt) ss += cr[u] * cr[u] + ci[u] * ci[u];
+            }
+            return ss;
+        };
+        // Few emitters: ||G^H a||^2 = ||a||^2 - ||S^H a||^2 needs n instead of m - n inner products.  The difference loses
+        // ~m eps ||a||^2 absolutely, so it is kept only above `below` (= m 1e-8 max ||a||^2, the rule of the specialised
+        // kernels' refinement: relative error <~ 1e-7 there); at or below it -- near a null -- the literal form runs.
+        double ss = 0.0;
+        bool literal = true;
+        if (Ssig) {
+            const double dp = A2[b] - proj(ssig, n);
+            if (dp > below) { ss = dp; literal = false; }
         }
+        if (literal) ss = proj(sg, nn);
         const double nrm = sqrt(ss);
         const double strength = 1.0 / (nrm * nrm);
         S[(size_t)item * res + b] = strength;

@@ -175,6 +175,62 @@ def test_wide_arrays_match_the_oracle(m, n, N, res, batch, gpu_device):
     assert np.array_equal(Rg, Rg.conj().transpose(0, 2, 1))          # exactly Hermitian
 
 
+@pytest.mark.parametrize("m,n,K,res", [(24, 2, 40, 180), (40, 3, 48, 120), (64, 1, 64, 90)])
+def test_wide_arrays_subspace_iteration_and_hand_back(m, n, K, res, gpu_device, monkeypatch):
+    """the wide path's sub_wide_kernel against its Jacobi (BAZ_MUSIC_SUB_EVD=0) on a batch that mixes easy, slow and
+    rank-deficient items; bits independent of the batch around an item"""
+    N = m * K
+    arr = mo.array_geometry(m)
+    table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
+    ang_n = tuple(np.linspace(25.0, 290.0, n))
+    parts = [mo.synth_items(3, m, N, arr, mo.FREQUENCY, mo.SPACING, angles_deg=ang_n, snr_db=snr, seed=700 + 7 * i + m)
+             for i, snr in enumerate((30.0, 10.0, -10.0))]
+    parts.append(mo.synth_items(2, m, N, arr, mo.FREQUENCY, mo.SPACING, angles_deg=ang_n[:n - 1] or (), snr_db=20.0, seed=750 + m))
+    parts.append(np.zeros((1, N), np.complex64))
+    items = np.concatenate(parts)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BAZ_MUSIC_SUB_EVD", mode)
+        with _capi().Context(m, n, N, res, table) as ctx:
+            outs[mode] = (device_run(ctx, items, gpu_device), device_run(ctx, items[::-1].copy(), gpu_device),
+                          device_run(ctx, items[4:5], gpu_device))
+    full, rev, one = outs["1"]
+    for x, y in zip(full, rev):
+        assert np.array_equal(x[::-1], y)
+    for x, y in zip(full, one):
+        assert np.array_equal(x[4:5], y)
+    s1, s0 = full[2].astype(np.float64), outs["0"][0][2].astype(np.float64)
+    assert np.all(np.abs(s1 - s0) <= 2e-6 * np.abs(s0))            # same subspace either way (float32 spectra: 1-2 ulp)
+    ao, lo, so, st = mo.music_doa_work_batch(items[:-1], table, m, n)
+    assert_spectrum_close(full[2][:-1], so)
+    assert_doa_match(full[0][:-1], full[1][:-1], ao, lo, res, st)
+    assert np.array_equal(full[2][-1], outs["0"][0][2][-1])          # zero item: handed back -> the Jacobi's answer
+
+
+@pytest.mark.parametrize("m,n,K,res,snr", [(20, 2, 64, 720, 60.0), (32, 1, 48, 360, 100.0), (24, 3, 80, 500, 80.0), (18, 2, 64, 360, 20.0)])
+def test_wide_arrays_short_form_and_literal_form_agree(m, n, K, res, snr, gpu_device, monkeypatch):
+    """scan_wide_kernel evaluates ||a||^2 - ||S^H a||^2 away from the nulls and the reference's literal form near them:
+    up to 100 dB SNR (nulls 1e-10 of ||a||^2 deep) the spectrum must match the literal-only build and the oracle"""
+    N = m * K
+    arr = mo.array_geometry(m)
+    table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
+    bins = np.round(np.linspace(0.09, 0.84, n) * res)                       # emitters exactly on bins: the nulls are SNR-deep
+    items = mo.synth_items(8, m, N, arr, mo.FREQUENCY, mo.SPACING, angles_deg=tuple(bins * 360.0 / res), snr_db=snr,
+                           seed=31 * m + n)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("BAZ_MUSIC_WIDE_LITERAL", mode)
+        with _capi().Context(m, n, N, res, table) as ctx:
+            outs[mode] = device_run(ctx, items, gpu_device)
+    s_short, s_lit = outs["0"][2].astype(np.float64), outs["1"][2].astype(np.float64)
+    assert np.all(np.abs(s_short - s_lit) <= 3e-6 * s_lit)
+    assert np.array_equal(outs["0"][0], outs["1"][0]) or np.abs(s_short - s_lit).max() > 0      # same bins unless a tie moved
+    ao, lo, so, st = mo.music_doa_work_batch(items, table, m, n)
+    assert_spectrum_close(outs["0"][2], so)
+    assert_doa_match(outs["0"][0], outs["0"][1], ao, lo, res, st)
+    assert so.max() / np.median(so) > (1e5 if snr >= 60 else 10)        # the peaks really are that sharp
+
+
 def test_wide_arrays_top_n_and_non_finite_items(gpu_device):
     """the wide path's own top-n: exact ties keep the earlier bin, an item with a NaN sample yields (0, 0) pairs and
     a NaN spectrum, its neighbours are untouched"""

@@ -84,7 +84,8 @@ def test_no_device_is_a_loud_runtime_error():
 
 # --------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["cfg1_m4_n2_N256_r360", "grc_default_ula", "m5_n3_N1000_r720", "cfg3_m8_n2_N4096_r36000"])
+@pytest.mark.parametrize("name", ["cfg1_m4_n2_N256_r360", "grc_default_ula", "m5_n3_N1000_r720", "cfg3_m8_n2_N4096_r36000",
+                                  "cfg5_m16_n2_N4096_r3600", "wide_m17_n2_N816_r360", "wide_m33_n32_N2112_r90"])
 def test_host_block_work_matches_golden(name, gpu_device, capfd):
     g = load_golden(name)
     blk = _baz().music_doa(g["m"], g["n"], g["nsamples"], [list(map(complex, r)) for r in g["table"]], g["res"])
