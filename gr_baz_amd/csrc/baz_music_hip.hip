@@ -829,19 +829,21 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         c->wide = wide;
         if (wide) {   // run-time-m kernels: only the transposed table and the statistic counters (which stay 0)
             if (resolution > (1u << 20)) { r = BAZ_MUSIC_E_UNSUPPORTED; break; }
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(bazwide::evd_wide_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_evd_lds(m)) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(bazwide::scan_wide_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)m * m * sizeof(double2))) != hipSuccess) {
-                r = BAZ_MUSIC_E_HIP; break;
-            }
-            {
-                const int sub_lds = (int)(((size_t)m * (m + 1) + (size_t)std::min(n, 3u) * 64) * sizeof(double2));
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(bazwide::sub_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, sub_lds) != hipSuccess ||
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(bazwide::sub_wide_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, sub_lds) != hipSuccess ||
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(bazwide::sub_wide_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, sub_lds) != hipSuccess) {
-                    r = BAZ_MUSIC_E_HIP; break;
-                }
+            {   // dynamic LDS beyond 64 KiB needs the attribute; it is per FUNCTION (shared by every context of the process),
+                // so it is always set for the largest m, never for this context's
+                constexpr uint32_t MX = BAZ_MUSIC_MAX_M;
+                const int evd_lds = (int)wide_evd_lds(MX), scan_lds = (int)((size_t)MX * MX * sizeof(double2));
+                const int sub_lds = (int)(((size_t)MX * (MX + 1) + 3u * 64u) * sizeof(double2));
+                const void* fn[5] = {reinterpret_cast<const void*>(bazwide::evd_wide_kernel),
+                                     reinterpret_cast<const void*>(bazwide::scan_wide_kernel),
+                                     reinterpret_cast<const void*>(bazwide::sub_wide_kernel<1>),
+                                     reinterpret_cast<const void*>(bazwide::sub_wide_kernel<2>),
+                                     reinterpret_cast<const void*>(bazwide::sub_wide_kernel<3>)};
+                const int sz[5] = {evd_lds, scan_lds, sub_lds, sub_lds, sub_lds};
+                bool ok = true;
+                for (int k = 0; k < 5; ++k)
+                    ok = ok && hipFuncSetAttribute(fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, sz[k]) == hipSuccess;
+                if (!ok) { r = BAZ_MUSIC_E_HIP; break; }
             }
             if (const char* v = getenv("BAZ_MUSIC_SUB_EVD")) c->sub_evd = atoi(v);                   // lab / tests
             if (hipMalloc((void**)&c->dTA, (size_t)m * resolution * sizeof(float2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }

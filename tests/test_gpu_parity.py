@@ -231,6 +231,27 @@ def test_wide_arrays_short_form_and_literal_form_agree(m, n, K, res, snr, gpu_de
     assert so.max() / np.median(so) > (1e5 if snr >= 60 else 10)        # the peaks really are that sharp
 
 
+def test_wide_contexts_of_different_sizes_coexist(gpu_device):
+    """the run-time-m kernels use more than 64 KiB of dynamic LDS at m = 64, a per-function attribute: a small wide
+    context created AFTER a large one must not shrink it"""
+    cfgs = []
+    for m, n, K, res in ((64, 2, 64, 90), (20, 2, 32, 90)):
+        arr = mo.array_geometry(m)
+        table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
+        items = mo.synth_items(3, m, m * K, arr, mo.FREQUENCY, mo.SPACING, snr_db=20.0, seed=m)
+        cfgs.append((m, n, m * K, res, table, items))
+    big = _capi().Context(*cfgs[0][:5])
+    small = _capi().Context(*cfgs[1][:5])
+    try:
+        for ctx, c in ((big, cfgs[0]), (small, cfgs[1]), (big, cfgs[0])):
+            ang, lvl, spec = device_run(ctx, c[5], gpu_device)
+            ao, lo, so, st = mo.music_doa_work_batch(c[5], c[4], c[0], c[1])
+            assert_spectrum_close(spec, so)
+            assert_doa_match(ang, lvl, ao, lo, c[3], st)
+    finally:
+        small.close(); big.close()
+
+
 def test_wide_arrays_top_n_and_non_finite_items(gpu_device):
     """the wide path's own top-n: exact ties keep the earlier bin, an item with a NaN sample yields (0, 0) pairs and
     a NaN spectrum, its neighbours are untouched"""
