@@ -89,6 +89,9 @@ struct baz_music_ctx {
     double* dA2 = nullptr;         // ||a||^2 per bin
     int wide_literal_only = 0;     // lab (BAZ_MUSIC_WIDE_LITERAL=1): no short form in scan_wide_kernel
     uint32_t wide_cap = 0;         // items the three buffers above (and dR) hold
+    double* dSs = nullptr;         // m >= 9, n = 2: coefficient vectors of the scan's short form, [4 * 2m][q_stride]
+    double* dA2p = nullptr;        // ... and ||a||^2 per bin, padded like dFB (fb_steps + 2 steps of 64)
+    int sig_scan = 1;              // lab / tests: BAZ_MUSIC_SIG_SCAN=0 keeps the projector GEMM
     uint8_t* dRedo = nullptr;      // [cap] items evd_sub_kernel hands back to the Jacobi
     int sub_evd = 1;               // signal subspace by orthogonal iteration where n <= 3 (lab: BAZ_MUSIC_SUB_EVD=0)
     int fused_covevd = 0;          // m = 4, K % 256 == 0: covariance + EVD in one kernel (BAZ_MUSIC_FUSE=0: lab, two kernels)
@@ -213,12 +216,15 @@ int ensure_workspace(baz_music_ctx* c, uint32_t batch)
     if (c->dQ) { (void)hipFree(c->dQ); c->dQ = nullptr; }
     if (c->dG) { (void)hipFree(c->dG); c->dG = nullptr; }
     if (c->dRedo) { (void)hipFree(c->dRedo); c->dRedo = nullptr; }
+    if (c->dSs) { (void)hipFree(c->dSs); c->dSs = nullptr; }
     c->cap = 0;
     HIP_TRY(c, hipMalloc((void**)&c->dR, (size_t)cap * mm * sizeof(double2)));
     HIP_TRY(c, hipMalloc((void**)&c->dQ, (size_t)cap * mm * sizeof(double)));
     HIP_TRY(c, hipMalloc((void**)&c->dG, (size_t)cap * mm * 2 * sizeof(double)));
     if (c->dRedo) { (void)hipFree(c->dRedo); c->dRedo = nullptr; }
     HIP_TRY(c, hipMalloc((void**)&c->dRedo, (size_t)cap));
+    if (c->dSs) { (void)hipFree(c->dSs); c->dSs = nullptr; }
+    if (c->m >= 9 && c->n == 2) HIP_TRY(c, hipMalloc((void**)&c->dSs, (size_t)cap * 8 * c->m * sizeof(double)));
     c->cap = cap;
     return BAZ_MUSIC_OK;
 }
@@ -318,17 +324,19 @@ int launch_evd_t(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ
         const uint32_t blocks = (batch + IPW - 1) / IPW;
         // few emitters: the signal subspace by orthogonal iteration (evd_sub_kernel), then the Jacobi only for the items
         // it hands back (gap too small, zero / non-finite R)
+        // (the scan's short form wants the signal vectors of the product's own workspace only: dQ == c->dQ)
+        double* ss = (dQ == c->dQ && batch <= c->cap) ? c->dSs : nullptr;
         const uint8_t* only = nullptr;
         if (c->sub_evd && c->n <= 3 && 2 * c->n <= (uint32_t)M && c->dRedo && batch <= c->cap) {
             constexpr uint32_t GS = M <= 8 ? 8 : 16, IPS = 64 / GS;
             const uint32_t sblocks = (batch + IPS - 1) / IPS;
             if (c->n == 1) hipLaunchKernelGGL((evd_sub_kernel<M, 1>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQ, batch, qstride, dG, c->dRedo);
-            else if (c->n == 2) hipLaunchKernelGGL((evd_sub_kernel<M, 2>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQ, batch, qstride, dG, c->dRedo);
+            else if (c->n == 2) hipLaunchKernelGGL((evd_sub_kernel<M, 2>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQ, batch, qstride, dG, c->dRedo, ss);
             else if constexpr (M >= 6) hipLaunchKernelGGL((evd_sub_kernel<M, 3>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQ, batch, qstride, dG, c->dRedo);
             HIP_TRY(c, hipGetLastError());
             only = c->dRedo;
         }
-        hipLaunchKernelGGL((evd_proj_lds_kernel<M>), dim3(blocks), dim3(64), 0, c->stream, dR, dQ, batch, c->n, qstride, dG, only);
+        hipLaunchKernelGGL((evd_proj_lds_kernel<M>), dim3(blocks), dim3(64), 0, c->stream, dR, dQ, batch, c->n, qstride, dG, only, ss);
     }
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
@@ -409,7 +417,23 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
     rf.TB = c->dTB + c->tb_step_elems;
     rf.below = c->refine_below;
     rf.count = c->dRefined + c->stat_parity;
+    rf.A2 = c->dA2p ? c->dA2p + 64 : nullptr;
     const double2* fb0 = c->dFB + c->fb_step_elems;   // step 0 (a padded step lies in front)
+    if constexpr (M >= 9 && NMAX == 2) {
+        // two emitters on a wide-ish array: the short form ||a||^2 - |s_0^H a|^2 - |s_1^H a|^2 (scan_mfma_kernel, SIG)
+        if (c->n == 2 && c->sig_scan && c->dSs && c->dA2p && dQ == c->dQ && !c->lab_variant) {
+            const double2* tb0 = c->dTB + c->tb_step_elems;
+#define BAZ_SIG_LAUNCH(SPEC, VEC4)                                                                                          \
+    hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4, 0, (1 | 2 | 16), true>), dim3(G.blocks), dim3(256), 0, c->stream, \
+                       c->dSs, tb0, d_spec, cand, batch, c->res, qstride, G.nsplit, c->nclass, G.rows_per_class, c->keep_mask, c->n, rf)
+            if (spec && vec4) BAZ_SIG_LAUNCH(true, true);
+            else if (spec) BAZ_SIG_LAUNCH(true, false);
+            else BAZ_SIG_LAUNCH(false, false);
+#undef BAZ_SIG_LAUNCH
+            HIP_TRY(c, hipGetLastError());
+            return BAZ_MUSIC_OK;
+        }
+    }
 #define BAZ_SCAN_ARGS dQ, fb0, d_spec, cand, batch, c->res, qstride, G.nsplit, c->nclass, G.rows_per_class, c->keep_mask, c->n, rf
 #define BAZ_SCAN_LAUNCH(SPEC, VEC4, ABLV, AUXV)                                                                    \
     hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4, ABLV, AUXV>), dim3(G.blocks), dim3(256), 0, c->stream, \
@@ -676,6 +700,18 @@ int upload_table(baz_music_ctx* c, const float* table_ri)
         if (a2 > amax2 && a2 < 1e300) amax2 = a2;
     }
     c->refine_below = amax2 * (double)c->m * 1e-8;
+    if (c->dA2p) {   // ||a||^2 per bin for the scan's short form; huge outside the table, like FB's diagonal there
+        std::vector<double> a2((size_t)(c->fb_steps + 2) * 64, 1e300);
+        for (uint32_t b = 0; b < c->res; ++b) {
+            double v = 0.0;
+            for (uint32_t i = 0; i < c->m; ++i) {
+                const double re = table_ri[2 * ((size_t)b * c->m + i)], im = table_ri[2 * ((size_t)b * c->m + i) + 1];
+                v += re * re + im * im;
+            }
+            a2[64 + b] = v;
+        }
+        HIP_TRY(c, hipMemcpy(c->dA2p, a2.data(), a2.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     return BAZ_MUSIC_OK;
 }
 
@@ -884,6 +920,8 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         }
         if (hipMalloc((void**)&c->dFB, (size_t)(c->fb_steps + 2) * c->fb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         if (hipMalloc((void**)&c->dTB, (size_t)(c->fb_steps + 2) * c->tb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+        if (const char* v = getenv("BAZ_MUSIC_SIG_SCAN")) c->sig_scan = atoi(v);                  // lab / tests
+        if (m >= 9 && n == 2 && hipMalloc((void**)&c->dA2p, (size_t)(c->fb_steps + 2) * 64 * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         {
             // ONE workgroup per CU (4 persistent waves, 8 KiB in flight each = 8 MB chip-wide): measured against 2 / 3 / 4 /
             // 6 (the occupancy limit) / 8 per CU, the fewest concurrent input streams read fastest -- 0.370 vs 0.396 ms per
@@ -937,6 +975,8 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->dQ) (void)hipFree(c->dQ);
         if (c->dG) (void)hipFree(c->dG);
         if (c->dRedo) (void)hipFree(c->dRedo);
+        if (c->dSs) (void)hipFree(c->dSs);
+        if (c->dA2p) (void)hipFree(c->dA2p);
         if (c->dTB) (void)hipFree(c->dTB);
         if (c->dRefined) (void)hipFree(c->dRefined);
         if (c->dPeakSpec) (void)hipFree(c->dPeakSpec);

@@ -726,7 +726,8 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
                                                            double* __restrict__ Qs,
                                                            uint32_t batch, uint32_t n, uint32_t qstride,
                                                            double* __restrict__ Gs,
-                                                           const uint8_t* __restrict__ only = nullptr)
+                                                           const uint8_t* __restrict__ only = nullptr,
+                                                           double* __restrict__ Ss = nullptr)
 {
     constexpr int MM = M * M;
     constexpr int IPW = 64 / M;           // items per wave
@@ -946,6 +947,19 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
             Gs[(size_t)((r * M + j) * 2 + 1) * qstride + item] = v.y;
         }
     }
+    // the two signal eigenvectors as the coefficient vectors of the scan's short form (scan_mfma_kernel, SIG): output
+    // 2c = Re s_c^H a, 2c+1 = Im s_c^H a over the real coordinates (re a_0, im a_0, re a_1, ...)
+    if (valid && Ss && n == 2) {
+#pragma unroll
+        for (int cI = 0; cI < 2; ++cI) {
+            const double2 v = V[j][sSel[sl][nnoise + cI] & 15];
+            const double vr = v.x + poison, vi = v.y + poison;
+            Ss[(size_t)((2 * cI) * 2 * M + 2 * j) * qstride + item] = vr;
+            Ss[(size_t)((2 * cI) * 2 * M + 2 * j + 1) * qstride + item] = vi;
+            Ss[(size_t)((2 * cI + 1) * 2 * M + 2 * j) * qstride + item] = -vi;
+            Ss[(size_t)((2 * cI + 1) * 2 * M + 2 * j + 1) * qstride + item] = vr;
+        }
+    }
     // lane j emits row j of Q (upper part): Q_jl = sum_{k in set} V[j][k] conj(V[l][k])
     if (valid) {
         for (int l = j; l < M; ++l) {
@@ -1021,7 +1035,8 @@ __device__ __forceinline__ double2 cmulc(double2 a, double2 b) { return make_dou
 
 template <int M, int P>
 __global__ __launch_bounds__(64) void evd_sub_kernel(const double2* __restrict__ R, double* __restrict__ Qs, uint32_t batch,
-                                                      uint32_t qstride, double* __restrict__ Gs, uint8_t* __restrict__ redo)
+                                                      uint32_t qstride, double* __restrict__ Gs, uint8_t* __restrict__ redo,
+                                                      double* __restrict__ Ss = nullptr)
 {
     static_assert(M >= 5 && M <= 16 && P >= 1 && 2 * P <= M, "few emitters on the LDS-EVD antenna counts");
     constexpr int GS = M <= 8 ? 8 : 16, IPW = 64 / GS, MM = M * M;
@@ -1134,6 +1149,17 @@ __global__ __launch_bounds__(64) void evd_sub_kernel(const double2* __restrict__
     for (int c = 0; c < P; ++c) sY[g][c][j] = y[c];
     wave_lds_fence();
     const bool emit = conv && item_ok && row;
+    if constexpr (P == 2) {
+        if (emit && Ss) {      // coefficient vectors of the scan's short form (see evd_proj_lds_kernel)
+#pragma unroll
+            for (int cI = 0; cI < 2; ++cI) {
+                Ss[(size_t)((2 * cI) * 2 * M + 2 * j) * qstride + item] = y[cI].x;
+                Ss[(size_t)((2 * cI) * 2 * M + 2 * j + 1) * qstride + item] = y[cI].y;
+                Ss[(size_t)((2 * cI + 1) * 2 * M + 2 * j) * qstride + item] = -y[cI].y;
+                Ss[(size_t)((2 * cI + 1) * 2 * M + 2 * j + 1) * qstride + item] = y[cI].x;
+            }
+        }
+    }
     if (emit) {   // row j of Q = I - S S^H (upper part), packed as evd_proj_kernel does
         for (int l = j; l < M; ++l) {
             double re = 0.0, im = 0.0;
@@ -1356,6 +1382,7 @@ struct ScanRefine {
     const double2* TB;         // raw-table B-operand image (build_TB), same step padding and shift rule as FB
     double below;              // |d| <= below -> the step's tile is recomputed in literal form
     unsigned long long* count; // statistic: (item, bin) values recomputed (may be nullptr)
+    const double* A2;          // SIG scan only: ||a||^2 per bin, padded like FB (huge outside [0, res)); points at step 0
 };
 
 template <int M>
@@ -1417,7 +1444,16 @@ __device__ __forceinline__ uint32_t literal_tile(v4f64 (&acc)[4], const ScanRefi
 // Occupancy floors: m <= 4: 4 waves/SIMD = 128 registers; m >= 9 (q alone is m^2/2 registers): 2 waves/SIMD = 256
 // registers INCLUDING accumulation registers (without the floor the m = 16 kernel took 256 + 28 and ran one wave per
 // SIMD: scan 0.56 -> 0.78 ms on config 5).  What this displaces lives in the rare literal / statistic paths.
-template <int M, int NMAX, bool SPEC, bool VEC4, int ABL = 0, int AUX = (1 | 2 | 16)>
+//
+// SIG (m >= 9, n = 2): the short form of the same quantity.  With S = the two signal eigenvectors,
+//     a^H (I - S S^H) a = ||a||^2 - |s_0^H a|^2 - |s_1^H a|^2,
+// i.e. FOUR real inner products of length 2m per (item, bin) -- Re/Im of s_c^H a against the raw table -- instead of one
+// of length m^2: half the matrix-core work at m = 16.  Rows of an MFMA tile = (4 items) x (4 outputs), row = item + 4 out,
+// so that the 4 outputs of one (item, bin) land in the 4 accumulator registers of ONE lane; a wave still owns 16 items,
+// as four groups of 4 (group r = items g + 4r ... see below), and from `acc[t][r]` on the kernel is the same code: gate,
+// literal refinement of near-null tiles (the difference loses ~m eps ||a||^2 like the projector form), stores, top-n.
+// Qs then carries the coefficient vectors ((out*2M + k) * qstride + item), FB the raw-table image (build_TB).
+template <int M, int NMAX, bool SPEC, bool VEC4, int ABL = 0, int AUX = (1 | 2 | 16), bool SIG = false>
 __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) void scan_mfma_kernel(const double* __restrict__ Qs,
                                                          const double2* __restrict__ FB,
                                                          float* __restrict__ spec,
@@ -1427,7 +1463,8 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
                                                          uint32_t keep_mask, uint32_t n, ScanRefine rf)
 {
     constexpr int MM = M * M;
-    constexpr int KS = (MM + 3) / 4;                  // MFMA k-steps per bin step
+    constexpr int KS = SIG ? (2 * M + 3) / 4 : (MM + 3) / 4;   // MFMA k-steps per bin step
+    static_assert(!SIG || (M >= 9 && KS <= 8), "the short form: one phase per step, no row classes");
     constexpr int SCH = (KS <= 8) ? KS : 8;           // k-steps per phase
     constexpr int PPS = (KS + SCH - 1) / SCH;         // phases per bin step
     constexpr int CPP = 2 * SCH;                      // 1-KiB chunks (64 x double2) per full phase
@@ -1453,10 +1490,25 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
     // (rows beyond the batch, in the last groups of a class, still stage and sync but store nothing)
 
     // A operand: q[item of row c][e = 4 s + g]   (zero for the K padding e >= MM)
-    double qa[KS];
+    double qa[SIG ? 1 : KS];
+    [[maybe_unused]] double sa[SIG ? 4 : 1][SIG ? KS : 1];     // SIG: group r = items 4r .. 4r+3 of the wave; row c = item (c & 3), output (c >> 2)
     const uint32_t it_c = item0 + nclass * (uint32_t)c;
     const uint32_t itc = (it_c < batch) ? it_c : (batch - 1);
-    {
+    if constexpr (SIG) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // D rows are item rows g' + 4r (r = accumulator register): group q must produce the d of rows g' + 4q, so its
+            // tile row (item ig, output o) = ig + 4o carries wave item ig + 4q
+            const uint32_t it_q = item0 + nclass * (uint32_t)((c & 3) + 4 * q);
+            const uint32_t itq = (it_q < batch) ? it_q : (batch - 1);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int e = 4 * s + g;
+                sa[q][s] = (e < 2 * M) ? Qs[(size_t)((c >> 2) * 2 * M + e) * qstride + itq] : 0.0;
+            }
+        }
+        qa[0] = 0.0;
+    } else {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int e = 4 * s + g;
@@ -1549,6 +1601,29 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
             if (more) BAZ_STAGE_LOAD(last_p ? st + 1 : st, last_p ? 0 : p + 1);
 
             // 2. this phase: B operands from LDS, MFMAs
+            if constexpr (SIG) {
+                // ||a||^2 of this lane's 4 bins (huge outside the table), then per group of 4 items the four outputs
+                const v4f64 a2v = *reinterpret_cast<const v4f64*>(rf.A2 + (size_t)st * 64 + 4 * c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v4f64 tmp[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) tmp[t] = (v4f64){0, 0, 0, 0};
+#pragma unroll
+                    for (int sl = 0; sl < KS; ++sl) {
+                        const v2f64 f01 = stage[buf][(2 * sl) * 64 + lane];
+                        const v2f64 f23 = stage[buf][(2 * sl + 1) * 64 + lane];
+                        tmp[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[q][sl], f01.x, tmp[0], 0, 0, 0);
+                        tmp[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[q][sl], f01.y, tmp[1], 0, 0, 0);
+                        tmp[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[q][sl], f23.x, tmp[2], 0, 0, 0);
+                        tmp[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[q][sl], f23.y, tmp[3], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[t][q] = a2v[t] - ((tmp[t][0] * tmp[t][0] + tmp[t][1] * tmp[t][1]) +
+                                              (tmp[t][2] * tmp[t][2] + tmp[t][3] * tmp[t][3]));
+                }
+            } else
 #pragma unroll
             for (int sl = 0; sl < SCH; ++sl) {
                 const int s = p * SCH + sl;
