@@ -89,7 +89,7 @@ struct baz_music_ctx {
     double* dA2 = nullptr;         // ||a||^2 per bin
     int wide_literal_only = 0;     // lab (BAZ_MUSIC_WIDE_LITERAL=1): no short form in scan_wide_kernel
     uint32_t wide_cap = 0;         // items the three buffers above (and dR) hold
-    double* dSs = nullptr;         // m >= 9, n = 2: coefficient vectors of the scan's short form, [4 * 2m][q_stride]
+    double* dSs = nullptr;         // m >= 9, n <= 2: coefficient vectors of the scan's short form, [2n * 2m][q_stride]
     double* dA2p = nullptr;        // ... and ||a||^2 per bin, padded like dFB (fb_steps + 2 steps of 64)
     int sig_scan = 1;              // lab / tests: BAZ_MUSIC_SIG_SCAN=0 keeps the projector GEMM
     uint8_t* dRedo = nullptr;      // [cap] items evd_sub_kernel hands back to the Jacobi
@@ -224,7 +224,7 @@ int ensure_workspace(baz_music_ctx* c, uint32_t batch)
     if (c->dRedo) { (void)hipFree(c->dRedo); c->dRedo = nullptr; }
     HIP_TRY(c, hipMalloc((void**)&c->dRedo, (size_t)cap));
     if (c->dSs) { (void)hipFree(c->dSs); c->dSs = nullptr; }
-    if (c->m >= 9 && c->n == 2) HIP_TRY(c, hipMalloc((void**)&c->dSs, (size_t)cap * 8 * c->m * sizeof(double)));
+    if (c->m >= 9 && c->n <= 2) HIP_TRY(c, hipMalloc((void**)&c->dSs, (size_t)cap * 4 * c->n * c->m * sizeof(double)));
     c->cap = cap;
     return BAZ_MUSIC_OK;
 }
@@ -330,7 +330,7 @@ int launch_evd_t(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ
         if (c->sub_evd && c->n <= 3 && 2 * c->n <= (uint32_t)M && c->dRedo && batch <= c->cap) {
             constexpr uint32_t GS = M <= 8 ? 8 : 16, IPS = 64 / GS;
             const uint32_t sblocks = (batch + IPS - 1) / IPS;
-            if (c->n == 1) hipLaunchKernelGGL((evd_sub_kernel<M, 1>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQ, batch, qstride, dG, c->dRedo);
+            if (c->n == 1) hipLaunchKernelGGL((evd_sub_kernel<M, 1>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQ, batch, qstride, dG, c->dRedo, ss);
             else if (c->n == 2) hipLaunchKernelGGL((evd_sub_kernel<M, 2>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQ, batch, qstride, dG, c->dRedo, ss);
             else if constexpr (M >= 6) hipLaunchKernelGGL((evd_sub_kernel<M, 3>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQ, batch, qstride, dG, c->dRedo);
             HIP_TRY(c, hipGetLastError());
@@ -421,14 +421,20 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
     const double2* fb0 = c->dFB + c->fb_step_elems;   // step 0 (a padded step lies in front)
     if constexpr (M >= 9 && NMAX == 2) {
         // two emitters on a wide-ish array: the short form ||a||^2 - |s_0^H a|^2 - |s_1^H a|^2 (scan_mfma_kernel, SIG)
-        if (c->n == 2 && c->sig_scan && c->dSs && c->dA2p && dQ == c->dQ && !c->lab_variant) {
+        if (c->n <= 2 && c->sig_scan && c->dSs && c->dA2p && dQ == c->dQ && !c->lab_variant) {
             const double2* tb0 = c->dTB + c->tb_step_elems;
-#define BAZ_SIG_LAUNCH(SPEC, VEC4)                                                                                          \
-    hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4, 0, (1 | 2 | 16), true>), dim3(G.blocks), dim3(256), 0, c->stream, \
+#define BAZ_SIG_LAUNCH(SPEC, VEC4, SIGV)                                                                                    \
+    hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4, 0, (1 | 2 | 16), SIGV>), dim3(G.blocks), dim3(256), 0, c->stream, \
                        c->dSs, tb0, d_spec, cand, batch, c->res, qstride, G.nsplit, c->nclass, G.rows_per_class, c->keep_mask, c->n, rf)
-            if (spec && vec4) BAZ_SIG_LAUNCH(true, true);
-            else if (spec) BAZ_SIG_LAUNCH(true, false);
-            else BAZ_SIG_LAUNCH(false, false);
+            if (c->n == 2) {
+                if (spec && vec4) BAZ_SIG_LAUNCH(true, true, 2);
+                else if (spec) BAZ_SIG_LAUNCH(true, false, 2);
+                else BAZ_SIG_LAUNCH(false, false, 2);
+            } else {
+                if (spec && vec4) BAZ_SIG_LAUNCH(true, true, 1);
+                else if (spec) BAZ_SIG_LAUNCH(true, false, 1);
+                else BAZ_SIG_LAUNCH(false, false, 1);
+            }
 #undef BAZ_SIG_LAUNCH
             HIP_TRY(c, hipGetLastError());
             return BAZ_MUSIC_OK;
@@ -921,7 +927,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (hipMalloc((void**)&c->dFB, (size_t)(c->fb_steps + 2) * c->fb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         if (hipMalloc((void**)&c->dTB, (size_t)(c->fb_steps + 2) * c->tb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         if (const char* v = getenv("BAZ_MUSIC_SIG_SCAN")) c->sig_scan = atoi(v);                  // lab / tests
-        if (m >= 9 && n == 2 && hipMalloc((void**)&c->dA2p, (size_t)(c->fb_steps + 2) * 64 * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+        if (m >= 9 && n <= 2 && hipMalloc((void**)&c->dA2p, (size_t)(c->fb_steps + 2) * 64 * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         {
             // ONE workgroup per CU (4 persistent waves, 8 KiB in flight each = 8 MB chip-wide): measured against 2 / 3 / 4 /
             // 6 (the occupancy limit) / 8 per CU, the fewest concurrent input streams read fastest -- 0.370 vs 0.396 ms per

@@ -949,9 +949,8 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
     }
     // the two signal eigenvectors as the coefficient vectors of the scan's short form (scan_mfma_kernel, SIG): output
     // 2c = Re s_c^H a, 2c+1 = Im s_c^H a over the real coordinates (re a_0, im a_0, re a_1, ...)
-    if (valid && Ss && n == 2) {
-#pragma unroll
-        for (int cI = 0; cI < 2; ++cI) {
+    if (valid && Ss && n <= 2) {
+        for (int cI = 0; cI < (int)n; ++cI) {
             const double2 v = V[j][sSel[sl][nnoise + cI] & 15];
             const double vr = v.x + poison, vi = v.y + poison;
             Ss[(size_t)((2 * cI) * 2 * M + 2 * j) * qstride + item] = vr;
@@ -1149,10 +1148,10 @@ __global__ __launch_bounds__(64) void evd_sub_kernel(const double2* __restrict__
     for (int c = 0; c < P; ++c) sY[g][c][j] = y[c];
     wave_lds_fence();
     const bool emit = conv && item_ok && row;
-    if constexpr (P == 2) {
+    if constexpr (P <= 2) {
         if (emit && Ss) {      // coefficient vectors of the scan's short form (see evd_proj_lds_kernel)
 #pragma unroll
-            for (int cI = 0; cI < 2; ++cI) {
+            for (int cI = 0; cI < P; ++cI) {
                 Ss[(size_t)((2 * cI) * 2 * M + 2 * j) * qstride + item] = y[cI].x;
                 Ss[(size_t)((2 * cI) * 2 * M + 2 * j + 1) * qstride + item] = y[cI].y;
                 Ss[(size_t)((2 * cI + 1) * 2 * M + 2 * j) * qstride + item] = -y[cI].y;
@@ -1453,7 +1452,9 @@ __device__ __forceinline__ uint32_t literal_tile(v4f64 (&acc)[4], const ScanRefi
 // as four groups of 4 (group r = items g + 4r ... see below), and from `acc[t][r]` on the kernel is the same code: gate,
 // literal refinement of near-null tiles (the difference loses ~m eps ||a||^2 like the projector form), stores, top-n.
 // Qs then carries the coefficient vectors ((out*2M + k) * qstride + item), FB the raw-table image (build_TB).
-template <int M, int NMAX, bool SPEC, bool VEC4, int ABL = 0, int AUX = (1 | 2 | 16), bool SIG = false>
+// SIG = 2: n = 2 as described; SIG = 1: n = 1, two outputs per item, so a tile holds 8 items (row = item + 4 (2 half + out),
+// registers (0, 1) = item g, (2, 3) = item g + 4) and a wave's 16 items are two groups: a quarter of the work at m = 16.
+template <int M, int NMAX, bool SPEC, bool VEC4, int ABL = 0, int AUX = (1 | 2 | 16), int SIG = 0>
 __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) void scan_mfma_kernel(const double* __restrict__ Qs,
                                                          const double2* __restrict__ FB,
                                                          float* __restrict__ spec,
@@ -1465,6 +1466,7 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
     constexpr int MM = M * M;
     constexpr int KS = SIG ? (2 * M + 3) / 4 : (MM + 3) / 4;   // MFMA k-steps per bin step
     static_assert(!SIG || (M >= 9 && KS <= 8), "the short form: one phase per step, no row classes");
+    constexpr int NG = (SIG == 1) ? 2 : 4;            // SIG: item groups per wave (8 or 4 items per tile)
     constexpr int SCH = (KS <= 8) ? KS : 8;           // k-steps per phase
     constexpr int PPS = (KS + SCH - 1) / SCH;         // phases per bin step
     constexpr int CPP = 2 * SCH;                      // 1-KiB chunks (64 x double2) per full phase
@@ -1491,20 +1493,24 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
 
     // A operand: q[item of row c][e = 4 s + g]   (zero for the K padding e >= MM)
     double qa[SIG ? 1 : KS];
-    [[maybe_unused]] double sa[SIG ? 4 : 1][SIG ? KS : 1];     // SIG: group r = items 4r .. 4r+3 of the wave; row c = item (c & 3), output (c >> 2)
+    [[maybe_unused]] double sa[SIG ? NG : 1][SIG ? KS : 1];    // SIG: per item group, row c of the tile = (item, output)
     const uint32_t it_c = item0 + nclass * (uint32_t)c;
     const uint32_t itc = (it_c < batch) ? it_c : (batch - 1);
     if constexpr (SIG) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            // D rows are item rows g' + 4r (r = accumulator register): group q must produce the d of rows g' + 4q, so its
-            // tile row (item ig, output o) = ig + 4o carries wave item ig + 4q
-            const uint32_t it_q = item0 + nclass * (uint32_t)((c & 3) + 4 * q);
+        for (int q = 0; q < NG; ++q) {
+            // D rows are item rows g' + 4r (r = accumulator register).  SIG = 2: group q must produce the d of rows g' + 4q,
+            // so its tile row (item ig, output o) = ig + 4o carries wave item ig + 4q.  SIG = 1: tile row ig + 4 (2 half + o)
+            // carries wave item ig + 4 (2q + half), whose d comes out of registers (2 half, 2 half + 1).
+            const int sub = c >> 2;
+            const int wrow = (SIG == 1) ? (c & 3) + 4 * (2 * q + (sub >> 1)) : (c & 3) + 4 * q;
+            const int outp = (SIG == 1) ? (sub & 1) : sub;
+            const uint32_t it_q = item0 + nclass * (uint32_t)wrow;
             const uint32_t itq = (it_q < batch) ? it_q : (batch - 1);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int e = 4 * s + g;
-                sa[q][s] = (e < 2 * M) ? Qs[(size_t)((c >> 2) * 2 * M + e) * qstride + itq] : 0.0;
+                sa[q][s] = (e < 2 * M) ? Qs[(size_t)(outp * 2 * M + e) * qstride + itq] : 0.0;
             }
         }
         qa[0] = 0.0;
@@ -1605,7 +1611,7 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
                 // ||a||^2 of this lane's 4 bins (huge outside the table), then per group of 4 items the four outputs
                 const v4f64 a2v = *reinterpret_cast<const v4f64*>(rf.A2 + (size_t)st * 64 + 4 * c);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < NG; ++q) {
                     v4f64 tmp[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) tmp[t] = (v4f64){0, 0, 0, 0};
@@ -1619,9 +1625,15 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
                         tmp[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[q][sl], f23.y, tmp[3], 0, 0, 0);
                     }
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        acc[t][q] = a2v[t] - ((tmp[t][0] * tmp[t][0] + tmp[t][1] * tmp[t][1]) +
-                                              (tmp[t][2] * tmp[t][2] + tmp[t][3] * tmp[t][3]));
+                    for (int t = 0; t < 4; ++t) {
+                        if constexpr (SIG == 1) {
+                            acc[t][2 * q] = a2v[t] - (tmp[t][0] * tmp[t][0] + tmp[t][1] * tmp[t][1]);
+                            acc[t][2 * q + 1] = a2v[t] - (tmp[t][2] * tmp[t][2] + tmp[t][3] * tmp[t][3]);
+                        } else {
+                            acc[t][q] = a2v[t] - ((tmp[t][0] * tmp[t][0] + tmp[t][1] * tmp[t][1]) +
+                                                  (tmp[t][2] * tmp[t][2] + tmp[t][3] * tmp[t][3]));
+                        }
+                    }
                 }
             } else
 #pragma unroll

@@ -480,16 +480,17 @@ def test_signal_subspace_iteration_and_its_hand_back(m, n, K, res, gpu_device, m
 
 
 # ------------------------------------------------------------------ the scan's short form (m >= 9, n = 2)
-@pytest.mark.parametrize("m,K,res,batch,snr", [(16, 64, 3600, 70, 20.0), (9, 40, 361, 33, 10.0), (13, 50, 1000, 17, 40.0),
-                                                (16, 256, 720, 20, 0.0)])
-def test_short_form_scan_equals_the_projector_scan(m, K, res, batch, snr, gpu_device, monkeypatch):
-    """||a||^2 - |s_0^H a|^2 - |s_1^H a|^2 (scan_mfma_kernel SIG) against the projector GEMM of the same build
+@pytest.mark.parametrize("m,n,K,res,batch,snr", [(16, 2, 64, 3600, 70, 20.0), (9, 2, 40, 361, 33, 10.0), (13, 2, 50, 1000, 17, 40.0),
+                                                  (16, 2, 256, 720, 20, 0.0), (16, 1, 64, 3600, 70, 20.0), (9, 1, 40, 361, 33, 0.0),
+                                                  (12, 1, 48, 500, 21, 60.0)])
+def test_short_form_scan_equals_the_projector_scan(m, n, K, res, batch, snr, gpu_device, monkeypatch):
+    """||a||^2 - sum_c |s_c^H a|^2 (scan_mfma_kernel SIG, n = 1 and 2) against the projector GEMM of the same build
     (BAZ_MUSIC_SIG_SCAN=0): float32 spectra within 2 ulp, the same DoA pairs, both within 1e-5 of the oracle, with and
     without the spectrum port, res % 4 != 0 included"""
-    n, N = 2, m * K
+    N = m * K
     arr = mo.array_geometry(m)
     table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
-    items = mo.synth_items(batch, m, N, arr, mo.FREQUENCY, mo.SPACING, angles_deg=(40.3, 121.7), snr_db=snr, seed=17 * m + K)
+    items = mo.synth_items(batch, m, N, arr, mo.FREQUENCY, mo.SPACING, angles_deg=(40.3, 121.7)[:n], snr_db=snr, seed=17 * m + K)
     outs = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("BAZ_MUSIC_SIG_SCAN", mode)
@@ -538,7 +539,7 @@ def test_outputs_do_not_depend_on_the_range_split_of_the_scan(name, gpu_device, 
     (4, 3, 7, 1440, 257, 60.0, 11), (7, 6, 300, 360, 257, 60.0, 12), (4, 2, 256, 3600, 300, 80.0, 13),
     (8, 2, 64, 1000, 64, 70.0, 14), (16, 12, 64, 720, 33, 60.0, 15), (5, 4, 40, 361, 100, 90.0, 16),
     (4, 2, 256, 3600, 64, 120.0, 17),
-    (16, 2, 64, 720, 40, 80.0, 18), (11, 2, 50, 360, 33, 100.0, 19)])      # the scan's short form (m >= 9, n = 2)
+    (16, 2, 64, 720, 40, 80.0, 18), (11, 2, 50, 360, 33, 100.0, 19), (16, 1, 64, 720, 40, 90.0, 20)])   # the scan's short form (m >= 9, n <= 2)
 def test_extreme_snr_spectra_match_the_literal_form(m, n, K, res, batch, snr, seed, gpu_device):
     """At >~ 55 dB SNR some bin of an item falls into a near-null of the noise subspace (d = ||G^H a||^2 down to
     1e-12 ||a||^2).  The projector GEMM of the scan has only ~m^2 1e-16 ABSOLUTE accuracy there, so the scan redoes
