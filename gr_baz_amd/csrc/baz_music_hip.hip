@@ -89,7 +89,7 @@ struct baz_music_ctx {
     double* dA2 = nullptr;         // ||a||^2 per bin
     int wide_literal_only = 0;     // lab (BAZ_MUSIC_WIDE_LITERAL=1): no short form in scan_wide_kernel
     uint32_t wide_cap = 0;         // items the three buffers above (and dR) hold
-    double* dSs = nullptr;         // m >= 9, n <= 2: coefficient vectors of the scan's short form, [2n * 2m][q_stride]
+    double* dSs = nullptr;         // short_form_applies(): coefficient vectors of the scan's short form, [2n * 2m][q_stride]
     double* dA2p = nullptr;        // ... and ||a||^2 per bin, padded like dFB (fb_steps + 2 steps of 64)
     int sig_scan = 1;              // lab / tests: BAZ_MUSIC_SIG_SCAN=0 keeps the projector GEMM
     uint8_t* dRedo = nullptr;      // [cap] items evd_sub_kernel hands back to the Jacobi
@@ -207,6 +207,9 @@ void build_TB(const float* table_ri, uint32_t m, uint32_t res, uint32_t steps, s
 
 uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 
+// the scan's short form (scan_mfma_kernel, SIG) needs fewer MFMAs than the projector GEMM
+bool short_form_applies(uint32_t m, uint32_t n) { return (n == 2 && m >= 9 && m <= 16) || (n == 1 && m >= 6 && m <= 16); }
+
 int ensure_workspace(baz_music_ctx* c, uint32_t batch)
 {
     if (batch <= c->cap) return BAZ_MUSIC_OK;
@@ -224,7 +227,7 @@ int ensure_workspace(baz_music_ctx* c, uint32_t batch)
     if (c->dRedo) { (void)hipFree(c->dRedo); c->dRedo = nullptr; }
     HIP_TRY(c, hipMalloc((void**)&c->dRedo, (size_t)cap));
     if (c->dSs) { (void)hipFree(c->dSs); c->dSs = nullptr; }
-    if (c->m >= 9 && c->n <= 2) HIP_TRY(c, hipMalloc((void**)&c->dSs, (size_t)cap * 4 * c->n * c->m * sizeof(double)));
+    if (short_form_applies(c->m, c->n)) HIP_TRY(c, hipMalloc((void**)&c->dSs, (size_t)cap * 4 * c->n * c->m * sizeof(double)));
     c->cap = cap;
     return BAZ_MUSIC_OK;
 }
@@ -419,17 +422,20 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
     rf.count = c->dRefined + c->stat_parity;
     rf.A2 = c->dA2p ? c->dA2p + 64 : nullptr;
     const double2* fb0 = c->dFB + c->fb_step_elems;   // step 0 (a padded step lies in front)
-    if constexpr (M >= 9 && NMAX == 2) {
-        // two emitters on a wide-ish array: the short form ||a||^2 - |s_0^H a|^2 - |s_1^H a|^2 (scan_mfma_kernel, SIG)
-        if (c->n <= 2 && c->sig_scan && c->dSs && c->dA2p && dQ == c->dQ && !c->lab_variant) {
+    if constexpr (M >= 6 && NMAX == 2) {
+        // one or two emitters: the short form ||a||^2 - sum_c |s_c^H a|^2 (scan_mfma_kernel, SIG) where it needs fewer
+        // MFMAs than the projector GEMM: n = 2 from 9 antennas, n = 1 from 6
+        if (short_form_applies(c->m, c->n) && c->sig_scan && c->dSs && c->dA2p && dQ == c->dQ && !c->lab_variant) {
             const double2* tb0 = c->dTB + c->tb_step_elems;
 #define BAZ_SIG_LAUNCH(SPEC, VEC4, SIGV)                                                                                    \
     hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4, 0, (1 | 2 | 16), SIGV>), dim3(G.blocks), dim3(256), 0, c->stream, \
                        c->dSs, tb0, d_spec, cand, batch, c->res, qstride, G.nsplit, c->nclass, G.rows_per_class, c->keep_mask, c->n, rf)
             if (c->n == 2) {
-                if (spec && vec4) BAZ_SIG_LAUNCH(true, true, 2);
-                else if (spec) BAZ_SIG_LAUNCH(true, false, 2);
-                else BAZ_SIG_LAUNCH(false, false, 2);
+                if constexpr (M >= 9) {
+                    if (spec && vec4) BAZ_SIG_LAUNCH(true, true, 2);
+                    else if (spec) BAZ_SIG_LAUNCH(true, false, 2);
+                    else BAZ_SIG_LAUNCH(false, false, 2);
+                }
             } else {
                 if (spec && vec4) BAZ_SIG_LAUNCH(true, true, 1);
                 else if (spec) BAZ_SIG_LAUNCH(true, false, 1);
@@ -927,7 +933,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (hipMalloc((void**)&c->dFB, (size_t)(c->fb_steps + 2) * c->fb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         if (hipMalloc((void**)&c->dTB, (size_t)(c->fb_steps + 2) * c->tb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         if (const char* v = getenv("BAZ_MUSIC_SIG_SCAN")) c->sig_scan = atoi(v);                  // lab / tests
-        if (m >= 9 && n <= 2 && hipMalloc((void**)&c->dA2p, (size_t)(c->fb_steps + 2) * 64 * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+        if (short_form_applies(m, n) && hipMalloc((void**)&c->dA2p, (size_t)(c->fb_steps + 2) * 64 * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         {
             // ONE workgroup per CU (4 persistent waves, 8 KiB in flight each = 8 MB chip-wide): measured against 2 / 3 / 4 /
             // 6 (the occupancy limit) / 8 per CU, the fewest concurrent input streams read fastest -- 0.370 vs 0.396 ms per

@@ -1465,7 +1465,7 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
 {
     constexpr int MM = M * M;
     constexpr int KS = SIG ? (2 * M + 3) / 4 : (MM + 3) / 4;   // MFMA k-steps per bin step
-    static_assert(!SIG || (M >= 9 && KS <= 8), "the short form: one phase per step, no row classes");
+    static_assert(!SIG || (((SIG == 1 && M >= 6) || M >= 9) && KS <= 8), "the short form: one phase per step, no row classes (m >= 6)");
     constexpr int NG = (SIG == 1) ? 2 : 4;            // SIG: item groups per wave (8 or 4 items per tile)
     constexpr int SCH = (KS <= 8) ? KS : 8;           // k-steps per phase
     constexpr int PPS = (KS + SCH - 1) / SCH;         // phases per bin step

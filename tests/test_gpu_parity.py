@@ -482,7 +482,8 @@ def test_signal_subspace_iteration_and_its_hand_back(m, n, K, res, gpu_device, m
 # ------------------------------------------------------------------ the scan's short form (m >= 9, n = 2)
 @pytest.mark.parametrize("m,n,K,res,batch,snr", [(16, 2, 64, 3600, 70, 20.0), (9, 2, 40, 361, 33, 10.0), (13, 2, 50, 1000, 17, 40.0),
                                                   (16, 2, 256, 720, 20, 0.0), (16, 1, 64, 3600, 70, 20.0), (9, 1, 40, 361, 33, 0.0),
-                                                  (12, 1, 48, 500, 21, 60.0)])
+                                                  (12, 1, 48, 500, 21, 60.0), (8, 1, 64, 3600, 40, 20.0), (6, 1, 30, 250, 33, 5.0),
+                                                  (7, 1, 50, 1001, 18, 70.0)])
 def test_short_form_scan_equals_the_projector_scan(m, n, K, res, batch, snr, gpu_device, monkeypatch):
     """||a||^2 - sum_c |s_c^H a|^2 (scan_mfma_kernel SIG, n = 1 and 2) against the projector GEMM of the same build
     (BAZ_MUSIC_SIG_SCAN=0): float32 spectra within 2 ulp, the same DoA pairs, both within 1e-5 of the oracle, with and
