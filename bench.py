@@ -270,7 +270,9 @@ def extra_cfg5(torch, np, capi, synth, dev, stream, nitems, seconds):
             "music_stage_ms": dict(zip(("cov", "evd", "scan", "merge"), st)),
             "bound": "hbm (front-end: resampler + AGC) + fp64 matrix (scan); the EVD is the n = 2 signal subspace by "
                      "orthogonal iteration (evd_sub_kernel), Jacobi only for items it hands back",
-            "scan_fp64_tflops": 2.0 * m * m * res * nitems / (st[2] * 1e-3) / 1e12 if st[2] > 0 else None,
+            # the scan runs the short form ||a||^2 - sum_c |s_c^H a|^2: 4 n m FMAs per (item, bin), not m^2
+            "scan_fp64_tflops": 2.0 * 4 * N_EMIT * m * res * nitems / (st[2] * 1e-3) / 1e12 if st[2] > 0 else None,
+            "scan_form": "short form, 4*n*m = %d FMA per (item, bin) (projector form: m^2 = %d)" % (4 * N_EMIT * m, m * m),
             "resampler_GBs": (in_b + rs_b) / eng[0] / 1e6, "agc_GBs": (rs_b + 2 * nitems * N * 8) / eng[1] / 1e6,
             "chain_bytes_per_step": chain_bytes, "chain_hbm_fraction_of_8TBs": chain_bytes / (ms * 1e-3) / 8e12}
 
