@@ -209,6 +209,10 @@ uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 
 // the scan's short form (scan_mfma_kernel, SIG) needs fewer MFMAs than the projector GEMM
 bool short_form_applies(uint32_t m, uint32_t n) { return (n == 2 && m >= 9 && m <= 16) || (n == 1 && m >= 6 && m <= 16); }
+bool short_form_in_use(const baz_music_ctx* c)
+{
+    return short_form_applies(c->m, c->n) && c->sig_scan && c->dSs && c->dA2p && !c->lab_variant;
+}
 
 int ensure_workspace(baz_music_ctx* c, uint32_t batch)
 {
@@ -329,17 +333,19 @@ int launch_evd_t(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ
         // it hands back (gap too small, zero / non-finite R)
         // (the scan's short form wants the signal vectors of the product's own workspace only: dQ == c->dQ)
         double* ss = (dQ == c->dQ && batch <= c->cap) ? c->dSs : nullptr;
+        // ... and when that scan runs, nothing reads the projector coefficients: they are not written either
+        double* const dQw = (ss && short_form_in_use(c)) ? nullptr : dQ;
         const uint8_t* only = nullptr;
         if (c->sub_evd && c->n <= 3 && 2 * c->n <= (uint32_t)M && c->dRedo && batch <= c->cap) {
             constexpr uint32_t GS = M <= 8 ? 8 : 16, IPS = 64 / GS;
             const uint32_t sblocks = (batch + IPS - 1) / IPS;
-            if (c->n == 1) hipLaunchKernelGGL((evd_sub_kernel<M, 1>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQ, batch, qstride, dG, c->dRedo, ss);
-            else if (c->n == 2) hipLaunchKernelGGL((evd_sub_kernel<M, 2>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQ, batch, qstride, dG, c->dRedo, ss);
-            else if constexpr (M >= 6) hipLaunchKernelGGL((evd_sub_kernel<M, 3>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQ, batch, qstride, dG, c->dRedo);
+            if (c->n == 1) hipLaunchKernelGGL((evd_sub_kernel<M, 1>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQw, batch, qstride, dG, c->dRedo, ss);
+            else if (c->n == 2) hipLaunchKernelGGL((evd_sub_kernel<M, 2>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQw, batch, qstride, dG, c->dRedo, ss);
+            else if constexpr (M >= 6) hipLaunchKernelGGL((evd_sub_kernel<M, 3>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQw, batch, qstride, dG, c->dRedo);
             HIP_TRY(c, hipGetLastError());
             only = c->dRedo;
         }
-        hipLaunchKernelGGL((evd_proj_lds_kernel<M>), dim3(blocks), dim3(64), 0, c->stream, dR, dQ, batch, c->n, qstride, dG, only, ss);
+        hipLaunchKernelGGL((evd_proj_lds_kernel<M>), dim3(blocks), dim3(64), 0, c->stream, dR, dQw, batch, c->n, qstride, dG, only, ss);
     }
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
@@ -425,7 +431,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
     if constexpr (M >= 6 && NMAX == 2) {
         // one or two emitters: the short form ||a||^2 - sum_c |s_c^H a|^2 (scan_mfma_kernel, SIG) where it needs fewer
         // MFMAs than the projector GEMM: n = 2 from 9 antennas, n = 1 from 6
-        if (short_form_applies(c->m, c->n) && c->sig_scan && c->dSs && c->dA2p && dQ == c->dQ && !c->lab_variant) {
+        if (short_form_in_use(c) && dQ == c->dQ) {
             const double2* tb0 = c->dTB + c->tb_step_elems;
 #define BAZ_SIG_LAUNCH(SPEC, VEC4, SIGV)                                                                                    \
     hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4, 0, (1 | 2 | 16), SIGV>), dim3(G.blocks), dim3(256), 0, c->stream, \

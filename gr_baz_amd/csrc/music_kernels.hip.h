@@ -960,7 +960,8 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
         }
     }
     // lane j emits row j of Q (upper part): Q_jl = sum_{k in set} V[j][k] conj(V[l][k])
-    if (valid) {
+    // (Qs == nullptr: the scan runs the short form from Ss and never reads the projector)
+    if (valid && Qs) {
         for (int l = j; l < M; ++l) {
             double re = 0.0, im = 0.0;
             for (int i = 0; i < cnt; ++i) {
@@ -1159,7 +1160,7 @@ __global__ __launch_bounds__(64) void evd_sub_kernel(const double2* __restrict__
             }
         }
     }
-    if (emit) {   // row j of Q = I - S S^H (upper part), packed as evd_proj_kernel does
+    if (emit && Qs) {   // row j of Q = I - S S^H (upper part), packed as evd_proj_kernel does (not needed by the short-form scan)
         for (int l = j; l < M; ++l) {
             double re = 0.0, im = 0.0;
 #pragma unroll
