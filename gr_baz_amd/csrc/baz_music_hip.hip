@@ -336,12 +336,13 @@ int launch_evd_t(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ
         // ... and when that scan runs, nothing reads the projector coefficients: they are not written either
         double* const dQw = (ss && short_form_in_use(c)) ? nullptr : dQ;
         const uint8_t* only = nullptr;
-        if (c->sub_evd && c->n <= 3 && 2 * c->n <= (uint32_t)M && c->dRedo && batch <= c->cap) {
+        if (c->sub_evd && c->n <= 4 && 2 * c->n <= (uint32_t)M && c->dRedo && batch <= c->cap) {
             constexpr uint32_t GS = M <= 8 ? 8 : 16, IPS = 64 / GS;
             const uint32_t sblocks = (batch + IPS - 1) / IPS;
             if (c->n == 1) hipLaunchKernelGGL((evd_sub_kernel<M, 1>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQw, batch, qstride, dG, c->dRedo, ss);
             else if (c->n == 2) hipLaunchKernelGGL((evd_sub_kernel<M, 2>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQw, batch, qstride, dG, c->dRedo, ss);
-            else if constexpr (M >= 6) hipLaunchKernelGGL((evd_sub_kernel<M, 3>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQw, batch, qstride, dG, c->dRedo);
+            else if (c->n == 3) { if constexpr (M >= 6) hipLaunchKernelGGL((evd_sub_kernel<M, 3>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQw, batch, qstride, dG, c->dRedo); }
+            else { if constexpr (M >= 8) hipLaunchKernelGGL((evd_sub_kernel<M, 4>), dim3(sblocks), dim3(64), 0, c->stream, dR, dQw, batch, qstride, dG, c->dRedo); }
             HIP_TRY(c, hipGetLastError());
             only = c->dRedo;
         }
@@ -633,11 +634,12 @@ int process_wide_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void
         {
             ProfScope ps(c, BAZ_MUSIC_STAGE_EVD);
             const uint8_t* only = nullptr;
-            if (c->sub_evd && c->n <= 3) {     // few emitters: signal subspace by orthogonal iteration, Jacobi for what it hands back
+            if (c->sub_evd && c->n <= 4) {     // few emitters: signal subspace by orthogonal iteration, Jacobi for what it hands back
                 const size_t lds = ((size_t)c->m * (c->m + 1) + (size_t)c->n * 64) * sizeof(double2);
                 if (c->n == 1) hipLaunchKernelGGL(bazwide::sub_wide_kernel<1>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
                 else if (c->n == 2) hipLaunchKernelGGL(bazwide::sub_wide_kernel<2>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
-                else hipLaunchKernelGGL(bazwide::sub_wide_kernel<3>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
+                else if (c->n == 3) hipLaunchKernelGGL(bazwide::sub_wide_kernel<3>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
+                else hipLaunchKernelGGL(bazwide::sub_wide_kernel<4>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
                 HIP_TRY(c, hipGetLastError());
                 only = c->dRedo;
             }
@@ -887,15 +889,16 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
                 // so it is always set for the largest m, never for this context's
                 constexpr uint32_t MX = BAZ_MUSIC_MAX_M;
                 const int evd_lds = (int)wide_evd_lds(MX), scan_lds = (int)((size_t)MX * MX * sizeof(double2));
-                const int sub_lds = (int)(((size_t)MX * (MX + 1) + 3u * 64u) * sizeof(double2));
-                const void* fn[5] = {reinterpret_cast<const void*>(bazwide::evd_wide_kernel),
+                const int sub_lds = (int)(((size_t)MX * (MX + 1) + 4u * 64u) * sizeof(double2));
+                const void* fn[6] = {reinterpret_cast<const void*>(bazwide::evd_wide_kernel),
                                      reinterpret_cast<const void*>(bazwide::scan_wide_kernel),
                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<1>),
                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<2>),
-                                     reinterpret_cast<const void*>(bazwide::sub_wide_kernel<3>)};
-                const int sz[5] = {evd_lds, scan_lds, sub_lds, sub_lds, sub_lds};
+                                     reinterpret_cast<const void*>(bazwide::sub_wide_kernel<3>),
+                                     reinterpret_cast<const void*>(bazwide::sub_wide_kernel<4>)};
+                const int sz[6] = {evd_lds, scan_lds, sub_lds, sub_lds, sub_lds, sub_lds};
                 bool ok = true;
-                for (int k = 0; k < 5; ++k)
+                for (int k = 0; k < 6; ++k)
                     ok = ok && hipFuncSetAttribute(fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, sz[k]) == hipSuccess;
                 if (!ok) { r = BAZ_MUSIC_E_HIP; break; }
             }

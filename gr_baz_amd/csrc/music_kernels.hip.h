@@ -982,7 +982,7 @@ __global__ __launch_bounds__(64) void evd_proj_lds_kernel(const double2* __restr
 }
 
 // -------------------------------------------------------------------------------------
-// 2c. The projector WITHOUT the full eigen-decomposition, for m >= 5 and few emitters (n = P <= 3, 2P <= m).
+// 2c. The projector WITHOUT the full eigen-decomposition, for m >= 5 and few emitters (n = P <= 4, 2P <= m).
 //
 //     MUSIC needs only the noise-subspace projector I - S S^H, S = the eigenvectors of the n LARGEST eigenvalues
 //     (.cc:88-93 keeps the other m-n columns of eig_sym), and with n of m = 2 of 16 that invariant subspace is found far

@@ -175,7 +175,7 @@ def test_wide_arrays_match_the_oracle(m, n, N, res, batch, gpu_device):
     assert np.array_equal(Rg, Rg.conj().transpose(0, 2, 1))          # exactly Hermitian
 
 
-@pytest.mark.parametrize("m,n,K,res", [(24, 2, 40, 180), (40, 3, 48, 120), (64, 1, 64, 90)])
+@pytest.mark.parametrize("m,n,K,res", [(24, 2, 40, 180), (40, 3, 48, 120), (64, 1, 64, 90), (32, 4, 64, 180)])
 def test_wide_arrays_subspace_iteration_and_hand_back(m, n, K, res, gpu_device, monkeypatch):
     """the wide path's sub_wide_kernel against its Jacobi (BAZ_MUSIC_SUB_EVD=0) on a batch that mixes easy, slow and
     rank-deficient items; bits independent of the batch around an item"""
@@ -426,7 +426,7 @@ def test_fused_covariance_evd_kernel_equals_the_two_kernel_form(gpu_device, monk
 
 # ------------------------------------------------------------------ signal subspace by orthogonal iteration (m >= 5, n <= 3)
 @pytest.mark.parametrize("m,n,K,res", [(8, 2, 64, 360), (16, 2, 64, 360), (6, 3, 50, 200), (9, 1, 40, 180), (16, 3, 48, 500),
-                                        (5, 2, 32, 90), (13, 2, 30, 77)])
+                                        (5, 2, 32, 90), (13, 2, 30, 77), (16, 4, 64, 360), (8, 4, 40, 200), (11, 4, 48, 91)])
 def test_signal_subspace_iteration_and_its_hand_back(m, n, K, res, gpu_device, monkeypatch):
     """evd_sub_kernel finds the projector from the n dominant eigenvectors by orthogonal iteration and hands items with a
     small gap lambda_n / lambda_(n+1) back to the Jacobi.  A batch that mixes easy items (30 / 20 dB), slow ones (0 and
