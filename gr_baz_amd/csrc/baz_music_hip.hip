@@ -93,7 +93,7 @@ struct baz_music_ctx {
     double* dA2p = nullptr;        // ... and ||a||^2 per bin, padded like dFB (fb_steps + 2 steps of 64)
     int sig_scan = 1;              // lab / tests: BAZ_MUSIC_SIG_SCAN=0 keeps the projector GEMM
     uint8_t* dRedo = nullptr;      // [cap] items evd_sub_kernel hands back to the Jacobi
-    int sub_evd = 1;               // signal subspace by orthogonal iteration where n <= 3 (lab: BAZ_MUSIC_SUB_EVD=0)
+    int sub_evd = 1;               // signal subspace by orthogonal iteration where n <= 4 (lab: BAZ_MUSIC_SUB_EVD=0)
     int fused_covevd = 0;          // m = 4, K % 256 == 0: covariance + EVD in one kernel (BAZ_MUSIC_FUSE=0: lab, two kernels)
     uint32_t covevd_blocks = 512u; // grid of cov4_evd_kernel: the workgroups resident at once (2 per CU)
     uint32_t cov4_resident_blocks = 256u;        // grid of cov4_x4_kernel (persistent waves): one workgroup per CU

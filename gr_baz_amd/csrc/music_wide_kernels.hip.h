@@ -246,7 +246,7 @@ __global__ __launch_bounds__(WB) void evd_wide_kernel(const double2* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// 2b. The noise basis WITHOUT the eigen-decomposition for few emitters (P = n <= 3): the signal subspace by orthogonal
+// 2b. The noise basis WITHOUT the eigen-decomposition for few emitters (P = n <= 4): the signal subspace by orthogonal
 //     iteration, exactly the scheme of bazmusic::evd_sub_kernel (music_kernels.hip.h, section 2c) with m at run time:
 //     one wave per item, lane j = row j (m <= 64), R in LDS, all reductions XOR butterflies over the 64 lanes (DPP inside
 //     a row of 16, then lane ^ 16 and lane ^ 32: every lane ends with the same bits).  Items that do not converge are
