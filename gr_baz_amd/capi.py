@@ -27,6 +27,7 @@ SYMBOLS = [
     "baz_music_profile", "baz_music_stage_ms", "baz_music_stage_name", "baz_music_debug_cov",
     "baz_music_debug_evd", "baz_music_debug_q", "baz_music_q_stride", "baz_music_bytes_per_item", "baz_music_strerror",
     "baz_music_last_hip_error", "baz_music_version", "baz_music_device_count", "baz_music_device", "baz_music_set_peak_mode", "baz_music_refined_items",
+    "baz_music_host_register", "baz_music_set_host_pinning", "baz_music_host_unregister_all", "baz_music_host_pinned_bytes",
 ]
 
 _vp = ctypes.c_void_p
@@ -103,6 +104,14 @@ def lib():
     L.baz_music_refined_items.argtypes = [_vp]
     L.baz_music_set_peak_mode.restype = ctypes.c_int
     L.baz_music_set_peak_mode.argtypes = [_vp, ctypes.c_int]
+    L.baz_music_host_register.restype = ctypes.c_int
+    L.baz_music_host_register.argtypes = [_vp, _vp, ctypes.c_size_t]
+    L.baz_music_set_host_pinning.restype = ctypes.c_int
+    L.baz_music_set_host_pinning.argtypes = [_vp, ctypes.c_int]
+    L.baz_music_host_unregister_all.restype = ctypes.c_int
+    L.baz_music_host_unregister_all.argtypes = [_vp]
+    L.baz_music_host_pinned_bytes.restype = ctypes.c_uint64
+    L.baz_music_host_pinned_bytes.argtypes = [_vp]
     _lib = L
     return L
 
@@ -196,6 +205,22 @@ class Context:
     def refined_items(self):
         """Items of the last process call that were recomputed in literal form (near-null bins, extreme SNR)."""
         return int(lib().baz_music_refined_items(self._h))
+
+    # ---- page-locking of caller buffers that live across calls (a scheduler's stream buffers) ----
+    def host_register(self, array):
+        """Page-locks a numpy array's memory for this context (the array must outlive the registration: call
+        host_unregister_all() or close() before dropping it).  Returns the library's code: 0 = locked (or already was)."""
+        return int(lib().baz_music_host_register(self._h, _vp(array.ctypes.data), array.nbytes))
+
+    def set_host_pinning(self, enable):
+        """process() page-locks the ranges of every call the first time it sees them (persistent buffers only)."""
+        self._chk(lib().baz_music_set_host_pinning(self._h, 1 if enable else 0), "baz_music_set_host_pinning")
+
+    def host_unregister_all(self):
+        self._chk(lib().baz_music_host_unregister_all(self._h), "baz_music_host_unregister_all")
+
+    def host_pinned_bytes(self):
+        return int(lib().baz_music_host_pinned_bytes(self._h))
 
     def set_peak_mode(self, mode):
         """0: the reference's n strongest bins (default); 1: n strongest local maxima (opt-in extension)."""

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <mutex>
 #include <new>
 #include <string>
@@ -56,11 +57,12 @@ struct baz_music_ctx {
     // of chunk i and the D2H copy of chunk i-1 overlap on three streams
     struct Slot {
         float* in = nullptr;
-        float* ang = nullptr;
-        float* lvl = nullptr;
+        float* al = nullptr;         // ang then lvl of the chunk in flight, back to back (2 * cap * n floats)
+        float* h_al = nullptr;       // page-locked host image of `al`: ONE small D2H per chunk, then a CPU copy to the caller
         float* spec = nullptr;
         hipEvent_t h2d = nullptr, comp = nullptr, d2h = nullptr;
         bool busy = false;
+        uint32_t pend_done = 0, pend_nb = 0;   // the chunk whose ang / lvl still sit in h_al
     } slot[2];
     uint32_t s_cap = 0;
     bool s_has_spec = false;
@@ -101,6 +103,13 @@ struct baz_music_ctx {
     float* dPeakSpec = nullptr;   // internal spectrum when peak mode runs without the spectrum port
     size_t peak_spec_cap = 0;     // floats
     size_t chunk_bytes = 0;   // host-fed path: traffic per pipelined chunk (BAZ_MUSIC_CHUNK_MIB); 0 = by buffer kind
+    // host-fed path: page ranges of the caller's buffers this context has page-locked (baz_music_host_register)
+    struct HostPin { uintptr_t lo, hi; };                // [lo, hi): the caller's exact bytes
+    std::vector<HostPin> pins;                           // our registrations: disjoint, not touching
+    std::vector<HostPin> refused;                        // requests the runtime refused (not retried)
+    uint64_t pinned_bytes = 0;
+    uint64_t pin_limit = 4096ull << 20;                  // BAZ_MUSIC_PIN_LIMIT_MIB
+    int auto_pin = 0;                                    // baz_music_set_host_pinning
     StageProf prof[BAZ_MUSIC_NUM_STAGES];
     std::string stage_name[BAZ_MUSIC_NUM_STAGES];
     char hip_err[256] = {0};
@@ -111,6 +120,7 @@ namespace {
 int hip_fail(baz_music_ctx* c, hipError_t e, const char* what)
 {
     if (c) snprintf(c->hip_err, sizeof(c->hip_err), "%s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();   // the runtime's per-thread "last error" is sticky: do not let the next call find this one
     return BAZ_MUSIC_E_HIP;
 }
 
@@ -739,8 +749,8 @@ void free_slots(baz_music_ctx* c)
 {
     for (auto& sl : c->slot) {
         if (sl.in) (void)hipFree(sl.in);
-        if (sl.ang) (void)hipFree(sl.ang);
-        if (sl.lvl) (void)hipFree(sl.lvl);
+        if (sl.al) (void)hipFree(sl.al);
+        if (sl.h_al) (void)hipHostFree(sl.h_al);
         if (sl.spec) (void)hipFree(sl.spec);
         if (sl.h2d) (void)hipEventDestroy(sl.h2d);
         if (sl.comp) (void)hipEventDestroy(sl.comp);
@@ -762,8 +772,8 @@ int ensure_slots(baz_music_ctx* c, uint32_t chunk, bool want_spec)
     if (!c->s_d2h) HIP_TRY(c, hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
     for (auto& sl : c->slot) {
         HIP_TRY(c, hipMalloc((void**)&sl.in, (size_t)cap * c->nsamples * 8));
-        HIP_TRY(c, hipMalloc((void**)&sl.ang, (size_t)cap * c->n * 4));
-        HIP_TRY(c, hipMalloc((void**)&sl.lvl, (size_t)cap * c->n * 4));
+        HIP_TRY(c, hipMalloc((void**)&sl.al, (size_t)cap * c->n * 8));
+        HIP_TRY(c, hipHostMalloc((void**)&sl.h_al, (size_t)cap * c->n * 8, hipHostMallocDefault));
         if (spec) HIP_TRY(c, hipMalloc((void**)&sl.spec, (size_t)cap * c->res * 4));
         HIP_TRY(c, hipEventCreateWithFlags(&sl.h2d, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&sl.comp, hipEventDisableTiming));
@@ -784,6 +794,60 @@ bool is_pinned_host(const void* p)
         return false;
     }
     return a.type == hipMemoryTypeHost;
+}
+
+// Page-lock [p, p + bytes) for this context: see include/baz_music_hip.h.  Caller holds c->mtx.
+// The runtime rejects a copy whose host range is only PARTLY inside a registration (hipMemcpyAsync: invalid argument --
+// measured, also when the range straddles two registrations).  So (i) registrations are the caller's exact byte
+// ranges, never rounded out to pages (a neighbouring heap object must not end up half inside one); (ii) a request that
+// overlaps or touches earlier registrations replaces them by ONE registration of the union (a circular stream buffer
+// is covered after its first few calls); (iii) a request that cannot be locked as a whole (limit, refusal) leaves
+// nothing of itself locked: the registrations it touches are dropped.
+int host_register_locked(baz_music_ctx* c, const void* p, size_t bytes)
+{
+    if (!p || !bytes) return BAZ_MUSIC_OK;
+    uintptr_t lo = (uintptr_t)p, hi = (uintptr_t)p + bytes;
+    for (const auto& pin : c->pins)
+        if (pin.lo <= lo && hi <= pin.hi) return BAZ_MUSIC_OK;                       // known (the per-call case)
+    for (const auto& r : c->refused)
+        if (r.lo < hi && lo < r.hi) return BAZ_MUSIC_E_HIP;                          // refused before: not retried
+    std::vector<size_t> touch;
+    uint64_t held = 0;
+    for (size_t i = 0; i < c->pins.size(); ++i)
+        if (c->pins[i].hi >= lo && c->pins[i].lo <= hi) {
+            touch.push_back(i);
+            held += c->pins[i].hi - c->pins[i].lo;
+        }
+    if (touch.empty() && is_pinned_host(p) && is_pinned_host((const char*)p + bytes - 1))
+        return BAZ_MUSIC_OK;                   // its owner's page-locked memory (hipHostMalloc, torch): not ours to manage
+    for (size_t i : touch) {
+        lo = std::min(lo, c->pins[i].lo);
+        hi = std::max(hi, c->pins[i].hi);
+    }
+    const bool fits = c->pinned_bytes - held + (hi - lo) <= c->pin_limit;
+    for (size_t k = touch.size(); k-- > 0;) {                                         // back to front: indices stay valid
+        if (hipHostUnregister((void*)c->pins[touch[k]].lo) != hipSuccess) (void)hipGetLastError();
+        c->pins.erase(c->pins.begin() + touch[k]);
+    }
+    c->pinned_bytes -= held;
+    if (!fits) return BAZ_MUSIC_E_UNSUPPORTED;
+    const hipError_t e = hipHostRegister((void*)lo, hi - lo, hipHostRegisterDefault);
+    if (e == hipSuccess) {
+        c->pins.push_back({lo, hi});
+        c->pinned_bytes += hi - lo;
+        return BAZ_MUSIC_OK;
+    }
+    c->refused.push_back({lo, hi});
+    return hip_fail(c, e, "hipHostRegister");
+}
+
+void host_unregister_all_locked(baz_music_ctx* c)
+{
+    for (const auto& pin : c->pins)
+        if (hipHostUnregister((void*)pin.lo) != hipSuccess) (void)hipGetLastError();   // already unmapped
+    c->pins.clear();
+    c->refused.clear();
+    c->pinned_bytes = 0;
 }
 
 // One pass of the hot path over `batch` device-resident items: covariance, EVD, scan (with the literal-form
@@ -877,6 +941,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     c->device = dev;
     if (const char* v = getenv("BAZ_MUSIC_SCAN_VARIANT")) c->lab_variant = atoi(v);
     if (const char* v = getenv("BAZ_MUSIC_CHUNK_MIB")) c->chunk_bytes = (size_t)std::max(1, std::min(1024, atoi(v))) << 20;
+    if (const char* v = getenv("BAZ_MUSIC_PIN_LIMIT_MIB")) c->pin_limit = (uint64_t)std::max(0, atoi(v)) << 20;
     DeviceGuard guard(dev);
     int r = BAZ_MUSIC_OK;
     do {
@@ -1006,6 +1071,7 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->dWS) (void)hipFree(c->dWS);
         if (c->dSw) (void)hipFree(c->dSw);
         if (c->dA2) (void)hipFree(c->dA2);
+        host_unregister_all_locked(c);
         free_slots(c);
         if (c->ev_in) (void)hipEventDestroy(c->ev_in);
         if (c->ev_out) (void)hipEventDestroy(c->ev_out);
@@ -1062,6 +1128,7 @@ int baz_music_process_device(baz_music_ctx* c, const void* d_in, uint32_t batch,
     if (batch == 0) return BAZ_MUSIC_OK;
     std::lock_guard<std::mutex> lk(c->mtx);   // .cc:101
     DeviceGuard guard(c->device);
+    (void)hipGetLastError();                  // launches below are checked with hipGetLastError(): start from a clean slate
     int r = begin_statistic(c);
     return r ? r : process_device_locked(c, d_in, batch, d_ang, d_lvl, d_spec);
 }
@@ -1073,6 +1140,7 @@ int baz_music_process_device_on(baz_music_ctx* c, void* caller_stream, const voi
     if (batch == 0) return BAZ_MUSIC_OK;
     std::lock_guard<std::mutex> lk(c->mtx);   // .cc:101
     DeviceGuard guard(c->device);
+    (void)hipGetLastError();                  // launches below are checked with hipGetLastError(): start from a clean slate
     hipStream_t cs = static_cast<hipStream_t>(caller_stream);
     const bool foreign = (cs != c->stream);
     if (foreign) {
@@ -1098,19 +1166,38 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
     if (batch == 0) return 0;
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
+    (void)hipGetLastError();
 
-    // chunks of ~BAZ_MUSIC_CHUNK_MIB of traffic each (>= 64 items): a GNU Radio work() call of a few thousand items
-    // still becomes several chunks, so that H2D of chunk i+1, the kernels of chunk i and D2H of chunk i-1 overlap
-    // (measured, profiles/r01h_hostfed_chunk_sweep.txt: pageable buffers want big chunks -- the runtime's pageable copy
-    // has a large fixed cost --, page-locked ones overlap best at 16-32 MiB)
+    if (c->auto_pin) {   // the caller's (scheduler's) buffers: lock what this call touches and is not locked yet
+        // (the two DMA targets; ang / lvl travel through the slots' own page-locked image)
+        (void)host_register_locked(c, in_ri, (size_t)batch * c->nsamples * 8);
+        if (spectrum) (void)host_register_locked(c, spectrum, (size_t)batch * c->res * 4);
+    }
+    // Cutting a call into chunks (H2D of chunk i+1, the kernels of chunk i and D2H of chunk i-1 overlap on three
+    // streams) only pays when a chunk carries enough bytes to hide what the extra copies, events and stream hops cost.
+    // Measured under the scheduler model (profiles/r02_flowgraph_model_rates.txt): a 128-item config-2 call (2.9 MB) cut
+    // in two ran at 0.41-0.53 ms, as one chunk on one stream at 0.20-0.22 ms; pageable 2,048-item calls (46 MB) in four
+    // chunks were SLOWER per item than 512-item calls in one (the runtime stages pageable copies and blocks in them, so
+    // little overlaps).  Hence:
+    //   page-locked caller memory   below 16 MiB of traffic ONE chunk on ONE stream (copy in, three launches, copies
+    //                               out, one synchronize); above, >= 4 chunks of >= 8 MiB and <= 32 MiB each;
+    //   pageable caller memory      one chunk up to 64 MiB, 64-MiB chunks beyond (profiles/r01h_hostfed_chunk_sweep.txt);
+    //   BAZ_MUSIC_CHUNK_MIB         forces the chunk size (tests, lab).
     const size_t per_item = (size_t)c->nsamples * 8 + (size_t)c->res * 4 + (size_t)c->n * 8;
-    size_t chunk_bytes = c->chunk_bytes;
-    if (!chunk_bytes) chunk_bytes = (is_pinned_host(in_ri) && (!spectrum || is_pinned_host(spectrum))) ? (32u << 20) : (64u << 20);
-    // ... but a call is always cut into >= 4 chunks (of >= 64 items) so that the three stages overlap inside ONE work()
-    // call too: a 4,096-item cfg2 call used to be 1.4 chunks, i.e. copy-in, kernels and copy-out back to back.
-    const size_t by_bytes = std::max<size_t>(64, chunk_bytes / per_item);
-    const size_t by_count = std::max<size_t>(64, ((size_t)batch + 3) / 4);
-    const uint32_t chunk = (uint32_t)std::min<size_t>(batch, c->chunk_bytes ? by_bytes : std::min(by_bytes, by_count));
+    const bool locked = is_pinned_host(in_ri) && (!spectrum || is_pinned_host(spectrum));
+    uint32_t chunk;
+    if (c->chunk_bytes) {
+        chunk = (uint32_t)std::min<size_t>(batch, std::max<size_t>(64, c->chunk_bytes / per_item));
+    } else if (!locked) {
+        chunk = (uint32_t)std::min<size_t>(batch, std::max<size_t>(64, (64u << 20) / per_item));
+    } else if ((size_t)batch * per_item < (16u << 20)) {
+        chunk = batch;
+    } else {
+        const size_t floor_items = std::max<size_t>(64, (8u << 20) / per_item);
+        const size_t by_count = std::max<size_t>(floor_items, ((size_t)batch + 3) / 4);
+        chunk = (uint32_t)std::min<size_t>(batch, std::min<size_t>(std::max<size_t>(64, (32u << 20) / per_item), by_count));
+    }
+    const bool single = chunk >= batch;
     const bool want_spec = spectrum != nullptr;
     int r = ensure_slots(c, chunk, want_spec);
     if (r) return r;
@@ -1131,36 +1218,91 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
         hipError_t e__ = (call);                                           \
         if (e__ != hipSuccess) rc = hip_fail(c, e__, #call);               \
     }
+    // ang / lvl of a finished chunk: from the slot's page-locked image to the caller's two streams
+    auto hand_over = [&](baz_music_ctx::Slot& sl) {
+        if (!sl.pend_nb) return;
+        const size_t cnt = (size_t)sl.pend_nb * c->n;
+        memcpy(ang + (size_t)sl.pend_done * c->n, sl.h_al, cnt * 4);
+        if (lvl) memcpy(lvl + (size_t)sl.pend_done * c->n, sl.h_al + cnt, cnt * 4);
+        sl.pend_nb = 0;
+    };
+    hipStream_t s_in = single ? c->stream : c->s_h2d, s_out = single ? c->stream : c->s_d2h;
     for (uint32_t done = 0; done < batch && rc == BAZ_MUSIC_OK; done += chunk, ++idx) {
         baz_music_ctx::Slot& sl = c->slot[idx & 1];
         const uint32_t nb = std::min(chunk, batch - done);
         if (sl.busy) {   // chunk idx-2 used this slot: its outputs must be on the host before we reuse it
             HIP_STEP(hipEventSynchronize(sl.d2h));
+            if (rc == BAZ_MUSIC_OK) hand_over(sl);
             sl.busy = false;
         }
+        float* d_ang = sl.al;
+        float* d_lvl = sl.al + (size_t)nb * c->n;
         HIP_STEP(hipMemcpyAsync(sl.in, in_ri + (size_t)done * c->nsamples * 2, (size_t)nb * c->nsamples * 8,
-                                hipMemcpyHostToDevice, c->s_h2d));
-        HIP_STEP(hipEventRecord(sl.h2d, c->s_h2d));
-        HIP_STEP(hipStreamWaitEvent(c->stream, sl.h2d, 0));
-        if (rc == BAZ_MUSIC_OK) rc = process_device_locked(c, sl.in, nb, sl.ang, sl.lvl, want_spec ? sl.spec : nullptr);
-        HIP_STEP(hipEventRecord(sl.comp, c->stream));
-        HIP_STEP(hipStreamWaitEvent(c->s_d2h, sl.comp, 0));
-        HIP_STEP(hipMemcpyAsync(ang + (size_t)done * c->n, sl.ang, (size_t)nb * c->n * 4, hipMemcpyDeviceToHost, c->s_d2h));
-        if (lvl)
-            HIP_STEP(hipMemcpyAsync(lvl + (size_t)done * c->n, sl.lvl, (size_t)nb * c->n * 4, hipMemcpyDeviceToHost, c->s_d2h));
+                                hipMemcpyHostToDevice, s_in));
+        if (!single) {
+            HIP_STEP(hipEventRecord(sl.h2d, s_in));
+            HIP_STEP(hipStreamWaitEvent(c->stream, sl.h2d, 0));
+        }
+        if (rc == BAZ_MUSIC_OK) rc = process_device_locked(c, sl.in, nb, d_ang, d_lvl, want_spec ? sl.spec : nullptr);
+        if (!single) {
+            HIP_STEP(hipEventRecord(sl.comp, c->stream));
+            HIP_STEP(hipStreamWaitEvent(s_out, sl.comp, 0));
+        }
+        HIP_STEP(hipMemcpyAsync(sl.h_al, sl.al, (size_t)nb * c->n * 8, hipMemcpyDeviceToHost, s_out));
         if (want_spec)
             HIP_STEP(hipMemcpyAsync(spectrum + (size_t)done * c->res, sl.spec, (size_t)nb * c->res * 4,
-                                    hipMemcpyDeviceToHost, c->s_d2h));
-        HIP_STEP(hipEventRecord(sl.d2h, c->s_d2h));
+                                    hipMemcpyDeviceToHost, s_out));
+        if (!single) HIP_STEP(hipEventRecord(sl.d2h, s_out));
         sl.busy = (rc == BAZ_MUSIC_OK);
+        if (sl.busy) {
+            sl.pend_done = done;
+            sl.pend_nb = nb;
+        }
     }
 #undef HIP_STEP
     // drain (also on the error path) so that no copy still targets the caller's buffers
-    (void)hipStreamSynchronize(c->s_h2d);
+    if (!single) (void)hipStreamSynchronize(c->s_h2d);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipStreamSynchronize(c->s_d2h);
-    c->slot[0].busy = c->slot[1].busy = false;
+    if (!single) (void)hipStreamSynchronize(c->s_d2h);
+    for (auto& sl : c->slot) {
+        if (rc == BAZ_MUSIC_OK && sl.busy) hand_over(sl);
+        sl.busy = false;
+        sl.pend_nb = 0;
+    }
     return rc ? rc : (int)batch;
+}
+
+int baz_music_host_register(baz_music_ctx* c, const void* p, size_t bytes)
+{
+    if (!c || (!p && bytes)) return BAZ_MUSIC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    DeviceGuard guard(c->device);
+    return host_register_locked(c, p, bytes);
+}
+
+int baz_music_set_host_pinning(baz_music_ctx* c, int enable)
+{
+    if (!c) return BAZ_MUSIC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    c->auto_pin = enable ? 1 : 0;
+    return BAZ_MUSIC_OK;
+}
+
+int baz_music_host_unregister_all(baz_music_ctx* c)
+{
+    if (!c) return BAZ_MUSIC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    DeviceGuard guard(c->device);
+    (void)hipStreamSynchronize(c->s_h2d ? c->s_h2d : c->stream);
+    host_unregister_all_locked(c);
+    return BAZ_MUSIC_OK;
+}
+
+uint64_t baz_music_host_pinned_bytes(baz_music_ctx* c)
+{
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    return c->pinned_bytes;
 }
 
 int baz_music_profile(baz_music_ctx* c, int enable)

@@ -87,7 +87,7 @@ baz_music_doa::baz_music_doa(unsigned int m, unsigned int n, unsigned int nsampl
                      gr::io_signature::make3(1, 3, n * sizeof(float), n * sizeof(float),
                                              resolution * sizeof(float))),
       d_m(m), d_n(n), d_nsamples(nsamples), d_resolution(resolution),
-      d_array_response(array_response), d_ctx(NULL)
+      d_array_response(array_response), d_ctx(NULL), d_pin_buffers(false)
 {
     const std::vector<float> flat = flatten_response(array_response, m, resolution);
     const int rc = baz_music_create(&d_ctx, m, n, nsamples, resolution, flat.data(), next_device());
@@ -103,6 +103,7 @@ baz_music_doa::baz_music_doa(unsigned int m, unsigned int n, unsigned int nsampl
      *                              the default 64 KiB (= 8 cfg2 items);
      *   set_min_output_buffer(B)   output buffers of at least B items, so that several multiples fit one call;
      *   set_max_noutput_items(C)   a CAP, separate from the two requests above, unset by default.
+     * What the runtime makes of them (call sizes per work()) is modelled in gr_shim/gnuradio/flowgraph_model.h.
      * N trades latency for launch efficiency (N items must have arrived before work() runs); the environment
      * overrides the defaults: BAZ_MUSIC_OUTPUT_MULTIPLE (64), BAZ_MUSIC_MIN_OUTPUT_BUFFER (8 multiples),
      * BAZ_MUSIC_MAX_NOUTPUT (0 = no cap). */
@@ -112,6 +113,8 @@ baz_music_doa::baz_music_doa(unsigned int m, unsigned int n, unsigned int nsampl
     set_output_multiple((int)multiple);
     if (min_buffer > 0) set_min_output_buffer(min_buffer);
     if (cap > 0) set_max_noutput_items((int)std::max(cap, multiple));
+
+    set_pin_buffers(env_long("BAZ_MUSIC_PIN_BUFFERS", 1, 0, 1) != 0);
 
     fprintf(stderr, "[%s<%li>] MUSIC DOA: M: %d, N: %d, # samples: %d, angular resolution: %d\n",
             name().c_str(), unique_id(), m, n, nsamples, resolution);
@@ -123,6 +126,23 @@ baz_music_doa::~baz_music_doa()
 }
 
 int baz_music_doa::device() const { return baz_music_device(d_ctx); }
+
+void baz_music_doa::set_pin_buffers(bool on)
+{
+    if (!on) (void)baz_music_host_unregister_all(d_ctx);
+    (void)baz_music_set_host_pinning(d_ctx, on ? 1 : 0);
+    d_pin_buffers = on;
+}
+
+unsigned long long baz_music_doa::pinned_bytes() const { return baz_music_host_pinned_bytes(d_ctx); }
+
+bool baz_music_doa::start() { return true; }
+
+bool baz_music_doa::stop()
+{
+    (void)baz_music_host_unregister_all(d_ctx);   /* the flowgraph's buffers go away after this */
+    return true;
+}
 
 void baz_music_doa::set_peak_mode(bool local_maxima)
 {

@@ -61,6 +61,16 @@ public:
      * instead of the n strongest bins (baz_music_set_peak_mode, include/baz_music_hip.h). */
     void set_peak_mode(bool local_maxima);
 
+    /* Page-locking of the scheduler's stream buffers (baz_music_set_host_pinning, include/baz_music_hip.h): work()
+     * registers the ranges it is handed the first time it sees them, stop() and the destructor release them.  On by
+     * default (BAZ_MUSIC_PIN_BUFFERS=0 turns it off): GNU Radio's buffers outlive every work() call.  A caller that
+     * hands work() temporaries (the pybind stand-in does) must switch it off. */
+    void set_pin_buffers(bool on);
+    bool pin_buffers() const { return d_pin_buffers; }
+    unsigned long long pinned_bytes() const;
+    bool start();   /* gr::block::start */
+    bool stop();    /* gr::block::stop: releases the page locks while the buffers still exist */
+
     unsigned int m() const { return d_m; }
     unsigned int n() const { return d_n; }
     unsigned int nsamples() const { return d_nsamples; }
@@ -77,6 +87,7 @@ private:
     array_response_t d_array_response;   /* host copy, guarded by d_mutex */
     gr::thread::mutex d_mutex;
     baz_music_ctx* d_ctx;                /* device-side state (table, workspace, stream) */
+    bool d_pin_buffers;
 };
 
 /* Placement rule of independent block instances (BASELINE config 4: 64 streams in one flowgraph; SURVEY.md 8e,

@@ -12,6 +12,8 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <gnuradio/flowgraph_model.h>
+
 namespace py = pybind11;
 
 namespace {
@@ -43,6 +45,105 @@ py::tuple drive_work(music_doa_handle& h, py::array_t<std::complex<float>, py::a
     }
     py::object none = py::none();
     return py::make_tuple(produced, ang, n_outputs > 1 ? py::object(lvl) : none, n_outputs > 2 ? py::object(spec) : none);
+}
+
+py::dict stats_dict(const gr::shim::run_stats& st)
+{
+    py::dict d, sizes;
+    for (std::map<long, long>::const_iterator it = st.call_sizes.begin(); it != st.call_sizes.end(); ++it)
+        sizes[py::int_(it->first)] = it->second;
+    d["calls"] = st.calls;
+    d["items"] = st.items;
+    d["dropped_at_end"] = st.dropped_at_end;
+    d["in_bufsize"] = st.in_bufsize;
+    d["out_bufsize"] = st.out_bufsize;
+    d["call_sizes"] = sizes;
+    d["work_seconds"] = st.work_seconds;
+    d["total_seconds"] = st.total_seconds;
+    d["steady_items"] = st.steady_items;
+    d["steady_work_seconds"] = st.steady_work_seconds;
+    d["last_return"] = st.last_return;
+    return d;
+}
+
+// the block between a saturating source and draining sinks, driven as gnuradio-runtime 3.7 would (flowgraph_model.h):
+// persistent doubly mapped buffers sized from the block's hints, one work() per executor iteration
+py::tuple run_flowgraph(music_doa_handle& h, py::array_t<std::complex<float>, py::array::c_style | py::array::forcecast> items,
+                        int n_outputs, bool collect, bool pin, int passes)
+{
+    if (n_outputs < 1 || n_outputs > 3) throw std::invalid_argument("n_outputs must be 1, 2 or 3");
+    py::buffer_info bi = items.request();
+    const size_t N = h.blk->nsamples();
+    if (bi.size == 0 || (size_t)bi.size % N != 0) throw std::invalid_argument("items must hold k * nsamples complex64");
+    const long nitems = (long)((size_t)bi.size / N);
+    const size_t keep = collect ? (size_t)nitems : 0;
+    py::array_t<float> ang({keep, (size_t)h.blk->n()});
+    py::array_t<float> lvl({keep, (size_t)h.blk->n()});
+    py::array_t<float> spec({keep, (size_t)h.blk->resolution()});
+    char* sinks[3] = {NULL, NULL, NULL};
+    if (collect) {
+        sinks[0] = (char*)ang.mutable_data();
+        if (n_outputs > 1) sinks[1] = (char*)lvl.mutable_data();
+        if (n_outputs > 2) sinks[2] = (char*)spec.mutable_data();
+    }
+    gr::shim::run_stats st;
+    unsigned long long pinned = 0;
+    {
+        py::gil_scoped_release nogil;
+        h.blk->set_pin_buffers(pin);
+        struct restore {
+            baz_music_doa& b;
+            ~restore() { b.set_pin_buffers(false); }   // also releases whatever a failed run left registered
+        } r = {*h.blk};
+        st = gr::shim::run_sync_block(*h.blk, (const char*)bi.ptr, nitems, n_outputs, sinks, &pinned, passes);
+    }
+    py::dict d = stats_dict(st);
+    d["pinned_bytes_at_stop"] = pinned;
+    py::object none = py::none();
+    return py::make_tuple(d, collect ? py::object(ang) : none, collect && n_outputs > 1 ? py::object(lvl) : none,
+                          collect && n_outputs > 2 ? py::object(spec) : none);
+}
+
+// a device-free sync block for the model's self-test: copies its input to every output
+class shim_copy_block : public gr::sync_block
+{
+public:
+    shim_copy_block(int item, int nout, int multiple, long min_buffer, int cap)
+        : gr::sync_block("shim_copy", gr::io_signature::make(1, 1, item), gr::io_signature::make(1, 3, item)), d_item(item), d_nout(nout)
+    {
+        set_output_multiple(multiple);
+        if (min_buffer > 0) set_min_output_buffer(min_buffer);
+        if (cap > 0) set_max_noutput_items(cap);
+    }
+    int work(int noutput_items, gr_vector_const_void_star& in, gr_vector_void_star& out)
+    {
+        for (int p = 0; p < d_nout; ++p) std::memcpy(out[p], in[0], (size_t)noutput_items * (size_t)d_item);
+        return noutput_items;
+    }
+    unsigned long long pinned_bytes() const { return 0; }
+
+private:
+    int d_item, d_nout;
+};
+
+py::tuple model_selftest(py::array_t<unsigned char, py::array::c_style | py::array::forcecast> data, int item_size, int n_outputs,
+                         int multiple, long min_buffer, int cap)
+{
+    py::buffer_info bi = data.request();
+    if (item_size <= 0 || bi.size % item_size) throw std::invalid_argument("data must hold k * item_size bytes");
+    const long nitems = (long)(bi.size / item_size);
+    shim_copy_block blk(item_size, n_outputs, multiple, min_buffer, cap);
+    std::vector<py::array_t<unsigned char> > outs;
+    char* sinks[3] = {NULL, NULL, NULL};
+    for (int p = 0; p < n_outputs; ++p) {
+        outs.push_back(py::array_t<unsigned char>((size_t)bi.size));
+        sinks[p] = (char*)outs[p].mutable_data();
+    }
+    unsigned long long pinned = 0;
+    const gr::shim::run_stats st = gr::shim::run_sync_block(blk, (const char*)bi.ptr, nitems, n_outputs, sinks, &pinned);
+    py::list l;
+    for (int p = 0; p < n_outputs; ++p) l.append(outs[p]);
+    return py::make_tuple(stats_dict(st), l);
 }
 
 struct agc_handle {
@@ -141,7 +242,14 @@ PYBIND11_MODULE(_baz_music, mod)
         .def("output_multiple", [](music_doa_handle& h) { return h.blk->output_multiple(); })
         .def("min_output_buffer", [](music_doa_handle& h) { return h.blk->min_output_buffer(); })
         .def("max_noutput_items", [](music_doa_handle& h) { return h.blk->max_noutput_items(); })
-        .def("work", &drive_work, py::arg("items"), py::arg("n_outputs") = 3);
+        .def("work", &drive_work, py::arg("items"), py::arg("n_outputs") = 3)
+        /* page-locking of caller buffers: off in this stand-in (work() above is handed numpy temporaries), on for the
+         * persistent buffers of run_flowgraph() when asked */
+        .def("set_pin_buffers", [](music_doa_handle& h, bool on) { h.blk->set_pin_buffers(on); }, py::arg("on"))
+        .def("pin_buffers", [](music_doa_handle& h) { return h.blk->pin_buffers(); })
+        .def("pinned_bytes", [](music_doa_handle& h) { return h.blk->pinned_bytes(); })
+        .def("run_flowgraph", &run_flowgraph, py::arg("items"), py::arg("n_outputs") = 3, py::arg("collect") = true,
+             py::arg("pin") = false, py::arg("passes") = 1);
     py::class_<agc_handle>(mod, "baz_agc_cc_sptr")
         .def("name", [](agc_handle& h) { return h.blk->name(); })
         .def("input_item_sizes", [](agc_handle& h) { return h.blk->input_signature()->sizeof_stream_items(); })
@@ -191,12 +299,35 @@ PYBIND11_MODULE(_baz_music, mod)
                 return h;
             },
             py::arg("rate") = 1e-4f, py::arg("reference") = 1.0f, py::arg("gain") = 1.0f, py::arg("max_gain") = 0.0f);
+    /* gnuradio-runtime 3.7's buffer sizing and call planning as restated in gr_shim/gnuradio/flowgraph_model.h */
+    mod.def("gr37_buffer_items",
+            [](long item_size, int output_multiple, long min_output_buffer, long max_output_buffer,
+               const std::vector<std::tuple<double, int, int> >& downstream, long page_size) {
+                std::vector<gr::shim::downstream_t> r;
+                for (size_t i = 0; i < downstream.size(); ++i)
+                    r.push_back(gr::shim::downstream_t{std::get<0>(downstream[i]), std::get<1>(downstream[i]), std::get<2>(downstream[i])});
+                return gr::shim::buffer_items(item_size, output_multiple, min_output_buffer, max_output_buffer, r, page_size);
+            },
+            py::arg("item_size"), py::arg("output_multiple") = 1, py::arg("min_output_buffer") = -1L,
+            py::arg("max_output_buffer") = -1L, py::arg("downstream") = std::vector<std::tuple<double, int, int> >(),
+            py::arg("page_size") = 4096L);
+    mod.def("gr37_plan_noutput",
+            [](long items_in, const std::vector<long>& out_space, const std::vector<long>& out_bufsize, int multiple, int history,
+               int max_noutput_items) {
+                return gr::shim::plan_noutput(items_in, out_space, out_bufsize, multiple, history, max_noutput_items > 0,
+                                              max_noutput_items);
+            },
+            py::arg("items_in"), py::arg("out_space"), py::arg("out_bufsize"), py::arg("multiple") = 1, py::arg("history") = 1,
+            py::arg("max_noutput_items") = 0);
+    mod.def("gr37_model_selftest", &model_selftest, py::arg("data"), py::arg("item_size"), py::arg("n_outputs") = 1,
+            py::arg("multiple") = 1, py::arg("min_buffer") = -1L, py::arg("cap") = 0);
     mod.def("deal_device", &baz_music_doa_deal_device, py::arg("instance"), py::arg("device_count"),
             "placement rule of block instances: instance % device_count (-1 without devices)");
     mod.def("music_doa",
             [](unsigned int m, unsigned int n, unsigned int nsamples, const array_response_t& table, unsigned int resolution) {
                 music_doa_handle h;
                 h.blk = baz_make_music_doa(m, n, nsamples, table, resolution);
+                h.blk->set_pin_buffers(false);   // work() is handed temporaries here; run_flowgraph(pin=True) opts in
                 return h;
             },
             py::arg("m"), py::arg("n"), py::arg("nsamples"), py::arg("array_response"), py::arg("resolution"));

@@ -22,13 +22,23 @@ public:
     io_signature::sptr input_signature() const { return d_input_signature; }
     io_signature::sptr output_signature() const { return d_output_signature; }
 
-    /* scheduler hints (recorded only; the real runtime acts on them) */
+    /* scheduler hints (recorded; flowgraph_model.h acts on them the way the real runtime does) */
     void set_output_multiple(int multiple) { d_output_multiple = multiple; }
     int output_multiple() const { return d_output_multiple; }
-    void set_max_noutput_items(int m) { d_max_noutput_items = m; }
+    void set_max_noutput_items(int m) { d_max_noutput_items = m; d_max_noutput_items_set = true; }
     int max_noutput_items() const { return d_max_noutput_items; }
+    bool is_set_max_noutput_items() const { return d_max_noutput_items_set; }
     void set_min_output_buffer(long min_output_buffer) { d_min_output_buffer = min_output_buffer; }
     long min_output_buffer() const { return d_min_output_buffer; }
+    void set_max_output_buffer(long max_output_buffer) { d_max_output_buffer = max_output_buffer; }
+    long max_output_buffer() const { return d_max_output_buffer; }
+    unsigned history() const { return d_history; }
+    void set_history(unsigned history) { d_history = history; }
+    double relative_rate() const { return 1.0; }   /* sync block */
+
+    /* called by the runtime when the flowgraph starts / stops (gr::block::start / stop) */
+    virtual bool start() { return true; }
+    virtual bool stop() { return true; }
 
     /* 1:1 rate block: returns the number of items produced == consumed on every input; -1 = done */
     virtual int work(int noutput_items, gr_vector_const_void_star& input_items,
@@ -37,7 +47,8 @@ public:
 protected:
     sync_block(const std::string& name, io_signature::sptr input_signature, io_signature::sptr output_signature)
         : d_name(name), d_input_signature(input_signature), d_output_signature(output_signature),
-          d_unique_id(next_unique_id()), d_output_multiple(1), d_max_noutput_items(0), d_min_output_buffer(-1)
+          d_unique_id(next_unique_id()), d_output_multiple(1), d_max_noutput_items(0), d_max_noutput_items_set(false),
+          d_min_output_buffer(-1), d_max_output_buffer(-1), d_history(1)
     {
     }
 
@@ -51,7 +62,9 @@ private:
     io_signature::sptr d_input_signature, d_output_signature;
     long d_unique_id;
     int d_output_multiple, d_max_noutput_items;
-    long d_min_output_buffer;
+    bool d_max_noutput_items_set;
+    long d_min_output_buffer, d_max_output_buffer;
+    unsigned d_history;
 };
 
 }  // namespace gr

@@ -153,6 +153,30 @@ BAZ_MUSIC_API int64_t baz_music_refined_items(baz_music_ctx* ctx);
 BAZ_MUSIC_API int baz_music_device_count(void);
 BAZ_MUSIC_API int baz_music_device(const baz_music_ctx* ctx);
 
+/* Host-fed path: page-locking of the CALLER's buffers.  baz_music_process() copies straight
+ * between the caller's host memory and HBM; when that memory is pageable the runtime stages every copy through its own
+ * bounce buffers (measured: 1.1e6 items/s pageable against 2.5e6 page-locked for 8-MiB calls of config 2).  A
+ * scheduler's stream buffers live as long as the flowgraph and are handed to work() over and over, so they are worth
+ * locking once:
+ *   baz_music_host_register(ctx, p, bytes)   page-locks [p, p+bytes) for this context (hipHostRegister on exactly
+ *       that range, or on its union with the registrations of this context it overlaps or touches: a buffer may be
+ *       registered piecewise, and may map the same physical pages twice like GNU Radio's circular buffers; every
+ *       request ends up inside ONE registration, because the runtime rejects copies that are only partly inside one).
+ *       0 when the range is locked (or already was, also by its owner: hipHostMalloc / torch pinned memory);
+ *       BAZ_MUSIC_E_HIP when the runtime refuses it (remembered, not retried); BAZ_MUSIC_E_UNSUPPORTED when the
+ *       context's limit (BAZ_MUSIC_PIN_LIMIT_MIB, default 4096) would be exceeded.  A range that cannot be locked as
+ *       a whole is left entirely pageable (registrations it touches are dropped); process() works on it either way.
+ *   baz_music_set_host_pinning(ctx, 1)       makes baz_music_process() do that for the input and spectrum ranges of
+ *       every call before it copies (a lookup per call once they are known).  Default 0: the caller must guarantee that the
+ *       memory outlives the registration -- true for scheduler buffers, not for temporaries.
+ *   baz_music_host_unregister_all(ctx)       undoes every registration of this context (also done by destroy);
+ *       call it before the buffers are unmapped (the host block does in stop()).
+ *   baz_music_host_pinned_bytes(ctx)         bytes this context holds locked. */
+BAZ_MUSIC_API int baz_music_host_register(baz_music_ctx* ctx, const void* p, size_t bytes);
+BAZ_MUSIC_API int baz_music_set_host_pinning(baz_music_ctx* ctx, int enable);
+BAZ_MUSIC_API int baz_music_host_unregister_all(baz_music_ctx* ctx);
+BAZ_MUSIC_API uint64_t baz_music_host_pinned_bytes(baz_music_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

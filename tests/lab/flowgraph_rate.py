@@ -1,0 +1,44 @@
+"""Lab (GPU box): the MUSIC host block driven the way gnuradio-runtime 3.7 would drive it (gr_shim/gnuradio/flowgraph_model.h:
+persistent doubly mapped stream buffers sized from the block's hints, one work() per executor iteration, saturating
+source, draining sinks), config 2, by output multiple, with and without page-locking of the stream buffers and with
+and without the spectrum port.  Host-fed, PCIe-inclusive: NOT the headline metric.  argv: [items=16384]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+from gr_baz_amd import synth
+from gr_baz_amd.baz.music_doa_helper import calculate_antenna_array_response
+
+M, NE, N, RES = 4, 2, 1024, 3600
+ITEMS = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+dev = torch.device("cuda:0")
+arr = synth.array_geometry(M)
+table = calculate_antenna_array_response([[0.5 * x, 0.5 * y] for x, y in arr], RES, 1.0)
+x = synth.synth_stream(torch, dev, ITEMS, M, N, arr, synth.C_LIGHT, 0.5, seed=1002)
+items = np.ascontiguousarray(torch.view_as_complex(x.reshape(ITEMS, N, 2)).cpu().numpy())
+del x
+
+for multiple in (1, 64, 256, 1024, 4096):
+    os.environ["BAZ_MUSIC_OUTPUT_MULTIPLE"] = str(multiple)
+    os.environ.pop("BAZ_MUSIC_MIN_OUTPUT_BUFFER", None)
+    if multiple == 1:
+        os.environ["BAZ_MUSIC_MIN_OUTPUT_BUFFER"] = "0"          # the reference's block: no hints at all
+    from gr_baz_amd import baz
+    blk = baz.music_doa(M, NE, N, table, RES)
+    for n_outputs in (3, 2):
+        for pin in (False, True):
+            # 4 passes over the source data; the rates are those of passes 2-4 (buffers touched, page locks taken)
+            best, _, _, _ = blk.run_flowgraph(items, n_outputs, False, pin, 4)
+            if best["last_return"] < 0 or not best["steady_items"]:
+                print("multiple %d ports %d pin %s: work() returned %d after %d items" % (multiple, n_outputs, pin, best["last_return"], best["items"]))
+                continue
+            sizes = ", ".join("%d x %d" % (v, k) for k, v in sorted(best["call_sizes"].items(), reverse=True)[:3])
+            print("multiple %5d%s  ports %d  stream buffers %-11s  in/out buffers %5d / %s items  calls: %-28s  work() %.3e items/s  "
+                  "whole run incl. first pass and source / sink copies %.3e items/s  locked %.1f MiB"
+                  % (multiple, " (no hints)" if multiple == 1 else "           ", n_outputs, "page-locked" if pin else "pageable",
+                     best["in_bufsize"], best["out_bufsize"], sizes, best["steady_items"] / best["steady_work_seconds"],
+                     best["items"] / best["total_seconds"], best["pinned_bytes_at_stop"] / 2**20), flush=True)
+    del blk

@@ -144,3 +144,21 @@ def test_plain_c_consumer_finds_the_emitter(tmp_path, gpu_device):
     for l in lines:
         f = l.split()
         assert abs(float(f[3]) - 137.0) <= 1.0 and f[-1] == "1"
+
+
+def test_collecting_the_suite_does_not_load_the_native_libraries():
+    """pytest imports every test module before the first test runs.  A module that imports gr_baz_amd.baz (or calls
+    capi.lib()) at import time loads /opt/rocm's HIP runtime BEFORE torch brings its own copy of the same soname, and the
+    process then runs torch on a runtime it was not built for (seen once as 'no usable gfx950 device' in the first GPU
+    test).  Native code is loaded lazily, inside tests."""
+    import subprocess
+    import sys
+    code = ("import sys, importlib, glob, os\n"
+            "sys.path.insert(0, 'tests')\n"
+            "for f in sorted(glob.glob('tests/test_*.py')):\n"
+            "    importlib.import_module(os.path.basename(f)[:-3])\n"
+            "print(sorted(set(os.path.basename(l.split()[-1]) for l in open('/proc/self/maps') if 'libbaz_' in l or '_baz_music' in l "
+            "or 'libgnuradio_baz' in l)))\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip().splitlines()[-1] == "[]", r.stdout

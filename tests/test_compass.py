@@ -2,9 +2,18 @@
 (python/doa_compass_control.py:23-114; plotter contract python/doa_compass_plotter.py:141-199).  CPU only."""
 import math
 
+import importlib.util
+import os
+
 import pytest
 
-from gr_baz_amd.baz import doa_compass_control as dcc
+# loaded from its file: the controller is plain python, and importing the `gr_baz_amd.baz` package here would load the
+# native module (and with it the HIP runtime) while pytest is still collecting
+_spec = importlib.util.spec_from_file_location(
+    "doa_compass_control", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gr_baz_amd", "baz",
+                                        "doa_compass_control.py"))
+dcc = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(dcc)
 
 
 def test_constants_and_surface_match_the_reference():

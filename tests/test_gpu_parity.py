@@ -687,6 +687,49 @@ def test_host_path_with_several_chunks_equals_device_path(gpu_device):
     assert np.array_equal(l_h[:256], l_d) and np.array_equal(a_2, a_h[:777]) and np.array_equal(l_2, l_h[:777])
 
 
+def test_page_locking_of_persistent_caller_buffers(gpu_device, monkeypatch):
+    """baz_music_host_register / baz_music_set_host_pinning: locking a scheduler's long-lived buffers
+    changes how the copies travel, never the results; registrations are idempotent, piecewise, bounded and released."""
+    c = mo.make_config("cfg1", 512, seed=33)
+    items = np.ascontiguousarray(np.tile(c["items"], (16, 1)))         # 8,192 items, 16 MiB in + 12 MiB out (page-locked: 4 chunks)
+    B = items.shape[0]
+    out = (np.zeros((B, c["n"]), np.float32), np.zeros((B, c["n"]), np.float32), np.zeros((B, c["res"]), np.float32))
+    with _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"]) as ctx:
+        a0, l0, s0 = [x.copy() for x in ctx.process(items)]             # pageable everything
+        assert ctx.host_pinned_bytes() == 0
+        assert ctx.host_register(items) == 0
+        got = ctx.host_pinned_bytes()
+        assert got == items.nbytes                                      # the exact range, not rounded out to pages
+        assert ctx.host_register(items) == 0 and ctx.host_register(items[100:200]) == 0 and ctx.host_pinned_bytes() == got
+        ctx.process(items, out=out)                                     # locked input, pageable outputs
+        assert all(np.array_equal(x, y) for x, y in zip(out, (a0, l0, s0)))
+        ctx.set_host_pinning(True)                                      # the call locks what it touches: the spectrum now
+        for o in out:
+            o.fill(0)
+        ctx.process(items[:1000], out=tuple(o[:1000] for o in out))     # piecewise: first 1,000 rows ...
+        part = ctx.host_pinned_bytes()
+        assert part > got
+        ctx.process(items, out=out)                                     # ... then everything
+        full = ctx.host_pinned_bytes()
+        assert full == got + out[2].nbytes and full > part             # input + spectrum: the two DMA targets
+        assert all(np.array_equal(x, y) for x, y in zip(out, (a0, l0, s0)))
+        ctx.process(items, out=out)
+        assert ctx.host_pinned_bytes() == full                          # nothing new to lock
+        ctx.host_unregister_all()
+        assert ctx.host_pinned_bytes() == 0
+        ctx.set_host_pinning(False)
+        a1, l1, s1 = ctx.process(items)
+        assert np.array_equal(a1, a0) and np.array_equal(s1, s0)
+    monkeypatch.setenv("BAZ_MUSIC_PIN_LIMIT_MIB", "1")
+    with _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"]) as ctx:
+        assert ctx.host_register(items) == _capi().E_UNSUPPORTED and ctx.host_pinned_bytes() == 0
+        assert ctx.host_register(items[:64]) == 0 and ctx.host_pinned_bytes() == items[:64].nbytes
+        ctx.set_host_pinning(True)              # over the limit: the input stays pageable AS A WHOLE (its locked head is dropped)
+        ctx.process(items, out=out)
+        assert ctx.host_pinned_bytes() == 0
+        assert all(np.array_equal(x, y) for x, y in zip(out, (a0, l0, s0)))
+
+
 def test_caller_stream_ordering(gpu_device):
     """baz_music_set_stream: work is ordered on the caller's stream (here a torch side stream), so torch
     ops enqueued before/after on that stream see consistent data without extra synchronisation."""
