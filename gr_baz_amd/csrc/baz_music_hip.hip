@@ -110,6 +110,7 @@ struct baz_music_ctx {
     uint64_t pinned_bytes = 0;
     uint64_t pin_limit = 4096ull << 20;                  // BAZ_MUSIC_PIN_LIMIT_MIB
     int auto_pin = 0;                                    // baz_music_set_host_pinning
+    int zero_copy = 1;                                   // small calls on page-locked memory: no copies (BAZ_MUSIC_ZERO_COPY=0: lab)
     StageProf prof[BAZ_MUSIC_NUM_STAGES];
     std::string stage_name[BAZ_MUSIC_NUM_STAGES];
     char hip_err[256] = {0};
@@ -942,6 +943,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     if (const char* v = getenv("BAZ_MUSIC_SCAN_VARIANT")) c->lab_variant = atoi(v);
     if (const char* v = getenv("BAZ_MUSIC_CHUNK_MIB")) c->chunk_bytes = (size_t)std::max(1, std::min(1024, atoi(v))) << 20;
     if (const char* v = getenv("BAZ_MUSIC_PIN_LIMIT_MIB")) c->pin_limit = (uint64_t)std::max(0, atoi(v)) << 20;
+    if (const char* v = getenv("BAZ_MUSIC_ZERO_COPY")) c->zero_copy = atoi(v) != 0;
     DeviceGuard guard(dev);
     int r = BAZ_MUSIC_OK;
     do {
@@ -1206,6 +1208,33 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
         if (r) return r;
         r = reserve_candidates(c, chunk);
         if (r) return r;
+    }
+
+    // Small call on page-locked caller memory: no copies at all.  The kernels address the caller's buffers over PCIe
+    // (hipHostGetDevicePointer): the covariance kernel reads every input byte once, the scan stores every spectrum value
+    // once, ang / lvl land in the slot's page-locked image -- each byte crosses the link once, inside the three launches,
+    // instead of through two or three DMA transfers with their submission and completion latencies.  Larger calls keep
+    // the pipelined copies (there the DMA engines overlap both directions with the kernels).
+    if (single && locked && c->zero_copy) {
+        void *z_in = nullptr, *z_spec = nullptr, *z_al = nullptr;
+        bool ok = hipHostGetDevicePointer(&z_in, (void*)in_ri, 0) == hipSuccess;
+        if (ok && want_spec) ok = hipHostGetDevicePointer(&z_spec, (void*)spectrum, 0) == hipSuccess;
+        if (ok) ok = hipHostGetDevicePointer(&z_al, (void*)c->slot[0].h_al, 0) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();           // not addressable from the device after all: the copy path below
+        } else {
+            float* z_ang = static_cast<float*>(z_al);
+            int zr = begin_statistic(c);
+            if (zr == BAZ_MUSIC_OK)
+                zr = process_device_locked(c, z_in, batch, z_ang, z_ang + (size_t)batch * c->n, want_spec ? z_spec : nullptr);
+            const hipError_t es = hipStreamSynchronize(c->stream);   // also after a failed launch
+            if (zr == BAZ_MUSIC_OK && es != hipSuccess) zr = hip_fail(c, es, "hipStreamSynchronize");
+            if (zr != BAZ_MUSIC_OK) return zr;
+            const size_t cnt = (size_t)batch * c->n;
+            memcpy(ang, c->slot[0].h_al, cnt * 4);
+            if (lvl) memcpy(lvl, c->slot[0].h_al + cnt, cnt * 4);
+            return (int)batch;
+        }
     }
 
     int rc = BAZ_MUSIC_OK;

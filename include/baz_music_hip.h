@@ -169,6 +169,9 @@ BAZ_MUSIC_API int baz_music_device(const baz_music_ctx* ctx);
  *   baz_music_set_host_pinning(ctx, 1)       makes baz_music_process() do that for the input and spectrum ranges of
  *       every call before it copies (a lookup per call once they are known).  Default 0: the caller must guarantee that the
  *       memory outlives the registration -- true for scheduler buffers, not for temporaries.
+ *   (A call below 16 MiB of traffic whose input and spectrum are page-locked -- by this or by their owner -- runs
+ *   without copies: the kernels address the caller's buffers over PCIe, hipHostGetDevicePointer; BAZ_MUSIC_ZERO_COPY=0
+ *   keeps the copies.)
  *   baz_music_host_unregister_all(ctx)       undoes every registration of this context (also done by destroy);
  *       call it before the buffers are unmapped (the host block does in stop()).
  *   baz_music_host_pinned_bytes(ctx)         bytes this context holds locked. */

@@ -1,7 +1,7 @@
 """Lab (GPU box): the MUSIC host block driven the way gnuradio-runtime 3.7 would drive it (gr_shim/gnuradio/flowgraph_model.h:
 persistent doubly mapped stream buffers sized from the block's hints, one work() per executor iteration, saturating
 source, draining sinks), config 2, by output multiple, with and without page-locking of the stream buffers and with
-and without the spectrum port.  Host-fed, PCIe-inclusive: NOT the headline metric.  argv: [items=16384]"""
+and without the spectrum port.  Host-fed, PCIe-inclusive: NOT the headline metric.  argv: [items=16384] [multiples=1,64,256,1024,4096]"""
 import os
 import sys
 import time
@@ -21,7 +21,10 @@ x = synth.synth_stream(torch, dev, ITEMS, M, N, arr, synth.C_LIGHT, 0.5, seed=10
 items = np.ascontiguousarray(torch.view_as_complex(x.reshape(ITEMS, N, 2)).cpu().numpy())
 del x
 
-for multiple in (1, 64, 256, 1024, 4096):
+MULTIPLES = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 64, 256, 1024, 4096]
+PINS = (True,) if os.environ.get("FLOWGRAPH_RATE_PINNED_ONLY") else (False, True)
+print("# BAZ_MUSIC_ZERO_COPY=%s" % os.environ.get("BAZ_MUSIC_ZERO_COPY", "(default: 1)"), flush=True)
+for multiple in MULTIPLES:
     os.environ["BAZ_MUSIC_OUTPUT_MULTIPLE"] = str(multiple)
     os.environ.pop("BAZ_MUSIC_MIN_OUTPUT_BUFFER", None)
     if multiple == 1:
@@ -29,7 +32,7 @@ for multiple in (1, 64, 256, 1024, 4096):
     from gr_baz_amd import baz
     blk = baz.music_doa(M, NE, N, table, RES)
     for n_outputs in (3, 2):
-        for pin in (False, True):
+        for pin in PINS:
             # 4 passes over the source data; the rates are those of passes 2-4 (buffers touched, page locks taken)
             best, _, _, _ = blk.run_flowgraph(items, n_outputs, False, pin, 4)
             if best["last_return"] < 0 or not best["steady_items"]:
