@@ -277,6 +277,21 @@ def extra_cfg5(torch, np, capi, synth, dev, stream, nitems, seconds):
             "chain_bytes_per_step": chain_bytes, "chain_hbm_fraction_of_8TBs": chain_bytes / (ms * 1e-3) / 8e12}
 
 
+def host_fed_extra(timeout_s=90):
+    """scripts/hostfed_extra.py in its own process: host-fed (PCIe-inclusive) rates of the host block under the restated
+    GNU Radio 3.7 scheduling.  Whatever happens there -- no pybind module, a crash, a hang -- stays there."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "hostfed_extra.py")], capture_output=True, text=True,
+                           timeout=timeout_s, cwd=ROOT)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout).strip()[-300:])}
+        return json.loads(lines[-1])
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -465,6 +480,7 @@ def main():
                 except Exception as e:                       # a secondary measurement never takes the headline down
                     extra[name] = {"error": repr(e)}
                 torch.cuda.empty_cache()
+            extra["cfg2_host_fed_gr37_model"] = host_fed_extra()
             line["config"]["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(table)
