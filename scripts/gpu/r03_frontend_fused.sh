@@ -1,0 +1,7 @@
+#!/bin/bash
+# first call of the next round: the config-5 front-end with the resampler inside both AGC passes (scripts/frontend_fused_lab.hip:
+# bit-for-bit check against the three-engine chain, then timings of the chain, the lane-local and the LDS-staged fused forms)
+set -u
+O=gpurun_out/r03a; mkdir -p $O
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scripts/frontend_fused_lab scripts/frontend_fused_lab.hip 2> $O/build_err.txt || { tail $O/build_err.txt; exit 1; }
+timeout 120 scripts/frontend_fused_lab 16384 20 > $O/frontend_fused.txt 2>&1; echo "rc=$?" >> $O/frontend_fused.txt; cat $O/frontend_fused.txt
