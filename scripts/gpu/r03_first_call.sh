@@ -5,3 +5,5 @@ set -u
 O=gpurun_out/r03a; mkdir -p $O
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scripts/frontend_fused_lab scripts/frontend_fused_lab.hip 2> $O/build_err.txt || { tail $O/build_err.txt; exit 1; }
 timeout 120 scripts/frontend_fused_lab 16384 20 > $O/frontend_fused.txt 2>&1; echo "rc=$?" >> $O/frontend_fused.txt; cat $O/frontend_fused.txt
+# and: does the default wiring (no spectrum port) gain from contexts on separate streams?
+timeout 120 python tests/lab/nospec_two_ctx.py 1,2,4 262144 > $O/nospec_two_ctx.txt 2>&1; cat $O/nospec_two_ctx.txt | grep -v amdgpu.ids
