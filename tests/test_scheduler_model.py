@@ -19,7 +19,7 @@ def test_buffer_sizing_follows_allocate_buffer():
     b = _baz()
     # no hints: 2 x 32 KiB per port, rounded UP to page / gcd(item, page) items
     assert b.gr37_buffer_items(8) == 8192                      # gr_complex stream: the familiar 8,192 items
-    assert b.gr37_buffer_items(4) == 16384
+    assert b.gr37_buffer_items(4) == 16384 and b.gr37_buffer_items(2) == 32768 and b.gr37_buffer_items(1) == 65536
     assert b.gr37_buffer_items(24) == 3072                     # 2730 -> granularity 512
     assert b.gr37_buffer_items(14400) == 64                    # 4 items -> granularity 4096 / 64
     # at least two output multiples
