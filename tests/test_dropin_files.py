@@ -41,6 +41,23 @@ def test_grc_descriptor_is_byte_identical_to_the_reference():
     assert _read(os.path.join(ROOT, "grc", "baz_music_doa.xml")) == _read(os.path.join(REF, "grc", "baz_music_doa.xml"))
 
 
+def test_block_tree_entry_places_the_block_where_gr_baz_does():
+    """grc/baz_block_tree.xml of the reference lists baz_music_doa under [gr-baz] / DOA; the stand-alone entry (opt-in at
+    install time, a host with gr-baz already has it) names the same path."""
+    import xml.etree.ElementTree as ET
+    top = ET.parse(os.path.join(ROOT, "grc", "baz_music_block_tree.xml")).getroot()
+    assert top.tag == "cat" and top.findtext("name") == "[gr-baz]"
+    cats = top.findall("cat")
+    assert [(c.findtext("name"), [b.text for b in c.findall("block")]) for c in cats] == [("DOA", ["baz_music_doa"])]
+    cm = open(os.path.join(ROOT, "CMakeLists.txt")).read()
+    assert re.search(r'option\(BAZ_MUSIC_INSTALL_BLOCK_TREE "[^"]*" OFF\)', cm) and "grc/baz_music_block_tree.xml" in cm
+    if os.path.isdir(REF):
+        ref = ET.parse(os.path.join(REF, "grc", "baz_block_tree.xml")).getroot()
+        assert ref.findtext("name") == "[gr-baz]"
+        doa = [c for c in ref.iter("cat") if c.findtext("name") == "DOA"]
+        assert len(doa) == 1 and [b.text for b in doa[0].findall("block")] == ["baz_music_doa"]
+
+
 def _stanza(text, guard):
     """The declarations between `#ifdef <guard>` and its `#endif`, whitespace-normalised, comments dropped."""
     found = [b for b in re.findall(r"#ifdef\s+%s\b(.*?)#endif\s*//\s*%s" % (guard, guard), text, re.S)
