@@ -112,7 +112,7 @@ baz_music_doa::baz_music_doa(unsigned int m, unsigned int n, unsigned int nsampl
     const long cap = env_long("BAZ_MUSIC_MAX_NOUTPUT", 0, 0, 1L << 30);
     set_output_multiple((int)multiple);
     if (min_buffer > 0) set_min_output_buffer(min_buffer);
-    if (cap > 0) set_max_noutput_items((int)std::max(cap, multiple));
+    if (cap > 0) set_max_noutput_items((int)std::max(multiple, cap - cap % multiple));   /* the runtime does not round a cap */
 
     set_pin_buffers(env_long("BAZ_MUSIC_PIN_BUFFERS", 1, 0, 1) != 0);
 

@@ -49,6 +49,9 @@ def test_call_planning_follows_run_one_iteration():
     # the cap, never below one multiple
     assert b.gr37_plan_noutput(10**6, [8191], [8192], 64, 1, 128) == 128
     assert b.gr37_plan_noutput(10**6, [8191], [8192], 64, 1, 10) == 64
+    # ... and NOT rounded to a multiple: the runtime takes min(noutput, max_noutput_items) as it is, so a cap that is no
+    # multiple of the output multiple reaches work() -- the host block therefore rounds its cap down to a multiple
+    assert b.gr37_plan_noutput(10**6, [8191], [8192], 2, 1, 5) == 5
     # history: noutput + history - 1 inputs needed
     assert b.gr37_plan_noutput(100, [8191], [8192], 1, 11) == 90
     # the reference's block (no hints at all): one page of 8-byte items at a time is NOT the limit, the input is
@@ -110,3 +113,35 @@ def test_music_block_under_the_scheduler_model(name, n_outputs, pin, gpu_device,
     else:
         assert st["pinned_bytes_at_stop"] == 0
     assert blk.pinned_bytes() == 0 and blk.pin_buffers() is False             # ... and released by stop()
+
+
+def test_model_invariants_on_random_hints():
+    """Random item sizes, hints and lengths: every item arrives once and in order through the wrapping buffers, every call
+    is a multiple, no call exceeds half an output buffer, the cap (never below one multiple) or what the input buffer
+    can hold, and only a tail below one multiple is dropped."""
+    from hypothesis import given, settings, strategies as st
+
+    b = _baz()
+
+    @settings(max_examples=60, deadline=None)
+    @given(item=st.sampled_from([4, 8, 12, 24, 100, 1000, 8192, 14400]), nout=st.integers(1, 3),
+           multiple=st.sampled_from([1, 2, 3, 7, 16, 64, 100]), min_buffer=st.sampled_from([-1, 10, 512, 3000]),
+           capm=st.sampled_from([0, 1, 2, 9]), n=st.integers(1, 3000), seed=st.integers(0, 2**31 - 1))
+    def check(item, nout, multiple, min_buffer, capm, n, seed):
+        cap = capm * multiple            # (a cap that is no multiple of the output multiple is passed through: see above)
+        data = np.random.default_rng(seed).integers(0, 256, size=item * n, dtype=np.uint8)
+        stt, outs = b.gr37_model_selftest(data, item, nout, multiple, min_buffer, cap)
+        done = stt["items"]
+        assert done == n - n % multiple and stt["dropped_at_end"] == n - done
+        for o in outs:
+            assert np.array_equal(o[:done * item], data[:done * item])
+        limit = min(x // 2 for x in stt["out_bufsize"])
+        if cap > 0:
+            limit = min(limit, max(cap, multiple))
+        limit = min(limit, stt["in_bufsize"] - 1)
+        for size, count in stt["call_sizes"].items():
+            assert size % multiple == 0 and 0 < size <= limit and count > 0
+        assert sum(k * v for k, v in stt["call_sizes"].items()) == done
+        assert all(x >= 2 * multiple for x in stt["out_bufsize"]) and stt["in_bufsize"] >= 2 * (multiple + 1)
+
+    check()
