@@ -145,3 +145,12 @@ def test_model_invariants_on_random_hints():
         assert all(x >= 2 * multiple for x in stt["out_bufsize"]) and stt["in_bufsize"] >= 2 * (multiple + 1)
 
     check()
+
+
+def test_stand_in_module_exposes_the_scheduling_surface():
+    b = _baz()
+    for name in ("gr37_buffer_items", "gr37_plan_noutput", "gr37_model_selftest"):
+        assert callable(getattr(b, name))
+    for name in ("run_flowgraph", "set_pin_buffers", "pin_buffers", "pinned_bytes", "output_multiple", "min_output_buffer",
+                 "max_noutput_items", "work"):
+        assert hasattr(b.baz_music_doa_sptr, name), name
