@@ -74,6 +74,11 @@ def test_create_rejects_null_and_unsupported():
     assert L.baz_music_process(None, None, 0, None, None, None) == capi.E_INVALID
     assert L.baz_music_set_table(None, None) == capi.E_INVALID
     L.baz_music_destroy(None)          # harmless
+    # the page-locking calls without a context
+    assert L.baz_music_host_register(None, None, 0) == capi.E_INVALID
+    assert L.baz_music_set_host_pinning(None, 1) == capi.E_INVALID
+    assert L.baz_music_host_unregister_all(None) == capi.E_INVALID
+    assert L.baz_music_host_pinned_bytes(None) == 0
 
 
 def test_no_gpu_means_loud_failure():
