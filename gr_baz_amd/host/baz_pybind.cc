@@ -90,11 +90,17 @@ py::tuple run_flowgraph(music_doa_handle& h, py::array_t<std::complex<float>, py
     unsigned long long pinned = 0;
     {
         py::gil_scoped_release nogil;
+        const bool before = h.blk->pin_buffers();
         h.blk->set_pin_buffers(pin);
         struct restore {
             baz_music_doa& b;
-            ~restore() { b.set_pin_buffers(false); }   // also releases whatever a failed run left registered
-        } r = {*h.blk};
+            bool to;
+            ~restore()
+            {
+                b.set_pin_buffers(false);          // releases whatever a failed run left registered (the buffers are gone)
+                if (to) b.set_pin_buffers(true);
+            }
+        } r = {*h.blk, before};
         st = gr::shim::run_sync_block(*h.blk, (const char*)bi.ptr, nitems, n_outputs, sinks, &pinned, passes);
     }
     py::dict d = stats_dict(st);
