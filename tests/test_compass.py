@@ -81,3 +81,22 @@ def test_text_rules_of_the_plotter():
 ])
 def test_strongest_direction(ang, lvl, want):
     assert dcc.strongest_direction(ang, lvl) == want
+
+
+def test_compass_follows_the_golden_doa_stream():
+    """The consumer wired behind the block's ports 0 / 1 (as a GRC function probe would): every golden item's strongest
+    estimate becomes the pointer direction."""
+    import numpy as np
+    from conftest import load_golden
+    g = load_golden("cfg1_m4_n2_N256_r360")
+    c = dcc.compass_control(None, text=["searching", "locked"], text_visible=0)
+    assert c[dcc.BEAM_ENB_KEY] is False and c.plotter.polygons() == {} and c.plotter.shown_text == "searching"
+    for ang, lvl in zip(g["ang"], g["lvl"]):
+        d = dcc.strongest_direction(ang, lvl)
+        assert d == float(ang[int(np.argmax(lvl))]) and 0.0 <= d < 360.0      # ports 0 / 1 are in descending strength
+        c.set_direction(d)
+        assert c.plotter.profiles["1beam_azm"][2] == dcc.pointer_profile(d)
+    c.set_text_visible(1)
+    assert c.plotter.shown_text == "locked"
+    c.set_direction(dcc.strongest_direction([0.0, 0.0], [0.0, 0.0]))           # an item without estimates hides the pointer
+    assert c.plotter.polygons() == {}
