@@ -20,6 +20,17 @@ python scripts/pmc_summary.py "$W" "$F" "$S" > $O/bench_pmc_summary.txt 2>&1
 python scripts/pmc_traffic.py "$W" "$F" $O/scan_pmc_traffic.json $HEAD > $O/pmc_traffic_out.txt 2>&1
 cp $O/scan_pmc_traffic.json profiles/r02_scan_pmc_traffic.json      # so that the bench run below reports it
 python bench.py --steps 20 --warmup 3 > $O/bench_line.json 2> $O/bench_err.txt
+# raw counter rows of the product's kernels, kept beside the summaries (tests/test_evidence.py recomputes the traffic from them)
+python - "$W" "$F" "$S" <<'PY'
+import csv, sys
+for src, name in zip(sys.argv[1:4], ("write", "fetch", "sq")):
+    rows = list(csv.DictReader(open(src)))
+    with open("profiles/r02_pmc_raw_%s.csv" % name, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(r for r in rows if "bazmusic" in r["Kernel_Name"])
+PY
+mkdir -p $O/raw && cp profiles/r02_pmc_raw_*.csv $O/raw/
 python tests/lab/refine_rate.py > $O/refine_rate.txt 2>&1
 python scripts/cfg5_pipeline.py 16384 20 > $O/cfg5_pipeline.txt 2>&1
 head -12 $O/bench_kernel_stats.csv; cat $O/pmc_traffic_out.txt | tail -22; python -c "

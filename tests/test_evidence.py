@@ -50,3 +50,27 @@ def test_host_fed_extra_of_the_bench_stays_in_its_own_process():
     entry instead of raising (so it can never take the headline down)."""
     out = _bench().host_fed_extra(timeout_s=120)
     assert isinstance(out, dict) and ("error" in out or "runs" in out)
+
+
+def test_pmc_traffic_follows_from_the_kept_raw_counter_rows():
+    """profiles/r02_pmc_raw_{write,fetch}.csv are the rocprofv3 --pmc rows of the product's kernels (one pass per counter);
+    the traffic bench.py reports is their mean per scan launch, WRITE_SIZE + 2 x FETCH_SIZE in units of 1,024 B
+    (MI355X_MICROARCH.md: gfx950 tallies the 128-B requests of wide reads at 64 B)."""
+    import csv
+
+    def mean(path, counter):
+        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", path)))
+             if r["Counter_Name"] == counter and "scan_mfma_kernel" in r["Kernel_Name"]]
+        assert len(v) >= 3
+        return sum(v) / len(v), len(v)
+
+    t = json.load(open(os.path.join(ROOT, "profiles", "r02_scan_pmc_traffic.json")))
+    w, nw = mean("r02_pmc_raw_write.csv", "WRITE_SIZE")
+    f, nf = mean("r02_pmc_raw_fetch.csv", "FETCH_SIZE")
+    assert (nw, nf) == (t["dispatches_averaged"]["write_pass"], t["dispatches_averaged"]["fetch_pass"])
+    assert w == pytest.approx(t["WRITE_SIZE_KiB"], rel=1e-12) and f == pytest.approx(t["FETCH_SIZE_KiB_raw"], rel=1e-12)
+    assert int(round(w * 1024.0 + 2.0 * f * 1024.0)) == t["scan_hbm_bytes_per_launch"]
+    assert t["writes_over_algorithmic"] == pytest.approx(w * 1024.0 / t["algorithmic_bytes_per_launch"], rel=1e-12)
+    # the launch the counters saw is the bench's launch: 262,144 items = 65,536 workgroups-worth of 16-item tiles x ranges
+    rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_pmc_raw_write.csv"))) if "scan_mfma_kernel" in r["Kernel_Name"]]
+    assert len({(r["Grid_Size"], r["Workgroup_Size"]) for r in rows}) == 1
