@@ -148,3 +148,32 @@ def test_c_oracle_rejects_bad_arguments():
     assert lib.music_ref_work(p, p, 4, 0, 8, 1, p, p, None, None) == -1
     assert lib.music_ref_work(p, p, 4, 2, 6, 1, p, p, None, None) == -1   # nsamples % m != 0
     assert lib.music_ref_work(p, p, 0, 0, 8, 1, p, p, None, None) == -1
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_three_restatements_agree_on_random_shapes(seed, capfd):
+    """Fresh random cases (not the stored vectors): the numpy restatement, the plain-C restatement and -- where it is built
+    -- the reference's own baz_music_doa.cc (oracle/_ref, both eig_sym backends) give the same spectra to 1e-6 and the same
+    DoA bins up to the tie rule, over antennas 2..12, emitters 1..m-1, odd resolutions, -5..40 dB and 0..n actual emitters."""
+    rng = np.random.default_rng(4242 + seed)
+    m = int(rng.integers(2, 13))
+    n = int(rng.integers(1, m))
+    K = int(rng.integers(max(2 * m, 8), 200))
+    res = int(rng.integers(16, 900))
+    snr = float(rng.uniform(-5.0, 40.0))
+    emitters = int(rng.integers(0, n + 1))
+    arr = mo.array_geometry(m)
+    table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
+    items = mo.synth_items(5, m, K * m, arr, mo.FREQUENCY, mo.SPACING, angles_deg=tuple(rng.uniform(0, 360, emitters)),
+                           snr_db=snr, seed=int(rng.integers(1 << 30)))
+    a0, l0, s0, strength = mo.music_doa_work_batch(items, table, m, n)
+    a1, l1, s1 = mr.work_batch(items, table, m, n)
+    assert_spectrum_close(s1, s0, rtol=1e-6)
+    assert_doa_match(a1, l1, a0, l0, res, strength)
+    if mr.have_ref():
+        for lapack in (False, True):
+            mr.ref_use_lapack(lapack)
+            a2, l2, s2 = mr.ref_work_batch(items, table, m, n)
+            capfd.readouterr()
+            assert_spectrum_close(s2, s0, rtol=1e-6)
+            assert_doa_match(a2, l2, a0, l0, res, strength)
