@@ -7,7 +7,9 @@
 
 #include <gnuradio/io_signature.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -24,6 +26,17 @@ baz_agc_cc::baz_agc_cc(float rate, float reference, float gain, float max_gain)
     const int rc = baz_agc_create(&d_ctx, 1, rate, reference, gain, max_gain, -1);
     if (rc != BAZ_AGC_OK)
         throw std::runtime_error(std::string("agc_cc: cannot open the gfx950 engine: ") + baz_agc_strerror(rc));
+    /* Scheduler hints, as for the MUSIC block: a call is two copies and three launches whatever its
+     * size, and GNU Radio's default 64-KiB buffers would hand work() at most 4,096 samples (gr_shim/gnuradio/
+     * flowgraph_model.h) -- less than the launches cost.  Ask for calls of >= 16,384 samples (128 KiB each way; 16 ms of
+     * signal at 1 MS/s) and buffers of 8 such; BAZ_AGC_OUTPUT_MULTIPLE / BAZ_AGC_MIN_OUTPUT_BUFFER override (1 / 0 = the
+     * reference's scheduling). */
+    long multiple = 16384, min_buffer = -1;
+    if (const char* v = getenv("BAZ_AGC_OUTPUT_MULTIPLE")) multiple = std::max(1L, std::min(1L << 24, atol(v)));
+    if (const char* v = getenv("BAZ_AGC_MIN_OUTPUT_BUFFER")) min_buffer = std::max(0L, std::min(1L << 30, atol(v)));
+    if (min_buffer < 0) min_buffer = multiple > 1 ? 8 * multiple : 0;
+    set_output_multiple((int)multiple);
+    if (min_buffer > 0) set_min_output_buffer(min_buffer);
 }
 
 baz_agc_cc::~baz_agc_cc()

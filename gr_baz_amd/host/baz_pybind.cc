@@ -258,6 +258,8 @@ PYBIND11_MODULE(_baz_music, mod)
              py::arg("pin") = false, py::arg("passes") = 1);
     py::class_<agc_handle>(mod, "baz_agc_cc_sptr")
         .def("name", [](agc_handle& h) { return h.blk->name(); })
+        .def("output_multiple", [](agc_handle& h) { return h.blk->output_multiple(); })
+        .def("min_output_buffer", [](agc_handle& h) { return h.blk->min_output_buffer(); })
         .def("input_item_sizes", [](agc_handle& h) { return h.blk->input_signature()->sizeof_stream_items(); })
         .def("output_item_sizes", [](agc_handle& h) { return h.blk->output_signature()->sizeof_stream_items(); })
         .def("output_streams", [](agc_handle& h) {

@@ -154,3 +154,11 @@ def test_stand_in_module_exposes_the_scheduling_surface():
     for name in ("run_flowgraph", "set_pin_buffers", "pin_buffers", "pinned_bytes", "output_multiple", "min_output_buffer",
                  "max_noutput_items", "work"):
         assert hasattr(b.baz_music_doa_sptr, name), name
+    for name in ("output_multiple", "min_output_buffer", "work"):
+        assert hasattr(b.baz_agc_cc_sptr, name), name
+    # what the AGC block's hints buy under the runtime's rules: 4,096-sample calls by default, 16,384 x k with them
+    assert b.gr37_plan_noutput(8191, [8191, 16383], [8192, 16384], 1) == 4096
+    out = [b.gr37_buffer_items(8, 16384, 8 * 16384), b.gr37_buffer_items(4, 16384, 8 * 16384)]
+    assert out == [131072, 131072]
+    upstream = b.gr37_buffer_items(8, 1, -1, -1, [(1.0, 16384, 1)])
+    assert upstream == 32770 + (-32770) % 512 and b.gr37_plan_noutput(upstream - 1, [x - 1 for x in out], out, 16384) == 32768
