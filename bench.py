@@ -10,9 +10,12 @@ timing   : W warm-up steps, then EXACTLY K steps between barrier + synchronize o
            A K-step region is ~25 ms at the driver's K = 20, so the measurement is REPEATED (rounds of exactly K
            steps, each bracketed the same way) until >= --min-seconds of timed work has accumulated; the line
            reports the MEDIAN round (ms_per_step, value) and lists every round under "rounds".
-N GPUs   : one process per GPU (torch.distributed.run), streams dealt s mod N, NO data-path
-           collective; torch.distributed (RCCL) only provides the barrier and the max-over-ranks
-           clock.  scaling = weak (per-GPU work fixed).  "ranks" lists what every rank processed.
+N GPUs   : one process per GPU, streams dealt s mod N, NO data-path collective; torch.distributed (RCCL) only
+           provides the barrier and the max-over-ranks clock.  scaling = weak (per-GPU work fixed).  "ranks" lists
+           what every rank processed (asserted to be N entries).  Started either by the driver's
+           `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` or as plain
+           `python bench.py --gpus N`, which re-runs itself under that launcher (self_launch); a WORLD_SIZE that is
+           not N, or fewer than N visible devices, is an error, never a silently smaller run.
 roofline : dominant kernel = the scan (scan_mfma_kernel); achieved = its algorithmic bytes per launch
            (4*resolution + 8*n per item) / its average launch duration, measured with
            hipEvents recorded on the launch stream inside the timed rounds (baz_music_profile).  "traffic" = HBM
@@ -292,6 +295,26 @@ def host_fed_extra(timeout_s=90):
         return {"error": repr(e)}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: re-run this file as N ranks (one process per GPU) under
+    torch.distributed.run on 127.0.0.1 -- exactly the command line the driver uses -- and hand its exit code back.  Fails
+    loudly when fewer than N devices are visible (unless the BAZ_BENCH_SHARE_DEVICES=1 test hook is set)."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < n and os.environ.get("BAZ_BENCH_SHARE_DEVICES") != "1":
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (one process per GPU)" % (n, ndev))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -303,12 +326,15 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat the K-step timed region until this much timed work")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return self_launch(args.gpus)                        # plain `python bench.py --gpus N`: start the N ranks ourselves
+
     import numpy as np
     import torch
     from gr_baz_amd import capi, sharding, synth
 
     rank, local_rank, world = sharding.dist_env()
-    if world != max(1, args.gpus) and world > 1:
+    if world != max(1, args.gpus):                           # never print a line whose n_gpus is not what was asked for
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MUSIC-DoA path has no CPU fallback")
@@ -401,6 +427,7 @@ def main():
         gathered = [None] * world
         dist.all_gather_object(gathered, ranks[0])
         ranks = gathered
+    assert len(ranks) == world and sorted(r["rank"] for r in ranks) == list(range(world)), ranks
 
     if rank == 0:
         scan_avg_s = scan_ms_total / max(scan_launches, 1) * 1e-3

@@ -1,0 +1,62 @@
+"""bench.py's N > 1 path on the GPU box (row e of SURVEY.md 8): `python bench.py --gpus 2` with NO launcher around it
+must start its own two ranks and print n_gpus = 2.  The box has one GPU, so the two ranks share it
+(BAZ_BENCH_SHARE_DEVICES=1: the only thing the hook changes is local_rank %= ndev and the barrier backend, RCCL cannot
+put two ranks on one device); everything else -- the deal s mod N, one context per rank, barrier + max-over-ranks
+clock, the gathered per-rank records -- is the code an 8-GPU SCALE run executes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv, env=None, timeout=420):
+    e = dict(os.environ, **(env or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True,
+                       timeout=timeout, cwd=ROOT, env=e)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_share_one_gpu(gpu_device):
+    common = ("--steps", "3", "--warmup", "2", "--no-extras", "--no-cpu-baseline", "--min-seconds", "0.2")
+    r1, one = _bench("--gpus", "1", *common)
+    assert r1.returncode == 0 and one is not None, r1.stderr[-2000:]
+    assert one["n_gpus"] == 1 and len(one["config"]["ranks"]) == 1
+    r2, two = _bench("--gpus", "2", *common, env={"BAZ_BENCH_SHARE_DEVICES": "1"})
+    assert r2.returncode == 0 and two is not None, r2.stderr[-2000:]
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak"
+    ranks = two["config"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1]
+    s0, s1 = set(ranks[0]["streams"]), set(ranks[1]["streams"])
+    assert not (s0 & s1) and sorted(s0 | s1) == list(range(16))          # 8 streams per rank, dealt s mod 2
+    assert all(r["items_per_step"] == one["config"]["ranks"][0]["items_per_step"] for r in ranks)   # weak scaling
+    # both ranks time-share ONE device here: the whole-job rate is what that device delivers (within 2x of N = 1)
+    assert 0.5 * one["value"] <= two["value"] <= 1.5 * one["value"], (one["value"], two["value"])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_bench_refuses_more_ranks_than_devices(gpu_device):
+    import torch
+    n = torch.cuda.device_count() + 1
+    r, line = _bench("--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline")
+    assert r.returncode != 0 and line is None
+    assert "visible" in (r.stderr + r.stdout)
+
+
+def test_bench_rejects_a_world_size_that_is_not_gpus():
+    """The line must never carry an n_gpus other than the one asked for (round-2 review: --gpus 8 under WORLD_SIZE=1
+    printed n_gpus 1 with rc 0).  No GPU needed: the check comes before any device work."""
+    e = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], capture_output=True,
+                       text=True, timeout=240, cwd=ROOT, env=e)
+    assert r.returncode != 0 and "does not match --gpus 8" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
