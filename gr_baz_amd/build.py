@@ -48,7 +48,8 @@ def _hipcc():
 
 def build_hip(force=False, verbose=False):
     srcs = [os.path.join(CSRC, "baz_music_hip.hip"), os.path.join(CSRC, "music_kernels.hip.h"),
-            os.path.join(CSRC, "music_wide_kernels.hip.h"), os.path.join(INCLUDE, "baz_music_hip.h")]
+            os.path.join(CSRC, "music_wide_kernels.hip.h"), os.path.join(CSRC, "scan_coarse_kernels.hip.h"),
+            os.path.join(INCLUDE, "baz_music_hip.h")]
     if force or _newer(HIP_LIB, srcs):
         cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", HIP_LIB, srcs[0]]
         if verbose:

@@ -27,6 +27,7 @@ SYMBOLS = [
     "baz_music_profile", "baz_music_stage_ms", "baz_music_stage_name", "baz_music_debug_cov",
     "baz_music_debug_evd", "baz_music_debug_q", "baz_music_q_stride", "baz_music_bytes_per_item", "baz_music_strerror",
     "baz_music_last_hip_error", "baz_music_version", "baz_music_device_count", "baz_music_device", "baz_music_set_peak_mode", "baz_music_refined_items",
+    "baz_music_refined_values", "baz_music_debug_coarse_margin",
     "baz_music_host_register", "baz_music_set_host_pinning", "baz_music_host_unregister_all", "baz_music_host_pinned_bytes",
 ]
 
@@ -102,6 +103,10 @@ def lib():
     L.baz_music_device.argtypes = [_vp]
     L.baz_music_refined_items.restype = ctypes.c_int64
     L.baz_music_refined_items.argtypes = [_vp]
+    L.baz_music_refined_values.restype = ctypes.c_int64
+    L.baz_music_refined_values.argtypes = [_vp]
+    L.baz_music_debug_coarse_margin.restype = ctypes.c_int
+    L.baz_music_debug_coarse_margin.argtypes = [_vp, _vp, _u32, ctypes.POINTER(ctypes.c_float)]
     L.baz_music_set_peak_mode.restype = ctypes.c_int
     L.baz_music_set_peak_mode.argtypes = [_vp, ctypes.c_int]
     L.baz_music_host_register.restype = ctypes.c_int
@@ -202,9 +207,20 @@ class Context:
                                                   _vp(d_spec) if d_spec else None)
         self._chk(r, "baz_music_process_device")
 
-    def refined_items(self):
-        """Items of the last process call that were recomputed in literal form (near-null bins, extreme SNR)."""
-        return int(lib().baz_music_refined_items(self._h))
+    def refined_values(self):
+        """(item, bin) VALUES of the last process call that were recomputed in the reference's literal form (near-null
+        bins, extreme SNR) -- not items: one item can contribute up to `resolution` of them.  0 on the wide path."""
+        return int(lib().baz_music_refined_values(self._h))
+
+    refined_items = refined_values      # the round-1 name of the same statistic (kept for callers; the unit is values)
+
+    def debug_coarse_margin(self, d_in, batch):
+        """Worst observed |coarse - exact| / allowance of the coarse-gated scan over every (item, bin) of the batch
+        (baz_music_debug_coarse_margin; the gate is sound below 1)."""
+        w = ctypes.c_float(0.0)
+        self._chk(lib().baz_music_debug_coarse_margin(self._h, _vp(d_in), int(batch), ctypes.byref(w)),
+                  "baz_music_debug_coarse_margin")
+        return float(w.value)
 
     # ---- page-locking of caller buffers that live across calls (a scheduler's stream buffers) ----
     def host_register(self, array):

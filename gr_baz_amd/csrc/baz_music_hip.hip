@@ -7,6 +7,7 @@
 #include "../../include/baz_music_hip.h"
 #include "music_kernels.hip.h"
 #include "music_wide_kernels.hip.h"
+#include "scan_coarse_kernels.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -99,6 +100,15 @@ struct baz_music_ctx {
     int fused_covevd = 0;          // m = 4, K % 256 == 0: covariance + EVD in one kernel (BAZ_MUSIC_FUSE=0: lab, two kernels)
     uint32_t covevd_blocks = 512u; // grid of cov4_evd_kernel: the workgroups resident at once (2 per CU)
     uint32_t cov4_resident_blocks = 256u;        // grid of cov4_x4_kernel (persistent waves): one workgroup per CU
+    // coarse-gated scan (scan_coarse_kernels.hip.h): m <= 4, spectrum port not wired
+    uint4* dCS = nullptr;          // per 16-bin tile: f16 hi/lo pieces of the scaled table (B32, B16) + the fp64 B operand (X)
+    uint32_t cs_tiles = 0;         // tiles in the image (a multiple of 8)
+    CoarseParams cs = {0.0f, 0.0f, 0.0, 0.0};
+    bool cs_ok = false;            // image built and its scales representable
+    uint32_t last_nsplit = 1;      // bin ranges per item the last scan launch produced candidates for (the merge folds them)
+    int coarse = 1;                // BAZ_MUSIC_COARSE=0: the full fp64 scan also without the spectrum port (A/B, tests)
+    int coarse_rg = 4;             // BAZ_MUSIC_COARSE_RG: row groups (x 16 items) per wave, 2 or 4 (lab)
+    unsigned int* dMargin = nullptr;   // baz_music_debug_coarse_margin: worst observed error / allowance (float bits)
     int peak_mode = 0;      // 0: the reference's n strongest bins; 1 (opt-in extension): n strongest local maxima
     float* dPeakSpec = nullptr;   // internal spectrum when peak mode runs without the spectrum port
     size_t peak_spec_cap = 0;     // floats
@@ -217,6 +227,101 @@ void build_TB(const float* table_ri, uint32_t m, uint32_t res, uint32_t steps, s
 }
 
 uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+
+// float -> IEEE binary16, round to nearest even (values here are finite and below 65504)
+uint16_t f16_bits(float f)
+{
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const int32_t ex = (int32_t)((x >> 23) & 0xFF) - 127 + 15;
+    uint32_t man = x & 0x7FFFFFu;
+    if (((x >> 23) & 0xFF) == 0xFF) return (uint16_t)(sign | 0x7C00u | (man ? 0x200u : 0u));
+    if (ex >= 31) return (uint16_t)(sign | 0x7C00u);
+    if (ex <= 0) {                      // subnormal or zero
+        if (ex < -10) return (uint16_t)sign;
+        man |= 0x800000u;
+        const int shift = 14 - ex;      // 24-bit significand -> 10-bit field of a subnormal
+        uint32_t h = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) ++h;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((uint32_t)ex << 10) | (man >> 13);
+    const uint32_t rem = man & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;   // may carry into the exponent: still right
+    return (uint16_t)(sign | h);
+}
+float f16_value(uint16_t h)
+{
+    const int ex = (h >> 10) & 0x1F;
+    const float man = (float)(h & 0x3FF);
+    float v = ex ? std::ldexp(1.0f + man / 1024.0f, ex - 15) : std::ldexp(man, -24);
+    return (h & 0x8000u) ? -v : v;
+}
+
+// Table images of the coarse-gated scan (scan_coarse_kernel): the C array (1,536 B per 16-bin tile: B32, B16) followed by
+// the X array (2,048 B per tile):
+//   B32  lane (g, c), j < 8 : k = 8 g + j -> Fh[bin = 16 tile + c][e = k & 15]      (K = 32 B operand [Fh | Fh])
+//   B16  lane (g, c), j < 4 : Fl[bin][e = 4 g + j]                                  (K = 16 B operand)
+//   X    k-step pair p, lane (g, c), component s & 1: F[bin][e = 4 s + g], s = 2 p + (s & 1)   (fp64 B operand)
+// Fs = F * FS, Fh = f16(Fs), Fl = f16(Fs - Fh); bins outside the table: a huge diagonal (never selected), like build_FB.
+// Returns false when the table's scale cannot be represented (the full scan is used then).
+bool build_coarse_image(const std::vector<double>& F, uint32_t m, uint32_t res, uint32_t tiles, std::vector<uint8_t>& img,
+                        CoarseParams& cp)
+{
+    const uint32_t mm = m * m;
+    double fmax = 0.0;
+    for (double v : F) {
+        if (!std::isfinite(v)) return false;
+        fmax = std::max(fmax, std::fabs(v));
+    }
+    if (!(fmax > 0.0)) return false;
+    int ex = 0;
+    (void)std::frexp(fmax, &ex);                    // fmax = f * 2^ex, f in [0.5, 1)
+    const int fs_exp = 14 - ex;                     // fmax * 2^fs_exp in [2^13, 2^14)
+    if (fs_exp < -90 || fs_exp > 90) return false;  // SC must stay a comfortable float
+    const double FS = std::ldexp(1.0, fs_exp), SC = 1024.0 * FS;
+    cp.sc = SC;
+    cp.fmax = fmax;
+    cp.sc_up = std::nextafter((float)(SC * (1.0 + 0x1p-16) * (1.0 + 0x1p-20)), INFINITY);
+    cp.es_factor = std::nextafter((float)(0x1p-16 * fmax * SC), INFINITY);
+    const size_t cbytes = (size_t)CS_C_UNITS * 16, xbytes = (size_t)CS_X_UNITS * 16;
+    img.assign((size_t)tiles * (cbytes + xbytes), 0);        // [C of every tile][X of every tile]
+    for (uint32_t t = 0; t < tiles; ++t) {
+        uint8_t* T = img.data() + (size_t)t * cbytes;
+        uint16_t* b32 = reinterpret_cast<uint16_t*>(T);
+        uint16_t* b16 = reinterpret_cast<uint16_t*>(T + 1024);
+        double* X = reinterpret_cast<double*>(img.data() + (size_t)tiles * cbytes + (size_t)t * xbytes);
+        for (uint32_t lane = 0; lane < 64; ++lane) {
+            const uint32_t g = lane >> 4, c = lane & 15, bin = 16 * t + c;
+            auto fval = [&](uint32_t e) -> double {
+                if (e >= mm) return 0.0;
+                if (bin < res) return F[(size_t)bin * mm + e];
+                return ((e / m) == (e % m)) ? 1e300 : 0.0;
+            };
+            auto pieces = [&](uint32_t e, uint16_t& hi, uint16_t& lo) {
+                if (e >= mm) { hi = lo = 0; return; }
+                if (bin >= res) { hi = ((e / m) == (e % m)) ? f16_bits(32768.0f) : 0; lo = 0; return; }
+                const float fs = (float)(F[(size_t)bin * mm + e] * FS);
+                hi = f16_bits(fs);
+                lo = f16_bits(fs - f16_value(hi));
+            };
+            for (uint32_t j = 0; j < 8; ++j) {
+                uint16_t hi, lo;
+                pieces((8 * g + j) & 15u, hi, lo);
+                b32[lane * 8 + j] = hi;
+            }
+            for (uint32_t j = 0; j < 4; ++j) {
+                uint16_t hi, lo;
+                pieces(4 * g + j, hi, lo);
+                b16[lane * 4 + j] = lo;
+            }
+            for (uint32_t s = 0; s < 4; ++s) X[(s >> 1) * 128 + lane * 2 + (s & 1)] = fval(4 * s + g);
+        }
+    }
+    return true;
+}
 
 // the scan's short form (scan_mfma_kernel, SIG) needs fewer MFMAs than the projector GEMM
 bool short_form_applies(uint32_t m, uint32_t n) { return (n == 2 && m >= 9 && m <= 16) || (n == 1 && m >= 6 && m <= 16); }
@@ -424,11 +529,58 @@ int ensure_candidates(baz_music_ctx* c, size_t entries)
     return BAZ_MUSIC_OK;
 }
 
+// The coarse-gated scan applies: spectrum port not wired, m <= 4, n <= 4, the table's scale representable.
+bool coarse_applies(const baz_music_ctx* c)
+{
+    return c->coarse && c->cs_ok && c->dCS && c->m <= 4 && c->n <= 4 && !c->lab_variant;
+}
+
+// its launch geometry: a workgroup = 4 waves x RG x 16 items; ranges of table phases so that small batches still fill the chip
+constexpr uint32_t COARSE_WANT_BLOCKS = 1024;
+struct CoarseGeom {
+    uint32_t groups, nsplit, nphases, tpp;
+};
+CoarseGeom coarse_geometry(const baz_music_ctx* c, uint32_t batch)
+{
+    CoarseGeom G;
+    // four row groups per wave where the lists fit the register file beside them (n <= 2), else two
+    const uint32_t rg = (c->coarse_rg == 2 || c->n > 2) ? 2u : 4u;
+    G.tpp = (rg == 2) ? 4u : 8u;
+    G.nphases = c->cs_tiles / G.tpp;
+    G.groups = (batch + 64 * rg - 1) / (64 * rg);
+    const uint32_t ns = (COARSE_WANT_BLOCKS + G.groups - 1) / G.groups;
+    G.nsplit = std::max(1u, std::min(ns, std::min(G.nphases, 16u)));
+    if (c->force_nsplit > 0) G.nsplit = std::max(1u, std::min((uint32_t)c->force_nsplit, std::min(G.nphases, 16u)));
+    return G;
+}
+
 template <int M, int NMAX>
 int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t batch, float* d_ang,
                   float* d_lvl, float* d_spec)
 {
+    if constexpr (M <= 4 && NMAX <= 4) {
+        if (!d_spec && coarse_applies(c) && dQ == c->dQ) {
+            const CoarseGeom CG = coarse_geometry(c, batch);
+            if ((size_t)batch * CG.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;
+            ScanRefine rf;
+            rf.Gs = c->refine_off ? nullptr : c->dG;
+            rf.TB = c->dTB + c->tb_step_elems;
+            rf.below = c->refine_below;
+            rf.count = c->dRefined + c->stat_parity;
+            rf.A2 = nullptr;
+            if (CG.tpp == 4)
+                hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 2, 4>), dim3(CG.groups * CG.nsplit), dim3(256), 0, c->stream, dQ, c->dCS,
+                                   c->dCS + (size_t)c->cs_tiles * CS_C_UNITS, c->dCand, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, nullptr);
+            else
+                hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8>), dim3(CG.groups * CG.nsplit), dim3(256), 0, c->stream, dQ, c->dCS,
+                                   c->dCS + (size_t)c->cs_tiles * CS_C_UNITS, c->dCand, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, nullptr);
+            HIP_TRY(c, hipGetLastError());
+            c->last_nsplit = CG.nsplit;
+            return BAZ_MUSIC_OK;
+        }
+    }
     const ScanGeom G = scan_geometry(batch, c->fb_steps, c->nclass, c->force_nsplit);
+    c->last_nsplit = G.nsplit;
     double* cand = c->dCand;
     if ((size_t)batch * G.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;   // reserve_candidates() sized it
     const bool spec = d_spec != nullptr;
@@ -493,9 +645,8 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
 template <int NMAX>
 int launch_merge_t(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl, float* d_spec)
 {
-    const ScanGeom G = scan_geometry(batch, c->fb_steps, c->nclass, c->force_nsplit);
     hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream, c->dCand,
-                       d_spec, d_ang, d_lvl, batch, c->res, c->n, G.nsplit, c->keep_mask, c->dRefined + (c->stat_parity ^ 1));
+                       d_spec, d_ang, d_lvl, batch, c->res, c->n, c->last_nsplit, c->keep_mask, c->dRefined + (c->stat_parity ^ 1));
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
 }
@@ -518,7 +669,9 @@ uint32_t topn_list_len(uint32_t n) { return n <= 2 ? 2u : (n <= 4 ? 4u : (n <= 8
 // candidate keys one scan launch over `nb` items produces (mirrors launch_scan_t's geometry)
 size_t cand_entries(const baz_music_ctx* c, uint32_t nb)
 {
-    return (size_t)nb * scan_geometry(nb, c->fb_steps, c->nclass, c->force_nsplit).nsplit * topn_list_len(c->n);
+    size_t per_item = scan_geometry(nb, c->fb_steps, c->nclass, c->force_nsplit).nsplit;
+    if (c->m <= 4 && c->dCS) per_item = std::max<size_t>(per_item, coarse_geometry(c, nb).nsplit);
+    return (size_t)nb * per_item * topn_list_len(c->n);
 }
 
 // nb * nsplit(nb) is not monotonic in nb (nsplit = ceil(want_tasks / groups) while that is <= 64 and <= nsteps), so
@@ -531,7 +684,9 @@ size_t cand_entries_upto(const baz_music_ctx* c, uint32_t batch)
     const size_t cap_split = std::min<size_t>(64u, std::max<uint32_t>(1u, c->fb_steps));
     const size_t worst = std::min<size_t>((size_t)batch * cap_split, 16u * want_tasks + (size_t)batch);
     const size_t forced = c->force_nsplit > 0 ? (size_t)batch * std::min<size_t>((size_t)c->force_nsplit, cap_split) : 0;
-    return std::max(std::max(worst, forced), (size_t)batch) * topn_list_len(c->n);
+    // the coarse-gated scan: nsplit = ceil(COARSE_WANT_BLOCKS / ceil(nb / 128)) <= 16  ->  nb * nsplit <= 128 * WANT + nb
+    const size_t coarse = (c->m <= 4) ? std::min<size_t>((size_t)batch * 16u, 128u * COARSE_WANT_BLOCKS + (size_t)batch) : 0;
+    return std::max(std::max(std::max(worst, forced), coarse), (size_t)batch) * topn_list_len(c->n);
 }
 
 int reserve_candidates(baz_music_ctx* c, uint32_t batch)
@@ -731,6 +886,14 @@ int upload_table(baz_music_ctx* c, const float* table_ri)
         if (a2 > amax2 && a2 < 1e300) amax2 = a2;
     }
     c->refine_below = amax2 * (double)c->m * 1e-8;
+    c->cs_ok = false;
+    if (c->dCS) {    // coarse-gated scan: f16 pieces of the scaled table + the fp64 operand, per 16-bin tile
+        std::vector<uint8_t> img;
+        if (build_coarse_image(F, c->m, c->res, c->cs_tiles, img, c->cs)) {
+            HIP_TRY(c, hipMemcpy(c->dCS, img.data(), img.size(), hipMemcpyHostToDevice));
+            c->cs_ok = true;
+        }
+    }
     if (c->dA2p) {   // ||a||^2 per bin for the scan's short form; huge outside the table, like FB's diagonal there
         std::vector<double> a2((size_t)(c->fb_steps + 2) * 64, 1e300);
         for (uint32_t b = 0; b < c->res; ++b) {
@@ -797,6 +960,60 @@ bool is_pinned_host(const void* p)
     return a.type == hipMemoryTypeHost;
 }
 
+// Is the WHOLE range [p, p + bytes) page-locked and addressable from the device as one piece?  Both ends must be
+// page-locked host memory and their device addresses must be `bytes - 1` apart (one mapping, or mappings that continue
+// each other): a range of which only the head lies inside a registration -- two blocks fanned out from one upstream
+// buffer, one of them owning the registration -- would otherwise hand the zero-copy kernels a device pointer that runs
+// into unmapped host memory (a GPU fault, not an error code).  Such a range takes the pageable path.
+bool range_is_pinned(const void* p, size_t bytes)
+{
+    if (!p || !bytes) return false;
+    const char* last = static_cast<const char*>(p) + bytes - 1;
+    if (!is_pinned_host(p) || !is_pinned_host(last)) return false;
+    void *d0 = nullptr, *d1 = nullptr;
+    if (hipHostGetDevicePointer(&d0, const_cast<void*>(p), 0) != hipSuccess ||
+        hipHostGetDevicePointer(&d1, const_cast<char*>(last), 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return static_cast<char*>(d1) - static_cast<char*>(d0) == (ptrdiff_t)(bytes - 1);
+}
+
+// hipMemcpyAsync between a device buffer and a caller range that may be only PARTLY inside someone's page-lock
+// registration (measured: the runtime answers such a copy with "invalid argument", also when the range straddles two
+// registrations).  The whole range is tried first -- the only call the ordinary cases ever make --; a refused range
+// is halved at a page boundary of the host address until the pieces are homogeneous, and a piece of at most one page
+// that is still refused (a registration boundary inside it: registrations are byte-exact) crosses through a bounce
+// buffer with a synchronize.  Only the refused (rare) case costs anything.
+hipError_t copy_host_range(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t stream)
+{
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, stream);
+    if (e != hipErrorInvalidValue || bytes == 0) return e;
+    (void)hipGetLastError();
+    const bool h2d = kind == hipMemcpyHostToDevice;
+    const uintptr_t host = (uintptr_t)(h2d ? src : dst);
+    if (bytes > 4096) {
+        uintptr_t mid = (host + bytes / 2) & ~(uintptr_t)4095;
+        if (mid <= host || mid >= host + bytes) mid = host + bytes / 2;
+        const size_t first = mid - host;
+        e = copy_host_range(dst, src, first, kind, stream);
+        if (e != hipSuccess) return e;
+        return copy_host_range((char*)dst + first, (const char*)src + first, bytes - first, kind, stream);
+    }
+    char bounce[4096];
+    if (h2d) {
+        memcpy(bounce, src, bytes);
+        e = hipMemcpyAsync(dst, bounce, bytes, kind, stream);
+        if (e != hipSuccess) return e;
+        return hipStreamSynchronize(stream);      // the bounce buffer dies with this frame
+    }
+    e = hipMemcpyAsync(bounce, src, bytes, kind, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) memcpy(dst, bounce, bytes);
+    return e;
+}
+
 // Page-lock [p, p + bytes) for this context: see include/baz_music_hip.h.  Caller holds c->mtx.
 // The runtime rejects a copy whose host range is only PARTLY inside a registration (hipMemcpyAsync: invalid argument --
 // measured, also when the range straddles two registrations).  So (i) registrations are the caller's exact byte
@@ -819,7 +1036,7 @@ int host_register_locked(baz_music_ctx* c, const void* p, size_t bytes)
             touch.push_back(i);
             held += c->pins[i].hi - c->pins[i].lo;
         }
-    if (touch.empty() && is_pinned_host(p) && is_pinned_host((const char*)p + bytes - 1))
+    if (touch.empty() && range_is_pinned(p, bytes))
         return BAZ_MUSIC_OK;                   // its owner's page-locked memory (hipHostMalloc, torch): not ours to manage
     for (size_t i : touch) {
         lo = std::min(lo, c->pins[i].lo);
@@ -1009,6 +1226,13 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (hipMalloc((void**)&c->dFB, (size_t)(c->fb_steps + 2) * c->fb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         if (hipMalloc((void**)&c->dTB, (size_t)(c->fb_steps + 2) * c->tb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         if (const char* v = getenv("BAZ_MUSIC_SIG_SCAN")) c->sig_scan = atoi(v);                  // lab / tests
+        if (const char* v = getenv("BAZ_MUSIC_COARSE")) c->coarse = atoi(v);                      // A/B, tests
+        if (const char* v = getenv("BAZ_MUSIC_COARSE_RG")) c->coarse_rg = atoi(v);                // lab
+        if (m <= 4) {
+            c->cs_tiles = round_up((resolution + 15) / 16, 8);
+            if (hipMalloc((void**)&c->dCS, (size_t)c->cs_tiles * (CS_C_UNITS + CS_X_UNITS) * 16) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+            if (hipMalloc((void**)&c->dMargin, sizeof(unsigned int)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+        }
         if (short_form_applies(m, n) && hipMalloc((void**)&c->dA2p, (size_t)(c->fb_steps + 2) * 64 * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         {
             // ONE workgroup per CU (4 persistent waves, 8 KiB in flight each = 8 MB chip-wide): measured against 2 / 3 / 4 /
@@ -1066,6 +1290,8 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->dSs) (void)hipFree(c->dSs);
         if (c->dA2p) (void)hipFree(c->dA2p);
         if (c->dTB) (void)hipFree(c->dTB);
+        if (c->dCS) (void)hipFree(c->dCS);
+        if (c->dMargin) (void)hipFree(c->dMargin);
         if (c->dRefined) (void)hipFree(c->dRefined);
         if (c->dPeakSpec) (void)hipFree(c->dPeakSpec);
         if (c->dTA) (void)hipFree(c->dTA);
@@ -1186,13 +1412,17 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
     //   pageable caller memory      one chunk up to 64 MiB, 64-MiB chunks beyond (profiles/r01h_hostfed_chunk_sweep.txt);
     //   BAZ_MUSIC_CHUNK_MIB         forces the chunk size (tests, lab).
     const size_t per_item = (size_t)c->nsamples * 8 + (size_t)c->res * 4 + (size_t)c->n * 8;
-    const bool locked = is_pinned_host(in_ri) && (!spectrum || is_pinned_host(spectrum));
+    // "locked" is a statement about the WHOLE of both ranges (the first byte alone is not enough)
+    const bool locked = range_is_pinned(in_ri, (size_t)batch * c->nsamples * 8) &&
+                        (!spectrum || range_is_pinned(spectrum, (size_t)batch * c->res * 4));
     uint32_t chunk;
     if (c->chunk_bytes) {
         chunk = (uint32_t)std::min<size_t>(batch, std::max<size_t>(64, c->chunk_bytes / per_item));
     } else if (!locked) {
         chunk = (uint32_t)std::min<size_t>(batch, std::max<size_t>(64, (64u << 20) / per_item));
-    } else if ((size_t)batch * per_item < (16u << 20)) {
+    } else if ((size_t)batch * per_item < (spectrum ? (16u << 20) : (64u << 20))) {
+        // (without the spectrum port there is nothing to overlap on the way out: 2,048-item calls, 16.8 MB in and 16 KB
+        // out, ran at 4.2e6 items/s as one chunk and at 2.9e6 cut in four -- profiles/r02_flowgraph_model_rates.txt (B))
         chunk = batch;
     } else {
         const size_t floor_items = std::max<size_t>(64, (8u << 20) / per_item);
@@ -1266,8 +1496,8 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
         }
         float* d_ang = sl.al;
         float* d_lvl = sl.al + (size_t)nb * c->n;
-        HIP_STEP(hipMemcpyAsync(sl.in, in_ri + (size_t)done * c->nsamples * 2, (size_t)nb * c->nsamples * 8,
-                                hipMemcpyHostToDevice, s_in));
+        HIP_STEP(copy_host_range(sl.in, in_ri + (size_t)done * c->nsamples * 2, (size_t)nb * c->nsamples * 8,
+                                 hipMemcpyHostToDevice, s_in));
         if (!single) {
             HIP_STEP(hipEventRecord(sl.h2d, s_in));
             HIP_STEP(hipStreamWaitEvent(c->stream, sl.h2d, 0));
@@ -1279,8 +1509,8 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
         }
         HIP_STEP(hipMemcpyAsync(sl.h_al, sl.al, (size_t)nb * c->n * 8, hipMemcpyDeviceToHost, s_out));
         if (want_spec)
-            HIP_STEP(hipMemcpyAsync(spectrum + (size_t)done * c->res, sl.spec, (size_t)nb * c->res * 4,
-                                    hipMemcpyDeviceToHost, s_out));
+            HIP_STEP(copy_host_range(spectrum + (size_t)done * c->res, sl.spec, (size_t)nb * c->res * 4,
+                                     hipMemcpyDeviceToHost, s_out));
         if (!single) HIP_STEP(hipEventRecord(sl.d2h, s_out));
         sl.busy = (rc == BAZ_MUSIC_OK);
         if (sl.busy) {
@@ -1398,6 +1628,47 @@ int baz_music_debug_q(baz_music_ctx* c, const void* d_in, uint32_t batch, void* 
     return launch_evd(c, c->dR, batch, static_cast<double*>(d_Q), qstride, c->dG);
 }
 
+// Validation of the coarse-gated scan's error bound on this hardware (scan_coarse_kernels.hip.h, VAL): covariance + EVD of
+// the batch, then EVERY (item, bin) in both forms; *worst = max |coarse / SC - exact| / (2^-16 (S + |exact|)).  The gate is
+// sound while this stays below 1; the bound was derived with a factor > 2 to spare.
+int baz_music_debug_coarse_margin(baz_music_ctx* c, const void* d_in, uint32_t batch, float* worst)
+{
+    if (!c || !d_in || !worst || batch == 0) return BAZ_MUSIC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    DeviceGuard guard(c->device);
+    if (c->wide || c->m > 4 || c->n > 4 || !c->cs_ok) return BAZ_MUSIC_E_UNSUPPORTED;
+    int r = ensure_workspace(c, batch);
+    if (r) return r;
+    r = reserve_candidates(c, batch);
+    if (r) return r;
+    const uint32_t qstride = baz_music_q_stride(batch);
+    if (c->fused_covevd) r = launch_covevd(c, static_cast<const float*>(d_in), batch, c->dQ, qstride, c->dG);
+    else {
+        r = launch_cov(c, static_cast<const float*>(d_in), batch, c->dR);
+        if (!r) r = launch_evd(c, c->dR, batch, c->dQ, qstride, c->dG);
+    }
+    if (r) return r;
+    HIP_TRY(c, hipMemsetAsync(c->dMargin, 0, sizeof(unsigned int), c->stream));
+    ScanRefine rf;
+    rf.Gs = nullptr; rf.TB = c->dTB + c->tb_step_elems; rf.below = 0.0; rf.count = nullptr; rf.A2 = nullptr;
+    const uint32_t groups = (batch + 255) / 256, nph = c->cs_tiles / 8;
+#define BAZ_VAL(MV, NV)                                                                                                     \
+    hipLaunchKernelGGL((scan_coarse_kernel<MV, NV, 4, 8, true>), dim3(groups), dim3(256), 0, c->stream, c->dQ, c->dCS, \
+                       c->dCS + (size_t)c->cs_tiles * CS_C_UNITS, c->dCand,                                                       \
+                       batch, c->res, qstride, nph, 1u, c->keep_mask, c->n, rf, c->cs, c->dMargin)
+    const bool n2 = c->n <= 2;
+    if (c->m == 2) { BAZ_VAL(2, 2); }
+    else if (c->m == 3) { if (n2) BAZ_VAL(3, 2); else BAZ_VAL(3, 4); }
+    else { if (n2) BAZ_VAL(4, 2); else BAZ_VAL(4, 4); }
+#undef BAZ_VAL
+    HIP_TRY(c, hipGetLastError());
+    unsigned int bits = 0;
+    HIP_TRY(c, hipMemcpyAsync(&bits, c->dMargin, sizeof(bits), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::memcpy(worst, &bits, sizeof(float));
+    return BAZ_MUSIC_OK;
+}
+
 int baz_music_debug_evd(baz_music_ctx* c, const void* d_R, uint32_t batch, void* d_Q)
 {
     if (!c || !d_R || !d_Q || batch == 0) return BAZ_MUSIC_E_INVALID;
@@ -1455,7 +1726,9 @@ int baz_music_set_peak_mode(baz_music_ctx* c, int mode)
     return BAZ_MUSIC_OK;
 }
 
-int64_t baz_music_refined_items(baz_music_ctx* c)
+int64_t baz_music_refined_items(baz_music_ctx* c) { return baz_music_refined_values(c); }
+
+int64_t baz_music_refined_values(baz_music_ctx* c)
 {
     if (!c) return -1;
     std::lock_guard<std::mutex> lk(c->mtx);

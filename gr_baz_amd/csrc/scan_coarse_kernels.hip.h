@@ -1,0 +1,408 @@
+// scan_coarse_kernels.hip.h -- the pseudo-spectrum scan when ONLY the n strongest bins are wanted
+// (lib/baz_music_doa.cc:97-99,120-121: the spectrum port is not wired -- music_doa_helper's default
+// output_spectrum=False, python/music_doa_helper.py:49,61-64), m <= 4.  gfx950 only.
+//
+// The reference evaluates 1/||G^H a||^2 for every bin (.cc:103-121) and keeps the n largest (.cc:129-141).  Without the
+// spectrum port the only observable is that top-n list, i.e. the n SMALLEST d(bin) = a^H Q a.  scan_mfma_kernel
+// computes all res values of d on the fp64 matrix core (57,600 FMAs per cfg2 item) to throw all but n away; at 0.50 ms
+// per 262,144 items it is bound by fp64 matrix issue (77 % of 78.6 TF), and the step (0.88 ms) sits at 30 % of the
+// HBM-read roofline (review r2, weak 4).  Here every 16-item x 16-bin tile is first evaluated by a COARSE form on the
+// f16 matrix core (16x the fp64 rate) whose error against the fp64 value is bounded rigorously, and only tiles that
+// can still hold a top-n member run the exact fp64 form -- the same instructions on the same operands as
+// scan_mfma_kernel, so the keys that reach the lists, hence ang / lvl, are BIT-IDENTICAL to the full scan
+// (tests/test_gpu_parity.py::test_coarse_gated_scan_equals_the_full_scan).
+//
+// Coarse form.  d = sum_e q_e F_e over the MM = m^2 <= 16 real terms of the Hermitian form (music_kernels.hip.h 4.).
+// Both operands are split into two f16 pieces of scaled values,
+//     qs = q 2^10 = qh + ql + rq,      Fs = F FS = Fh + Fl + rF,     FS = the power of two with max|Fs| in [2^13, 2^14)
+// and  c = sum_e (qh + ql) Fh + qh Fl  is ONE K = 32 and ONE K = 16 f16 MFMA with f32 accumulation
+// (A = [qh | ql], B = [Fh | Fh];  A = qh, B = Fl).  f16 x f16 products are exact in f32.  Error budget, in units of
+// d (divide by SC = 2^10 FS), with S = max|F| sum_e |q_e|:
+//     representation   |rq| <= 2^-22 |qs| + 2^-14 (the second term covers a flushed subnormal ql),  same for rF,
+//                      dropped ql Fl <= 2^-22 |qs Fs|                                     ->  <= 1.75 2^-20 S
+//     accumulation     <= 50 additions, each <= 2^-23 (truncation) of a partial sum <= S + thr   ->  <= 2^-17.3 (S + thr)
+// so |c / SC - d| <= E := 2^-16 (S + D) with a factor > 2 to spare (D = the threshold d is compared with).  The bound
+// is checked on hardware over every (item, bin) of random batches by the VAL instantiation
+// (baz_music_debug_coarse_margin: worst observed |c/SC - d| / E).
+//
+// Gate.  A lane's list of item i holds n keys; its last entry K_n bounds the item's final n-th smallest key from
+// above, and so does any other lane's.  A bin can enter the final list only if |d| <= D := (K_n | low bits), so only
+// if  c <= thr := (D + E) SC.  thr enters the coarse MFMA as C = -thr (f32, rounded up): the instruction itself
+// delivers c - thr, three v_min and one compare per 64 values decide the tile.  After an exact tile the new
+// thresholds are shared over the 16 lanes of an item row (4 DPP row rotations on f32).  D never drops below
+// `refine_below`, so near-null values (literal-form refinement, music_kernels.hip.h) are always candidates.
+// NaN q (non-finite covariance): c - thr is NaN, no tile fires, the lists stay empty = (0, 0) pairs like the full scan.
+//
+// Layouts.  f16 MFMA C/D: col = lane & 15, row = 4 (lane >> 4) + reg;  f64 MFMA: row = (lane >> 4) + 4 reg.  The
+// coarse A operand therefore carries item pi(i) = (i >> 2) + 4 (i & 3) in row i: register r of lane (g, c) is item
+// g + 4 r and bin 16 tile + c in BOTH forms.  A wave owns RG row groups of 16 items and walks the bin tiles of its
+// range; the 4 waves of a workgroup share the table images through a double-buffered LDS stage of TPP tiles.
+// Table images, per tile: C (1,536 B) = [B32: 64 lanes x 8 f16][B16: 64 lanes x 4 f16];  X (2,048 B) = k-steps (0,1) as
+// 64 x double2, then (2,3).  Two arrays, because the first pass stages C only.
+#pragma once
+
+#include "music_kernels.hip.h"
+
+namespace bazmusic {
+
+typedef _Float16 v4f16 __attribute__((ext_vector_type(4)));
+typedef _Float16 v8f16 __attribute__((ext_vector_type(8)));
+
+constexpr int CS_C_UNITS = 96;            // 16-B units of a tile's coarse operands: 1024 B (B32) + 512 B (B16)
+constexpr int CS_X_UNITS = 128;           // ... of its fp64 operand: 2048 B
+
+struct CoarseParams {
+    float sc_up;        // SC (1 + 2^-16) rounded up: threshold scale, d units -> coarse units
+    float es_factor;    // 2^-16 max|F| SC, rounded up: es = es_factor * sum_e |q_e|
+    double sc;          // SC = 2^10 FS (VAL only)
+    double fmax;        // max|F| (VAL only)
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+
+// min over the 16 lanes of a DPP row (= the lanes that hold the same four items), result in every lane
+__device__ __forceinline__ float row_allmin(float v)
+{
+    v = fminf(v, dpp_f32<0x128>(v));   // row_ror:8
+    v = fminf(v, dpp_f32<0x124>(v));   // row_ror:4
+    v = fminf(v, dpp_f32<0x122>(v));   // row_ror:2
+    v = fminf(v, dpp_f32<0x121>(v));   // row_ror:1
+    return v;
+}
+
+// The reference's literal form ||G^H a||^2 (.cc:110-119) for ONE 16-item x 16-bin tile: literal_tile()'s instruction
+// sequence per value (k outer, Re / Im, k-steps inner, d += p p), B gathered from the TB image in its 64-bin-step
+// order.  Rare path (near-null tiles, SNR >~ 55 dB): not inlined, so the ordinary tiles do not pay its registers.
+template <int M>
+__device__ __noinline__ v4f64 literal16(const double* __restrict__ Gs, const double2* __restrict__ TB, const uint32_t itc,
+                                        const int g, const uint32_t qstride, const int nn, const uint32_t bin)
+{
+    constexpr int KS2 = (2 * M + 3) / 4;
+    const uint32_t st = bin >> 6, w = bin & 63u, c4 = w >> 2, t = w & 3u;
+    const double* __restrict__ tb = reinterpret_cast<const double*>(TB + ((size_t)st * KS2 * 2 + (t >> 1)) * 64 + (g * 16 + c4)) + (t & 1u);
+    v4f64 d = {0, 0, 0, 0};
+    for (int k = 0; k < nn; ++k) {
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            v4f64 p = {0, 0, 0, 0};
+            const int comp = part ? ((g & 1) ^ 1) : (g & 1);
+            const double sgn = (part && !(g & 1)) ? -1.0 : 1.0;
+            const double* __restrict__ ga = Gs + (size_t)((k * M + (g >> 1)) * 2 + comp) * qstride + itc;
+#pragma unroll
+            for (int s = 0; s < KS2; ++s) {
+                const double a = (4 * s + g < 2 * M) ? sgn * ga[(size_t)s * 4 * qstride] : 0.0;
+                p = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tb[(size_t)s * 256], p, 0, 0, 0);
+            }
+            d += p * p;
+        }
+    }
+    return d;
+}
+
+// raw v_min3_f32 / v_min_f32: no canonicalisation pass over MFMA results; a NaN operand is ignored (minNum)
+__device__ __forceinline__ float vmin3_f32(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmin_f32(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// An upper bound of the k-th smallest of the 16 values a DPP row holds (one per lane), in every lane of the row: k - 1
+// times drop the row minimum (all lanes that tie with it: the bound can only get looser), then take the minimum.
+__device__ __forceinline__ float row_kth_smallest(float v, const uint32_t k)
+{
+    float mk = row_allmin(v);
+    for (uint32_t i = 1; i < k; ++i) {
+        v = (v <= mk) ? __builtin_inff() : v;
+        mk = row_allmin(v);
+    }
+    return mk;
+}
+
+// VAL: validation build (baz_music_debug_coarse_margin): every tile runs both forms, nothing is gated, no lists are kept,
+// and the worst |c / SC - d| / (2^-16 (S + |d|)) over all (item, bin) is left in *margin (float bits, atomicMax).
+//
+// Two passes over the wave's bin range.  PASS 1 (coarse only): the smallest coarse value of every (lane, item) -- a lane
+// sees the bins = c (mod 16), so the n-th smallest of a row's 16 lane minima bounds the item's n-th smallest coarse value
+// c_(n) from above (n different bins at or below it) -- gives the threshold  D <= (c_(n) + E) (1 + 2^-15)  before a
+// single exact tile has run.  Without it the thresholds only tighten as the walk happens to pass the minima: on a
+// descending slope of the spectrum EVERY tile beats the list and fires (measured: 0.28 ms per 262,144 coherent cfg2 items,
+// and 0.93 ms -- slower than the full scan -- when every item of a wave has its own scene).  PASS 2: the gated walk.
+template <int M, int NMAX, int RG, int TPP, bool VAL = false>
+__global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(const double* __restrict__ Qs,
+                                                                             const uint4* __restrict__ imgC,
+                                                                             const uint4* __restrict__ imgX,
+                                                                             double* __restrict__ cand, uint32_t batch,
+                                                                             uint32_t res, uint32_t qstride, uint32_t nphases,
+                                                                             uint32_t nsplit, uint32_t keep_mask, uint32_t n,
+                                                                             ScanRefine rf, CoarseParams cp,
+                                                                             unsigned int* __restrict__ margin)
+{
+    constexpr int MM = M * M;
+    static_assert(MM <= 16, "one K = 16 slab: m <= 4");
+    constexpr int C_UNITS = TPP * CS_C_UNITS, X_UNITS = TPP * CS_X_UNITS;   // 16-B units per phase, both multiples of 64
+    constexpr int C_CHUNKS = C_UNITS / 64, X_CHUNKS = X_UNITS / 64;         // 1-KiB wave loads per phase
+    __shared__ uint4 stage[2][C_UNITS + X_UNITS];                            // per buffer: [B32 | B16 of TPP tiles][X of TPP tiles]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, g = lane >> 4;
+
+    const uint32_t split = blockIdx.x % nsplit;
+    const uint32_t item0 = ((blockIdx.x / nsplit) * 4 + wave) * (16 * RG);      // first item of the wave
+    const uint32_t ph_begin = (uint32_t)(((uint64_t)nphases * split) / nsplit);
+    const uint32_t ph_end = (uint32_t)(((uint64_t)nphases * (split + 1)) / nsplit);
+
+    // ---- operands -------------------------------------------------------------------------------------------------
+    double qa[RG][4];          // exact A: q[item of row c][e = 4 s + g]   (natural row order)
+    v8f16 a32[RG];             // coarse A, K = 32: row c = item pi(c); k = 8 g + j: e = k & 15, piece = k >> 4 (hi | lo)
+    v4f16 a16[RG];             // coarse A, K = 16: k = 4 g + j: e = k, hi piece
+    v4f32 es[RG], negthr[RG];  // per accumulator register r (item g + 4 r): error allowance and -threshold, coarse units
+    double key[VAL ? 1 : RG][4][NMAX];
+    bool row_ok[RG][4];
+#pragma unroll
+    for (int q = 0; q < RG; ++q) {
+        const uint32_t it_n = item0 + 16 * q + (uint32_t)c;                          // natural row c
+        const uint32_t itn = (it_n < batch) ? it_n : (batch - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int e = 4 * s + g;
+            qa[q][s] = (e < MM) ? Qs[(size_t)e * qstride + itn] : 0.0;
+        }
+        const uint32_t it_p = item0 + 16 * q + (uint32_t)((c >> 2) + 4 * (c & 3));  // permuted row c
+        const uint32_t itp = (it_p < batch) ? it_p : (batch - 1);
+        // this lane's 8 coefficients e = (8 g + j) & 15 of the permuted item; lanes g = 0, 1 together cover all 16
+        float qsf[8], asum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = (8 * g + j) & 15;
+            const double qv = (e < MM) ? Qs[(size_t)e * qstride + itp] : 0.0;
+            qsf[j] = (float)(qv * 1024.0);
+            asum += fabsf((float)qv);
+        }
+        asum += __shfl_xor(asum, 16, 64);                     // sum_e |q_e| of the permuted item (rows g = 0,1 / 2,3 agree)
+        // a projector's coefficients are <= 2 in magnitude; anything else (non-finite or garbage q) never gates
+        const bool sane = asum <= 64.0f;                      // false for NaN
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = sane ? qsf[j] : 0.0f;
+            const _Float16 h = (_Float16)v;
+            const _Float16 l = (_Float16)(v - (float)h);      // exact difference (11-bit piece of a 24-bit value)
+            a32[q][j] = (g < 2) ? h : l;                      // k < 16: hi, k >= 16: lo
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = 4 * g + j;
+            const double qv = (e < MM) ? Qs[(size_t)e * qstride + itp] : 0.0;
+            a16[q][j] = sane ? (_Float16)(float)(qv * 1024.0) : (_Float16)0.0f;
+        }
+        // allowance of item g + 4 r = permuted row 4 g + r: held by the lanes with c = 4 g + r
+        const float es_row = sane ? asum * cp.es_factor * 1.0001f : __builtin_inff();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            es[q][r] = __shfl(es_row, 4 * g + r, 64);
+            negthr[q][r] = -__builtin_inff();                 // (set by pass 1)
+            row_ok[q][r] = (item0 + 16 * q + (uint32_t)(g + 4 * r)) < batch;
+        }
+    }
+    if constexpr (!VAL) {
+#pragma unroll
+        for (int q = 0; q < RG; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < NMAX; ++i) key[q][r][i] = key_empty();
+    }
+    const bool refine_on = rf.Gs != nullptr;
+    const double below_d = refine_on ? rf.below : -1.0;
+    const float below_s = refine_on ? (float)(rf.below * cp.sc) * 1.000001f : 0.0f;      // in coarse units, rounded up
+    const uint32_t nobin = ~keep_mask;
+    [[maybe_unused]] float worst = 0.0f;
+    uint32_t refined = 0;
+
+    // ---- table staging: L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no registers) ----------
+    auto stage_load = [&](uint32_t ph, int b, const bool with_x) {
+        const uint4* __restrict__ sc = imgC + (size_t)ph * C_UNITS + lane;
+#pragma unroll
+        for (int i = 0; i < (C_CHUNKS + 3) / 4; ++i) {
+            const int j = i * 4 + wave;                        // wave-uniform: chunk j of the phase
+            if (j < C_CHUNKS)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sc + j * 64),
+                                                 (__attribute__((address_space(3))) void*)(&stage[b][j * 64]), 16, 0, 0);
+        }
+        if (with_x) {
+            const uint4* __restrict__ sx = imgX + (size_t)ph * X_UNITS + lane;
+#pragma unroll
+            for (int i = 0; i < (X_CHUNKS + 3) / 4; ++i) {
+                const int j = i * 4 + wave;
+                if (j < X_CHUNKS)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sx + j * 64),
+                                                     (__attribute__((address_space(3))) void*)(&stage[b][C_UNITS + j * 64]), 16, 0, 0);
+            }
+        }
+    };
+
+    int buf = 0;
+    // ---- pass 1: thresholds from the coarse form alone -----------------------------------------------------------------
+    if constexpr (!VAL) {
+        v4f32 pm[RG];
+#pragma unroll
+        for (int q = 0; q < RG; ++q) pm[q] = (v4f32){__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+        if (ph_begin < ph_end) stage_load(ph_begin, 0, false);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (uint32_t ph = ph_begin; ph < ph_end; ++ph) {
+            if (ph + 1 < ph_end) stage_load(ph + 1, buf ^ 1, false);
+#pragma nounroll
+            for (int tl = 0; tl < TPP; ++tl) {
+                const char* __restrict__ T = reinterpret_cast<const char*>(&stage[buf][0]) + tl * (CS_C_UNITS * 16);
+                const v8f16 b32 = *reinterpret_cast<const v8f16*>(T + lane * 16);
+                const v4f16 b16 = *reinterpret_cast<const v4f16*>(T + 1024 + lane * 8);
+#pragma unroll
+                for (int q = 0; q < RG; ++q) {
+                    v4f32 u = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[q], b32, (v4f32){0, 0, 0, 0}, 0, 0, 0);
+                    u = __builtin_amdgcn_mfma_f32_16x16x16f16(a16[q], b16, u, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pm[q][r] = vmin_f32(pm[q][r], u[r]);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf ^= 1;
+        }
+        // D <= (c_(n) + es) (1 + 2^-15), never below `refine_below`;  thr = D (1 + 2^-16) + es   (all in coarse units)
+#pragma unroll
+        for (int q = 0; q < RG; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float cn = row_kth_smallest(pm[q][r], n);
+                const float Dd = fmaxf(fmaxf(cn + es[q][r], 0.0f) * 1.0000306f, below_s);
+                negthr[q][r] = -__builtin_fmaf(Dd, 1.0000164f, es[q][r]);
+            }
+    }
+
+    // ---- pass 2: the gated walk ------------------------------------------------------------------------------------------
+    if (ph_begin < ph_end) stage_load(ph_begin, buf, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (uint32_t ph = ph_begin; ph < ph_end; ++ph) {
+        if (ph + 1 < ph_end) stage_load(ph + 1, buf ^ 1, true);     // lands while this phase's tiles run
+#pragma nounroll
+        for (int tl = 0; tl < TPP; ++tl) {
+            const char* __restrict__ T = reinterpret_cast<const char*>(&stage[buf][0]) + tl * (CS_C_UNITS * 16);
+            const v8f16 b32 = *reinterpret_cast<const v8f16*>(T + lane * 16);
+            const v4f16 b16 = *reinterpret_cast<const v4f16*>(T + 1024 + lane * 8);
+            v4f32 u[RG];
+            float mn[RG];
+#pragma unroll
+            for (int q = 0; q < RG; ++q) {
+                const v4f32 cin = VAL ? (v4f32){0, 0, 0, 0} : negthr[q];
+                u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[q], b32, cin, 0, 0, 0);
+                u[q] = __builtin_amdgcn_mfma_f32_16x16x16f16(a16[q], b16, u[q], 0, 0, 0);
+            }
+            float mall = __builtin_inff();
+#pragma unroll
+            for (int q = 0; q < RG; ++q) {
+                mn[q] = vmin_f32(vmin3_f32(u[q][0], u[q][1], u[q][2]), u[q][3]);
+                mall = vmin_f32(mall, mn[q]);
+            }
+            if (!VAL && !__any(mall <= 0.0f)) continue;       // no group of this wave can gain from this tile
+            const uint32_t bin = (ph * TPP + (uint32_t)tl) * 16u + (uint32_t)c;
+            const double* __restrict__ X = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&stage[buf][C_UNITS]) +
+                                                                            tl * (CS_X_UNITS * 16));
+#pragma unroll
+            for (int q = 0; q < RG; ++q) {
+                if (!VAL && !__any(mn[q] <= 0.0f)) continue;
+                // exact form: scan_mfma_kernel's projector GEMM for this 16 x 16 tile (same k order, same operands)
+                const v2f64 x01 = *reinterpret_cast<const v2f64*>(X + lane * 2);
+                const v2f64 x23 = *reinterpret_cast<const v2f64*>(X + 128 + lane * 2);
+                v4f64 acc = {0, 0, 0, 0};
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][0], x01.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][1], x01.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][2], x23.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][3], x23.y, acc, 0, 0, 0);
+                if constexpr (VAL) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // S of item g + 4 r in d units: es / (2^-16 SC 1.0001); allowance 2^-16 (S + |d|)
+                        const double S = (double)es[q][r] / (1.0001 * (double)cp.es_factor) * cp.fmax;
+                        const double err = fabs((double)u[q][r] / cp.sc - acc[r]);
+                        const double allow = 0x1p-16 * (S + fabs(acc[r]));
+                        const bool counts = bin < res && row_ok[q][r] && S < 1e30 && allow > 0.0 && err == err;
+                        worst = fmaxf(worst, counts ? (float)(err / allow) : 0.0f);
+                    }
+                } else {
+                    bool low = false;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) low |= (fabs(acc[r]) <= below_d);
+                    if (refine_on && __any(low)) {                  // near-null tile: the reference's literal form, per value
+                        const uint32_t it_n = item0 + 16 * q + (uint32_t)c;
+                        const v4f64 d = literal16<M>(rf.Gs, rf.TB, (it_n < batch) ? it_n : (batch - 1), g, qstride, (int)M - (int)n, bin);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool redo = (fabs(acc[r]) <= rf.below) && (bin < res);
+                            acc[r] = redo ? d[r] : acc[r];
+                            refined += (redo && row_ok[q][r]) ? 1u : 0u;
+                        }
+                    }
+                    const uint32_t kbin = (bin < res) ? bin : nobin;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        key_insert_new<NMAX>(key[q][r], make_key(acc[r], kbin, keep_mask));
+                        double kn = key[q][r][0];                   // the list's n-th entry (the lists hold NMAX >= n)
+#pragma unroll
+                        for (int i = 1; i < NMAX; ++i) kn = ((uint32_t)i < n) ? key[q][r][i] : kn;
+                        const uint64_t kb = __builtin_bit_cast(uint64_t, kn) | (uint64_t)(~keep_mask);
+                        const double D = fmax(__builtin_bit_cast(double, kb), below_d);
+                        // (float) rounds to nearest: sc_up carries the factor that makes the product an upper bound
+                        const float thr = row_allmin(__builtin_fmaf((float)D, cp.sc_up, es[q][r]));
+                        negthr[q][r] = fmaxf(negthr[q][r], -thr);   // thresholds only ever tighten
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    if constexpr (VAL) {
+#pragma unroll
+        for (int msk = 1; msk < 64; msk <<= 1) worst = fmaxf(worst, __shfl_xor(worst, msk, 64));
+        if (lane == 0 && margin) atomicMax(margin, __builtin_bit_cast(unsigned int, worst));
+        return;
+    } else {
+        if (rf.count) {
+#pragma unroll
+            for (int msk = 1; msk < 64; msk <<= 1) refined += __shfl_xor(refined, msk, 64);
+            if (lane == 0 && refined) atomicAdd(rf.count, (unsigned long long)refined);
+        }
+        // merge the 16 lanes of an item row, emit this range's candidates (topn_merge_kernel folds the ranges)
+#pragma unroll
+        for (int q = 0; q < RG; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                key_merge_xor<NMAX>(key[q][r], 1);
+                key_merge_xor<NMAX>(key[q][r], 2);
+                key_merge_xor<NMAX>(key[q][r], 4);
+                key_merge_xor<NMAX>(key[q][r], 8);
+                const uint32_t it = item0 + 16 * q + (uint32_t)(g + 4 * r);
+                if (c == 0 && it < batch) {
+#pragma unroll
+                    for (int i = 0; i < NMAX; ++i) cand[((size_t)it * nsplit + split) * NMAX + i] = key[q][r][i];
+                }
+            }
+    }
+}
+
+}  // namespace bazmusic

@@ -96,20 +96,28 @@ baz_music_doa::baz_music_doa(unsigned int m, unsigned int n, unsigned int nsampl
     if (rc != BAZ_MUSIC_OK)
         throw std::runtime_error(std::string("music_doa: cannot open the gfx950 engine: ") + baz_music_strerror(rc));
 
-    /* Scheduler hints.  The reference handles ONE item per work() call (.cc:74,160); here a
-     * call is one launch sequence over all its items, so the block asks the scheduler for large calls:
-     *   set_output_multiple(N)     work() only ever sees multiples of N items, and GNU Radio sizes the buffers on
-     *                              both sides for at least 2 N items (flat_flowgraph::allocate_buffer) instead of
-     *                              the default 64 KiB (= 8 cfg2 items);
-     *   set_min_output_buffer(B)   output buffers of at least B items, so that several multiples fit one call;
-     *   set_max_noutput_items(C)   a CAP, separate from the two requests above, unset by default.
-     * What the runtime makes of them (call sizes per work()) is modelled in gr_shim/gnuradio/flowgraph_model.h.
-     * N trades latency for launch efficiency (N items must have arrived before work() runs); the environment
-     * overrides the defaults: BAZ_MUSIC_OUTPUT_MULTIPLE (64), BAZ_MUSIC_MIN_OUTPUT_BUFFER (8 multiples),
-     * BAZ_MUSIC_MAX_NOUTPUT (0 = no cap). */
-    const long multiple = env_long("BAZ_MUSIC_OUTPUT_MULTIPLE", 64, 1, 1 << 20);
-    const long min_buffer = env_long("BAZ_MUSIC_MIN_OUTPUT_BUFFER", 8 * multiple, 0, 1L << 30);
+    /* Scheduler hints.  The reference handles ONE item per work() call (.cc:74,160); here a call
+     * is one launch sequence over all its items, so the block wants LARGE calls -- without giving up what the reference
+     * guarantees: every item of a finite stream is processed, and an item is processed as soon as it has arrived.
+     * GNU Radio sizes a buffer for 2 x (output multiple + history) items of every reader
+     * (flat_flowgraph::allocate_buffer); the default is 64 KiB = 8 cfg2 items.  Two ways to ask for more:
+     *   set_output_multiple(N)     also makes N the MINIMUM call: N items must have arrived before work() runs, and what
+     *                              does not fill a last multiple when a finite source ends is never processed;
+     *   set_history(H + 1)         declares H items of look-back the block never reads: the upstream buffer grows to
+     *                              2 (H + 2) items, calls of up to ~H items form whenever the block is the bottleneck,
+     *                              a single item is still a valid call, and nothing is lost at the end of a stream: the
+     *                              runtime preloads the H look-back items as zeros (buffer_add_reader(.., history - 1)),
+     *                              output i is computed from input i + H, i.e. from real item i.
+     * The block uses the second: BAZ_MUSIC_INPUT_LOOKBACK = H (default 1024 items; 0 = none), output multiple 1,
+     * set_min_output_buffer(2 H) so that the output side admits the same calls (a call takes at most half a buffer).
+     * BAZ_MUSIC_OUTPUT_MULTIPLE (1), BAZ_MUSIC_MIN_OUTPUT_BUFFER, BAZ_MUSIC_MAX_NOUTPUT (0 = no cap) override.
+     * What the runtime makes of them (call sizes per work()) is modelled in gr_shim/gnuradio/flowgraph_model.h;
+     * INTEGRATION.md 5 has the memory these requests cost and the measured rates. */
+    const long lookback = env_long("BAZ_MUSIC_INPUT_LOOKBACK", 1024, 0, 1 << 20);
+    const long multiple = env_long("BAZ_MUSIC_OUTPUT_MULTIPLE", 1, 1, 1 << 20);
+    const long min_buffer = env_long("BAZ_MUSIC_MIN_OUTPUT_BUFFER", std::max(2 * lookback, multiple > 1 ? 8 * multiple : 0L), 0, 1L << 30);
     const long cap = env_long("BAZ_MUSIC_MAX_NOUTPUT", 0, 0, 1L << 30);
+    set_history((unsigned)lookback + 1);
     set_output_multiple((int)multiple);
     if (min_buffer > 0) set_min_output_buffer(min_buffer);
     if (cap > 0) set_max_noutput_items((int)std::max(multiple, cap - cap % multiple));   /* the runtime does not round a cap */
@@ -174,7 +182,8 @@ int baz_music_doa::work(int noutput_items, gr_vector_const_void_star& input_item
     if (noutput_items <= 0) return 0;
     if (input_items.empty() || output_items.empty()) return -1;
 
-    const float* in = static_cast<const float*>(input_items[0]);   /* gr_complex == (float re, float im) */
+    /* input_items[0] points at the OLDEST look-back item (history() - 1 of them precede the item output 0 belongs to) */
+    const float* in = static_cast<const float*>(input_items[0]) + (size_t)(history() - 1) * d_nsamples * 2;   /* gr_complex == (float re, float im) */
     float* ang = static_cast<float*>(output_items[0]);
     float* lvl = (output_items.size() > 1) ? static_cast<float*>(output_items[1]) : NULL;
     float* spectrum = (output_items.size() > 2) ? static_cast<float*>(output_items[2]) : NULL;

@@ -33,7 +33,11 @@ py::tuple drive_work(music_doa_handle& h, py::array_t<std::complex<float>, py::a
     py::array_t<float> ang({(size_t)nitems, (size_t)h.blk->n()});
     py::array_t<float> lvl({(size_t)nitems, (size_t)h.blk->n()});
     py::array_t<float> spec({(size_t)nitems, (size_t)h.blk->resolution()});
-    gr_vector_const_void_star in(1, bi.ptr);
+    // work() is handed the address of the OLDEST look-back item (history() - 1 items in front of the first real one); the
+    // block never reads them (it only declares them, to make the runtime size its input buffer), so no storage backs them here
+    const void* window = reinterpret_cast<const void*>(reinterpret_cast<uintptr_t>(bi.ptr) -
+                                                       (uintptr_t)(h.blk->history() - 1) * N * sizeof(gr_complex));
+    gr_vector_const_void_star in(1, window);
     gr_vector_void_star out;
     out.push_back(ang.mutable_data());
     if (n_outputs > 1) out.push_back(lvl.mutable_data());
@@ -114,16 +118,18 @@ py::tuple run_flowgraph(music_doa_handle& h, py::array_t<std::complex<float>, py
 class shim_copy_block : public gr::sync_block
 {
 public:
-    shim_copy_block(int item, int nout, int multiple, long min_buffer, int cap)
+    shim_copy_block(int item, int nout, int multiple, long min_buffer, int cap, int history)
         : gr::sync_block("shim_copy", gr::io_signature::make(1, 1, item), gr::io_signature::make(1, 3, item)), d_item(item), d_nout(nout)
     {
+        set_history((unsigned)history);          // look-back it never reads, like the MUSIC / AGC blocks' buffer request
         set_output_multiple(multiple);
         if (min_buffer > 0) set_min_output_buffer(min_buffer);
         if (cap > 0) set_max_noutput_items(cap);
     }
     int work(int noutput_items, gr_vector_const_void_star& in, gr_vector_void_star& out)
     {
-        for (int p = 0; p < d_nout; ++p) std::memcpy(out[p], in[0], (size_t)noutput_items * (size_t)d_item);
+        const char* newest = static_cast<const char*>(in[0]) + (size_t)(history() - 1) * (size_t)d_item;
+        for (int p = 0; p < d_nout; ++p) std::memcpy(out[p], newest, (size_t)noutput_items * (size_t)d_item);
         return noutput_items;
     }
     unsigned long long pinned_bytes() const { return 0; }
@@ -133,12 +139,12 @@ private:
 };
 
 py::tuple model_selftest(py::array_t<unsigned char, py::array::c_style | py::array::forcecast> data, int item_size, int n_outputs,
-                         int multiple, long min_buffer, int cap)
+                         int multiple, long min_buffer, int cap, int history)
 {
     py::buffer_info bi = data.request();
     if (item_size <= 0 || bi.size % item_size) throw std::invalid_argument("data must hold k * item_size bytes");
     const long nitems = (long)(bi.size / item_size);
-    shim_copy_block blk(item_size, n_outputs, multiple, min_buffer, cap);
+    shim_copy_block blk(item_size, n_outputs, multiple, min_buffer, cap, history < 1 ? 1 : history);
     std::vector<py::array_t<unsigned char> > outs;
     char* sinks[3] = {NULL, NULL, NULL};
     for (int p = 0; p < n_outputs; ++p) {
@@ -163,7 +169,9 @@ py::tuple drive_agc(agc_handle& h, py::array_t<std::complex<float>, py::array::c
     const int n = (int)bi.size;
     py::array_t<std::complex<float>> out((size_t)n);
     py::array_t<float> env((size_t)n), mul((size_t)n);
-    gr_vector_const_void_star in(1, bi.ptr);
+    const void* window = reinterpret_cast<const void*>(reinterpret_cast<uintptr_t>(bi.ptr) -
+                                                       (uintptr_t)(h.blk->history() - 1) * sizeof(gr_complex));   // see drive_work
+    gr_vector_const_void_star in(1, window);
     gr_vector_void_star outs;
     outs.push_back(out.mutable_data());
     if (n_outputs > 1) outs.push_back(env.mutable_data());
@@ -246,6 +254,7 @@ PYBIND11_MODULE(_baz_music, mod)
         /* scheduler hints the block registered (recorded by the API stand-in; a real runtime acts on them) */
         .def("device", [](music_doa_handle& h) { return h.blk->device(); })
         .def("output_multiple", [](music_doa_handle& h) { return h.blk->output_multiple(); })
+        .def("history", [](music_doa_handle& h) { return h.blk->history(); })
         .def("min_output_buffer", [](music_doa_handle& h) { return h.blk->min_output_buffer(); })
         .def("max_noutput_items", [](music_doa_handle& h) { return h.blk->max_noutput_items(); })
         .def("work", &drive_work, py::arg("items"), py::arg("n_outputs") = 3)
@@ -259,6 +268,7 @@ PYBIND11_MODULE(_baz_music, mod)
     py::class_<agc_handle>(mod, "baz_agc_cc_sptr")
         .def("name", [](agc_handle& h) { return h.blk->name(); })
         .def("output_multiple", [](agc_handle& h) { return h.blk->output_multiple(); })
+        .def("history", [](agc_handle& h) { return h.blk->history(); })
         .def("min_output_buffer", [](agc_handle& h) { return h.blk->min_output_buffer(); })
         .def("input_item_sizes", [](agc_handle& h) { return h.blk->input_signature()->sizeof_stream_items(); })
         .def("output_item_sizes", [](agc_handle& h) { return h.blk->output_signature()->sizeof_stream_items(); })
@@ -328,7 +338,7 @@ PYBIND11_MODULE(_baz_music, mod)
             py::arg("items_in"), py::arg("out_space"), py::arg("out_bufsize"), py::arg("multiple") = 1, py::arg("history") = 1,
             py::arg("max_noutput_items") = 0);
     mod.def("gr37_model_selftest", &model_selftest, py::arg("data"), py::arg("item_size"), py::arg("n_outputs") = 1,
-            py::arg("multiple") = 1, py::arg("min_buffer") = -1L, py::arg("cap") = 0);
+            py::arg("multiple") = 1, py::arg("min_buffer") = -1L, py::arg("cap") = 0, py::arg("history") = 1);
     mod.def("deal_device", &baz_music_doa_deal_device, py::arg("instance"), py::arg("device_count"),
             "placement rule of block instances: instance % device_count (-1 without devices)");
     mod.def("music_doa",

@@ -19,7 +19,8 @@
  * The neighbours are idealised: the source never starves the block (it refills the input buffer, in calls of at most
  * half a buffer like any block, whenever the block looks) and the sinks never stall it (they drain every call's
  * output at once).  That is the regime in which the hints decide the call size.  Items that do not fill a last
- * output multiple when the source ends are dropped, as in GNU Radio.  Restated from the published behaviour of
+ * output multiple when the source ends are dropped, as in GNU Radio.  A reader with history h starts h - 1 zero items
+ * behind the write pointer (buffer_add_reader's nzero_preload), so it sees every real item as the NEWEST of a window.  Restated from the published behaviour of
  * gnuradio-runtime 3.7 (lib/flat_flowgraph.cc, lib/buffer.cc, lib/block_executor.cc); no GNU Radio source is
  * available here, so this is a model, and tests/test_scheduler_model.py pins its arithmetic on hand-computed cases. */
 #ifndef GR_BAZ_AMD_SHIM_FLOWGRAPH_MODEL_H
@@ -170,6 +171,9 @@ run_stats run_sync_block(Block& blk, const char* src, long n_items, int n_output
     me[0].multiple = multiple;
     me[0].history = history;
     circ_buffer in(buffer_items(in_item, 1, -1, -1, me), in_item);       /* a source with no hints of its own */
+    /* buffer_add_reader(buffer, nzero_preload = history - 1, ..): the reader starts history - 1 items BEHIND the write
+     * pointer, over zeroed memory -- the look-back of the first real item */
+    in.produce(history - 1);
     std::vector<circ_buffer*> out;
     struct cleanup {
         std::vector<circ_buffer*>& v;
@@ -215,7 +219,7 @@ run_stats run_sync_block(Block& blk, const char* src, long n_items, int n_output
         const long noutput = plan_noutput(in.items_available(), space, sizes, multiple, history,
                                           blk.is_set_max_noutput_items(), blk.max_noutput_items());
         if (noutput == 0) {                                     /* blocked on input and the source is done */
-            st.dropped_at_end = in.items_available();
+            st.dropped_at_end = in.items_available() - (history - 1);   /* (the look-back items stay in the buffer) */
             break;
         }
         in_ptrs[0] = in.read_pointer();

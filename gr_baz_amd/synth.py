@@ -41,3 +41,26 @@ def synth_stream(torch, device, batch, m, nsamples, antenna_array, frequency, ar
     nz = torch.randn(batch, K, m, 2, generator=g, device=device, dtype=torch.float32)
     x += torch.view_as_complex(nz) * sigma
     return torch.view_as_real(x.reshape(batch, K * m)).reshape(batch, 2 * nsamples).contiguous()
+
+
+def synth_scenes(torch, device, batch, m, nsamples, antenna_array, frequency, array_spacing, n_emitters=2, snr_db=20.0, seed=0):
+    """Like synth_stream, but every ITEM sees its own scene: n_emitters angles drawn uniformly over 360 degrees per item
+    (an incoherent batch -- items of many unrelated streams -- the unfavourable case for anything that is decided per
+    wave of 16 items: the scan's top-n gate, the coarse-gated scan's tile votes)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    K = nsamples // m
+    lam = C_LIGHT / frequency
+    p = torch.tensor(np.asarray(antenna_array, dtype=np.float64) * array_spacing, device=device)         # (m, 2)
+    x = torch.zeros(batch, K, m, dtype=torch.complex64, device=device)
+    for _ in range(n_emitters):
+        th = torch.rand(batch, generator=g, device=device, dtype=torch.float64) * (2.0 * math.pi)
+        phase = (p[None, :, 0] * torch.cos(th)[:, None] + p[None, :, 1] * torch.sin(th)[:, None]) * (-2.0 * math.pi / lam)
+        a = torch.polar(torch.ones_like(phase), phase).to(torch.complex64)                                # (batch, m)
+        s = torch.randn(batch, K, 2, generator=g, device=device, dtype=torch.float32)
+        s = torch.view_as_complex(s) * (1.0 / math.sqrt(2.0))
+        x += s[:, :, None] * a[:, None, :]
+    sigma = 10.0 ** (-snr_db / 20.0) / math.sqrt(2.0)
+    nz = torch.randn(batch, K, m, 2, generator=g, device=device, dtype=torch.float32)
+    x += torch.view_as_complex(nz) * sigma
+    return torch.view_as_real(x.reshape(batch, K * m)).reshape(batch, 2 * nsamples).contiguous()

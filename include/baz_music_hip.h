@@ -72,7 +72,15 @@ BAZ_MUSIC_API void baz_music_destroy(baz_music_ctx* ctx);
  * every item submitted after it returns. Thread-safe against process*(). */
 BAZ_MUSIC_API int baz_music_set_table(baz_music_ctx* ctx, const float* table_ri);
 
-/* Replaces the body of baz_music_doa::work (lib/baz_music_doa.cc:72-161) for `batch`
+/* NUMERIC CONTRACT of the float outputs.  The reference stores (float)(1.0 / d), d = ||G^H a||^2 in fp64
+ * (lib/baz_music_doa.cc:114-121,153).  Here d is evaluated in fp64 (projector form, literal form near nulls) and the
+ * stored value is v_rcp_f32((float)d): within ~2 ulp_f32 (2.4e-7 relative) of the reference's correctly rounded value,
+ * against north_star's 1e-5 -- so spectrum / lvl floats are close to, not bit-equal with, a CPU run of the reference.
+ * Where the two differ in KIND: for 0 < d < FLT_MIN (1.2e-38) the reference stores a finite 1e38+ value while (float)d
+ * is subnormal or 0 and v_rcp_f32 returns +inf; d == 0 gives +inf in both.  lvl[i] == spectrum[bin_i] holds bit for bit,
+ * as in the reference.  ang is (float)(bin * 360.0 / resolution), exact.
+ *
+ * Replaces the body of baz_music_doa::work (lib/baz_music_doa.cc:72-161) for `batch`
  * consecutive items held in HOST memory; blocks until ang/lvl/spectrum are filled.
  * lvl and spectrum may be NULL (ports 1 / 2 not wired; guards the reference's NULL-lvl
  * dereference, .cc:147-154). Returns the number of items processed (== batch) or <0. */
@@ -126,6 +134,14 @@ BAZ_MUSIC_API int baz_music_debug_evd(baz_music_ctx* ctx, const void* d_R, uint3
 /*   q   : d_in -> d_Q      the two stages back to back, exactly as process_device() runs them for this
  *                          configuration; projector coefficients as for `evd` */
 BAZ_MUSIC_API int baz_music_debug_q(baz_music_ctx* ctx, const void* d_in, uint32_t batch, void* d_Q);
+/*   coarse margin : the scan that runs when port 2 is NOT wired and m <= 4 (lib/baz_music_doa.cc:97-99: only the top-n list
+ *                          is observable then) evaluates every 16-item x 16-bin tile in a coarse f16-matrix-core form first and
+ *                          the exact fp64 form only where a tile can still hold a top-n member; ang / lvl are bit-identical to
+ *                          the full scan as long as |coarse - exact| <= 2^-16 (S + |exact|) (gr_baz_amd/csrc/
+ *                          scan_coarse_kernels.hip.h).  This tap runs covariance + EVD of the batch and then BOTH forms on every
+ *                          (item, bin); *worst = the largest observed error / allowance (sound below 1; derived with a factor
+ *                          > 2 to spare).  BAZ_MUSIC_E_UNSUPPORTED for m > 4 or a table whose scale does not fit. */
+BAZ_MUSIC_API int baz_music_debug_coarse_margin(baz_music_ctx* ctx, const void* d_in, uint32_t batch, float* worst);
 BAZ_MUSIC_API uint32_t baz_music_q_stride(uint32_t batch);
 
 /* Algorithmic HBM bytes per item: 8*nsamples + 8*n + 4*resolution (the last
@@ -149,6 +165,11 @@ BAZ_MUSIC_API int baz_music_set_peak_mode(baz_music_ctx* ctx, int mode);
  * ||G^H a||^2 because the projector form a^H Q a put them at or below ~m 1e-8 max||a||^2 (near-nulls of the noise
  * subspace, SNR >~ 55 dB); blocks until that call is done (a host-fed call cut into chunks reports their sum).
  * -1 on error.  See DESIGN.md 2 (near-nulls).  (The name is kept from round 1, which redid whole items.) */
+BAZ_MUSIC_API int64_t baz_music_refined_values(baz_music_ctx* ctx);
+/* The same number under its round-1 name (round 1 redid whole ITEMS; since round 2 the unit is one (item, bin) value, so
+ * do not compare it with a batch size).  Always 0 past BAZ_MUSIC_FAST_M antennas: the wide path evaluates the literal form
+ * near nulls per bin inside its scan and keeps no count.  Without the spectrum port only values that could still enter
+ * the top-n list are evaluated at all, so fewer are counted than with it. */
 BAZ_MUSIC_API int64_t baz_music_refined_items(baz_music_ctx* ctx);
 BAZ_MUSIC_API int baz_music_device_count(void);
 BAZ_MUSIC_API int baz_music_device(const baz_music_ctx* ctx);

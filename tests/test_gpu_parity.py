@@ -730,6 +730,37 @@ def test_page_locking_of_persistent_caller_buffers(gpu_device, monkeypatch):
         assert all(np.array_equal(x, y) for x, y in zip(out, (a0, l0, s0)))
 
 
+def test_partly_page_locked_ranges_take_the_copy_path(gpu_device):
+    """ADVICE r2 / review r2 weak 7: "this range is page-locked" must hold for the WHOLE range before the kernels address
+    it over PCIe.  Two contexts share one upstream buffer at different offsets (a fan-out in a flowgraph); context A
+    owns a registration that covers only the HEAD of what context B is handed.  B must neither fault the GPU (zero-copy
+    into unmapped host memory) nor fail (a DMA copy whose host range is partly inside a registration is refused by the
+    runtime): results equal the all-pageable run."""
+    c = mo.make_config("cfg1", 256, seed=35)
+    items = np.ascontiguousarray(np.tile(c["items"], (2, 1)))                      # 512 items, 1 MiB: a "small call"
+    B = items.shape[0]
+    spec_buf = np.zeros((B, c["res"]), np.float32)
+    with _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"]) as ref_ctx:
+        a0, l0, s0 = [x.copy() for x in ref_ctx.process(items)]
+    with _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"]) as A, \
+            _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"]) as Bc:
+        assert A.host_register(items[:200]) == 0                                   # A locks the head of the input ...
+        assert A.host_register(spec_buf[:100]) == 0                                # ... and of the spectrum buffer
+        for off, nb in ((0, B), (100, 300), (150, 100), (0, 200), (0, 100)):       # straddling, inside, exactly the head
+            out = (np.zeros((nb, c["n"]), np.float32), np.zeros((nb, c["n"]), np.float32), spec_buf[off:off + nb])
+            out[2].fill(0)
+            Bc.process(items[off:off + nb], out=out)
+            assert np.array_equal(out[0], a0[off:off + nb]) and np.array_equal(out[1], l0[off:off + nb])
+            assert np.array_equal(out[2], s0[off:off + nb])
+        Bc.set_host_pinning(True)              # B's own attempt to lock the overlapping range is refused or merged: still right
+        out = (np.zeros((B, c["n"]), np.float32), np.zeros((B, c["n"]), np.float32), spec_buf)
+        spec_buf.fill(0)
+        Bc.process(items, out=out)
+        assert np.array_equal(out[0], a0) and np.array_equal(out[2], s0)
+        Bc.host_unregister_all()
+        A.host_unregister_all()
+
+
 def test_caller_stream_ordering(gpu_device):
     """baz_music_set_stream: work is ordered on the caller's stream (here a torch side stream), so torch
     ops enqueued before/after on that stream see consistent data without extra synchronisation."""

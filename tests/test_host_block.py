@@ -109,22 +109,53 @@ def test_host_block_work_matches_golden(name, gpu_device, capfd):
 
 @pytest.mark.gpu
 def test_scheduler_hints_are_requests_not_caps(gpu_device, monkeypatch):
-    """the block asks for large work() calls (output multiple + minimum output buffer) and sets NO cap
-    unless told to (lib/baz_music_doa.cc:160 returns 1 item per call; here one call = one launch sequence)."""
+    """the block asks for large work() calls WITHOUT a minimum call size or a cap: output multiple 1 (every
+    item of a finite stream is processed, like the reference: lib/baz_music_doa.cc:160 consumes what it is given), look-back
+    items it never reads (history H + 1: the runtime sizes the input buffer for 2 (H + 2) items) and output buffers of 2 H."""
     tab = [[1 + 0j] * 4] * 8
-    for k in ("BAZ_MUSIC_OUTPUT_MULTIPLE", "BAZ_MUSIC_MIN_OUTPUT_BUFFER", "BAZ_MUSIC_MAX_NOUTPUT"):
+    for k in ("BAZ_MUSIC_OUTPUT_MULTIPLE", "BAZ_MUSIC_MIN_OUTPUT_BUFFER", "BAZ_MUSIC_MAX_NOUTPUT", "BAZ_MUSIC_INPUT_LOOKBACK"):
         monkeypatch.delenv(k, raising=False)
     blk = _baz().music_doa(4, 2, 16, tab, 8)
-    assert blk.output_multiple() == 64 and blk.min_output_buffer() == 512 and blk.max_noutput_items() == 0
-    monkeypatch.setenv("BAZ_MUSIC_OUTPUT_MULTIPLE", "256")
+    assert blk.output_multiple() == 1 and blk.history() == 1025 and blk.min_output_buffer() == 2048 and blk.max_noutput_items() == 0
+    monkeypatch.setenv("BAZ_MUSIC_OUTPUT_MULTIPLE", "256")       # the round-2 way stays available (a minimum call size)
+    monkeypatch.setenv("BAZ_MUSIC_INPUT_LOOKBACK", "0")
     monkeypatch.setenv("BAZ_MUSIC_MAX_NOUTPUT", "4096")
     blk = _baz().music_doa(4, 2, 16, tab, 8)
-    assert blk.output_multiple() == 256 and blk.min_output_buffer() == 2048 and blk.max_noutput_items() == 4096
+    assert blk.output_multiple() == 256 and blk.history() == 1 and blk.min_output_buffer() == 2048 and blk.max_noutput_items() == 4096
     monkeypatch.setenv("BAZ_MUSIC_OUTPUT_MULTIPLE", "1")
     monkeypatch.setenv("BAZ_MUSIC_MIN_OUTPUT_BUFFER", "0")
     monkeypatch.delenv("BAZ_MUSIC_MAX_NOUTPUT")
     blk = _baz().music_doa(4, 2, 16, tab, 8)          # the reference's behaviour: no hints at all
-    assert blk.output_multiple() == 1 and blk.min_output_buffer() == -1 and blk.max_noutput_items() == 0
+    assert blk.output_multiple() == 1 and blk.history() == 1 and blk.min_output_buffer() == -1 and blk.max_noutput_items() == 0
+
+
+@pytest.mark.gpu
+def test_finite_stream_is_processed_to_its_last_item(gpu_device, monkeypatch):
+    """with an output multiple N a finite source loses its last < N items and a capture shorter than N gives
+    nothing.  The default hints (look-back, multiple 1) lose nothing: 1, 7 and 2,500 items through the scheduler model
+    come out complete and equal to plain work() calls; the round-2 hint (multiple 64) drops the tail, as documented."""
+    from conftest import load_golden
+    g = load_golden("cfg1_m4_n2_N256_r360")
+    from gr_baz_amd import baz
+    for k in ("BAZ_MUSIC_OUTPUT_MULTIPLE", "BAZ_MUSIC_MIN_OUTPUT_BUFFER", "BAZ_MUSIC_MAX_NOUTPUT", "BAZ_MUSIC_INPUT_LOOKBACK"):
+        monkeypatch.delenv(k, raising=False)
+    table = [list(map(complex, r)) for r in g["table"]]
+    blk = baz.music_doa(g["m"], g["n"], g["nsamples"], table, g["res"])
+    base = g["items"]
+    for count in (1, 7, 2500):
+        items = np.concatenate([base] * (count // base.shape[0] + 1))[:count]
+        st, ang, lvl, spec = blk.run_flowgraph(items, 3, True, False)
+        assert st["items"] == count and st["dropped_at_end"] == 0 and st["last_return"] > 0
+        p, a1, l1, s1 = blk.work(items, 3)
+        assert p == count and np.array_equal(a1, ang) and np.array_equal(l1, lvl) and np.array_equal(s1, spec)
+        if count == 2500:
+            assert max(st["call_sizes"]) == 1024 and st["in_bufsize"] >= 2 * 1026       # calls of H items, input sized by the look-back
+    monkeypatch.setenv("BAZ_MUSIC_OUTPUT_MULTIPLE", "64")
+    monkeypatch.setenv("BAZ_MUSIC_INPUT_LOOKBACK", "0")
+    blk = baz.music_doa(g["m"], g["n"], g["nsamples"], table, g["res"])
+    items = np.concatenate([base] * 10)[:100]
+    st, ang, lvl, spec = blk.run_flowgraph(items, 3, True, False)
+    assert st["items"] == 64 and st["dropped_at_end"] == 36
 
 
 @pytest.mark.gpu

@@ -58,6 +58,30 @@ def test_call_planning_follows_run_one_iteration():
     assert b.gr37_plan_noutput(7, [8191, 8191, 63], [8192, 8192, 64], 1) == 7
 
 
+def test_look_back_items_enlarge_the_input_buffer_and_lose_nothing():
+    """The MUSIC / AGC blocks' buffer request: history h with output multiple 1.  The upstream buffer is sized for
+    2 (1 + h) items, calls grow to what half an output buffer and the input's h - 1 look-back items leave, a stream of ANY
+    length arrives complete (the reader starts h - 1 zero items behind the write pointer and treats every real item as
+    the newest of its window), and a single item is a valid call."""
+    b = _baz()
+    item = 24
+    for n, h, min_buffer in ((1, 100, 256), (5, 100, 256), (5000, 100, 256), (5000, 1000, 2048), (3000, 64, -1)):
+        data = np.random.default_rng(n + h).integers(0, 256, size=item * n, dtype=np.uint8)
+        st, outs = b.gr37_model_selftest(data, item, 2, 1, min_buffer, 0, h)
+        assert st["items"] == n and st["dropped_at_end"] == 0
+        for o in outs:
+            assert np.array_equal(o[:n * item], data)
+        assert st["in_bufsize"] >= 2 * (1 + h)
+        if n == 5000:
+            half_out = min(x // 2 for x in st["out_bufsize"])
+            assert max(st["call_sizes"]) == min(half_out, st["in_bufsize"] - 1 - (h - 1))
+    # the arithmetic behind it
+    assert b.gr37_buffer_items(8192, 1, -1, -1, [(1.0, 1, 1025)]) == 2052                    # cfg2 input behind H = 1024
+    assert b.gr37_plan_noutput(2051, [2047, 2047, 2047], [2048, 2048, 2048], 1, 1025) == 1024
+    assert b.gr37_plan_noutput(1025, [2047], [2048], 1, 1025) == 1                          # one real item: a call
+    assert b.gr37_plan_noutput(1024, [2047], [2048], 1, 1025) == 0                          # only look-back: blocked on input
+
+
 @pytest.mark.parametrize("item, nout, multiple, min_buffer, cap, want_sizes", [
     (24, 2, 64, 512, 0, {1536: 3, 384: 1}),          # half of the 3,072-item buffers, then what is left in multiples
     (24, 1, 1, -1, 0, {1536: 3, 392: 1}),
@@ -156,9 +180,11 @@ def test_stand_in_module_exposes_the_scheduling_surface():
         assert hasattr(b.baz_music_doa_sptr, name), name
     for name in ("output_multiple", "min_output_buffer", "work"):
         assert hasattr(b.baz_agc_cc_sptr, name), name
-    # what the AGC block's hints buy under the runtime's rules: 4,096-sample calls by default, 16,384 x k with them
+    # what the AGC block's hints buy under the runtime's rules: 4,096-sample calls without them, 16,384-sample calls with its
+    # 16,384 look-back samples and 32,768-sample output buffers -- and a 3-sample capture is still a call
     assert b.gr37_plan_noutput(8191, [8191, 16383], [8192, 16384], 1) == 4096
-    out = [b.gr37_buffer_items(8, 16384, 8 * 16384), b.gr37_buffer_items(4, 16384, 8 * 16384)]
-    assert out == [131072, 131072]
-    upstream = b.gr37_buffer_items(8, 1, -1, -1, [(1.0, 16384, 1)])
-    assert upstream == 32770 + (-32770) % 512 and b.gr37_plan_noutput(upstream - 1, [x - 1 for x in out], out, 16384) == 32768
+    out = [b.gr37_buffer_items(8, 1, 2 * 16384), b.gr37_buffer_items(4, 1, 2 * 16384)]
+    assert out == [32768, 32768]
+    upstream = b.gr37_buffer_items(8, 1, -1, -1, [(1.0, 1, 16385)])
+    assert upstream == 32772 + (-32772) % 512 and b.gr37_plan_noutput(upstream - 1, [x - 1 for x in out], out, 1, 16385) == 16384
+    assert b.gr37_plan_noutput(16384 + 3, [x - 1 for x in out], out, 1, 16385) == 3
