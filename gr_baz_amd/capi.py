@@ -27,7 +27,7 @@ SYMBOLS = [
     "baz_music_profile", "baz_music_stage_ms", "baz_music_stage_name", "baz_music_debug_cov",
     "baz_music_debug_evd", "baz_music_debug_q", "baz_music_q_stride", "baz_music_bytes_per_item", "baz_music_strerror",
     "baz_music_last_hip_error", "baz_music_version", "baz_music_device_count", "baz_music_device", "baz_music_set_peak_mode", "baz_music_refined_items",
-    "baz_music_refined_values", "baz_music_debug_coarse_margin",
+    "baz_music_refined_values", "baz_music_debug_coarse_margin", "baz_music_debug_coarse_fired",
     "baz_music_host_register", "baz_music_set_host_pinning", "baz_music_host_unregister_all", "baz_music_host_pinned_bytes",
 ]
 
@@ -105,6 +105,8 @@ def lib():
     L.baz_music_refined_items.argtypes = [_vp]
     L.baz_music_refined_values.restype = ctypes.c_int64
     L.baz_music_refined_values.argtypes = [_vp]
+    L.baz_music_debug_coarse_fired.restype = ctypes.c_int64
+    L.baz_music_debug_coarse_fired.argtypes = [_vp]
     L.baz_music_debug_coarse_margin.restype = ctypes.c_int
     L.baz_music_debug_coarse_margin.argtypes = [_vp, _vp, _u32, ctypes.POINTER(ctypes.c_float)]
     L.baz_music_set_peak_mode.restype = ctypes.c_int
@@ -213,6 +215,10 @@ class Context:
         return int(lib().baz_music_refined_values(self._h))
 
     refined_items = refined_values      # the round-1 name of the same statistic (kept for callers; the unit is values)
+
+    def debug_coarse_fired(self):
+        """Lab statistic (context created under BAZ_MUSIC_COARSE_STATS=1): exact tile evaluations since the last read."""
+        return int(lib().baz_music_debug_coarse_fired(self._h))
 
     def debug_coarse_margin(self, d_in, batch):
         """Worst observed |coarse - exact| / allowance of the coarse-gated scan over every (item, bin) of the batch

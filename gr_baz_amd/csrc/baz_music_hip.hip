@@ -103,12 +103,14 @@ struct baz_music_ctx {
     // coarse-gated scan (scan_coarse_kernels.hip.h): m <= 4, spectrum port not wired
     uint4* dCS = nullptr;          // per 16-bin tile: f16 hi/lo pieces of the scaled table (B32, B16) + the fp64 B operand (X)
     uint32_t cs_tiles = 0;         // tiles in the image (a multiple of 8)
-    CoarseParams cs = {0.0f, 0.0f, 0.0, 0.0};
+    CoarseParams cs = {0.0f, 0.0f, 0.0, 0.0, 1};
     bool cs_ok = false;            // image built and its scales representable
     uint32_t last_nsplit = 1;      // bin ranges per item the last scan launch produced candidates for (the merge folds them)
     int coarse = 1;                // BAZ_MUSIC_COARSE=0: the full fp64 scan also without the spectrum port (A/B, tests)
     int coarse_rg = 4;             // BAZ_MUSIC_COARSE_RG: row groups (x 16 items) per wave, 2 or 4 (lab)
-    unsigned int* dMargin = nullptr;   // baz_music_debug_coarse_margin: worst observed error / allowance (float bits)
+    int coarse_lab = 0;            // BAZ_MUSIC_COARSE_LAB=1: never run an exact tile (cost of the coarse passes alone; wrong results)
+    int coarse_stats = 0;          // BAZ_MUSIC_COARSE_STATS=1: count exact tile evaluations (baz_music_debug_coarse_fired)
+    unsigned long long* dMargin = nullptr;   // baz_music_debug_coarse_margin: worst error / allowance (float bits << 32 | where)
     int peak_mode = 0;      // 0: the reference's n strongest bins; 1 (opt-in extension): n strongest local maxima
     float* dPeakSpec = nullptr;   // internal spectrum when peak mode runs without the spectrum port
     size_t peak_spec_cap = 0;     // floats
@@ -260,10 +262,10 @@ float f16_value(uint16_t h)
     return (h & 0x8000u) ? -v : v;
 }
 
-// Table images of the coarse-gated scan (scan_coarse_kernel): the C array (1,536 B per 16-bin tile: B32, B16) followed by
-// the X array (2,048 B per tile):
-//   B32  lane (g, c), j < 8 : k = 8 g + j -> Fh[bin = 16 tile + c][e = k & 15]      (K = 32 B operand [Fh | Fh])
-//   B16  lane (g, c), j < 4 : Fl[bin][e = 4 g + j]                                  (K = 16 B operand)
+// Table images of the coarse-gated scan (scan_coarse_kernel): the C array (1,024 B per 16-bin tile) followed by the X
+// array (2,048 B per tile):
+//   C    Fh then Fl, each 32 entries x 8 f16: entry (gb, c), j < 8 -> piece[bin = 16 tile + c][e = 8 gb + j]
+//        (lane (g, c) of the K = 32 B operand [F | F] reads entry (g & 1, c))
 //   X    k-step pair p, lane (g, c), component s & 1: F[bin][e = 4 s + g], s = 2 p + (s & 1)   (fp64 B operand)
 // Fs = F * FS, Fh = f16(Fs), Fl = f16(Fs - Fh); bins outside the table: a huge diagonal (never selected), like build_FB.
 // Returns false when the table's scale cannot be represented (the full scan is used then).
@@ -290,34 +292,32 @@ bool build_coarse_image(const std::vector<double>& F, uint32_t m, uint32_t res, 
     img.assign((size_t)tiles * (cbytes + xbytes), 0);        // [C of every tile][X of every tile]
     for (uint32_t t = 0; t < tiles; ++t) {
         uint8_t* T = img.data() + (size_t)t * cbytes;
-        uint16_t* b32 = reinterpret_cast<uint16_t*>(T);
-        uint16_t* b16 = reinterpret_cast<uint16_t*>(T + 1024);
+        uint16_t* fh = reinterpret_cast<uint16_t*>(T);
+        uint16_t* fl = reinterpret_cast<uint16_t*>(T + 512);
         double* X = reinterpret_cast<double*>(img.data() + (size_t)tiles * cbytes + (size_t)t * xbytes);
-        for (uint32_t lane = 0; lane < 64; ++lane) {
-            const uint32_t g = lane >> 4, c = lane & 15, bin = 16 * t + c;
-            auto fval = [&](uint32_t e) -> double {
-                if (e >= mm) return 0.0;
-                if (bin < res) return F[(size_t)bin * mm + e];
-                return ((e / m) == (e % m)) ? 1e300 : 0.0;
-            };
-            auto pieces = [&](uint32_t e, uint16_t& hi, uint16_t& lo) {
-                if (e >= mm) { hi = lo = 0; return; }
-                if (bin >= res) { hi = ((e / m) == (e % m)) ? f16_bits(32768.0f) : 0; lo = 0; return; }
-                const float fs = (float)(F[(size_t)bin * mm + e] * FS);
-                hi = f16_bits(fs);
-                lo = f16_bits(fs - f16_value(hi));
-            };
-            for (uint32_t j = 0; j < 8; ++j) {
-                uint16_t hi, lo;
-                pieces((8 * g + j) & 15u, hi, lo);
-                b32[lane * 8 + j] = hi;
+        for (uint32_t c = 0; c < 16; ++c) {
+            const uint32_t bin = 16 * t + c;
+            for (uint32_t e = 0; e < 16; ++e) {
+                uint16_t hi = 0, lo = 0;
+                if (e < mm) {
+                    if (bin >= res) hi = ((e / m) == (e % m)) ? f16_bits(32768.0f) : 0;
+                    else {
+                        const float fs = (float)(F[(size_t)bin * mm + e] * FS);
+                        hi = f16_bits(fs);
+                        lo = f16_bits(fs - f16_value(hi));
+                    }
+                }
+                const uint32_t gb = e >> 3, j = e & 7u;
+                fh[(gb * 16 + c) * 8 + j] = hi;
+                fl[(gb * 16 + c) * 8 + j] = lo;
             }
-            for (uint32_t j = 0; j < 4; ++j) {
-                uint16_t hi, lo;
-                pieces(4 * g + j, hi, lo);
-                b16[lane * 4 + j] = lo;
-            }
-            for (uint32_t s = 0; s < 4; ++s) X[(s >> 1) * 128 + lane * 2 + (s & 1)] = fval(4 * s + g);
+            for (uint32_t g = 0; g < 4; ++g)
+                for (uint32_t sidx = 0; sidx < 4; ++sidx) {
+                    const uint32_t e = 4 * sidx + g, lane = g * 16 + c;
+                    double v = 0.0;
+                    if (e < mm) v = (bin < res) ? F[(size_t)bin * mm + e] : (((e / m) == (e % m)) ? 1e300 : 0.0);
+                    X[(sidx >> 1) * 128 + lane * 2 + (sidx & 1)] = v;
+                }
         }
     }
     return true;
@@ -568,12 +568,13 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             rf.below = c->refine_below;
             rf.count = c->dRefined + c->stat_parity;
             rf.A2 = nullptr;
-            if (CG.tpp == 4)
-                hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 2, 4>), dim3(CG.groups * CG.nsplit), dim3(256), 0, c->stream, dQ, c->dCS,
-                                   c->dCS + (size_t)c->cs_tiles * CS_C_UNITS, c->dCand, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, nullptr);
-            else
-                hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8>), dim3(CG.groups * CG.nsplit), dim3(256), 0, c->stream, dQ, c->dCS,
-                                   c->dCS + (size_t)c->cs_tiles * CS_C_UNITS, c->dCand, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, nullptr);
+            unsigned long long* stats = c->coarse_stats ? c->dMargin : nullptr;     // lab: exact tile evaluations, summed over launches
+#define BAZ_COARSE_ARGS dim3(CG.groups * CG.nsplit), dim3(256), 0, c->stream, dQ, c->dCS, c->dCS + (size_t)c->cs_tiles * CS_C_UNITS, \
+                        c->dCand, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, stats, nullptr
+            if (CG.tpp == 4) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 2, 4>), BAZ_COARSE_ARGS);
+            else if (c->coarse_lab == 1) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8, false, 1>), BAZ_COARSE_ARGS);
+            else hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8>), BAZ_COARSE_ARGS);
+#undef BAZ_COARSE_ARGS
             HIP_TRY(c, hipGetLastError());
             c->last_nsplit = CG.nsplit;
             return BAZ_MUSIC_OK;
@@ -890,6 +891,7 @@ int upload_table(baz_music_ctx* c, const float* table_ri)
     if (c->dCS) {    // coarse-gated scan: f16 pieces of the scaled table + the fp64 operand, per 16-bin tile
         std::vector<uint8_t> img;
         if (build_coarse_image(F, c->m, c->res, c->cs_tiles, img, c->cs)) {
+            if (const char* v = getenv("BAZ_MUSIC_COARSE_LAZY")) c->cs.lazy = atoi(v);            // lab
             HIP_TRY(c, hipMemcpy(c->dCS, img.data(), img.size(), hipMemcpyHostToDevice));
             c->cs_ok = true;
         }
@@ -1228,10 +1230,13 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (const char* v = getenv("BAZ_MUSIC_SIG_SCAN")) c->sig_scan = atoi(v);                  // lab / tests
         if (const char* v = getenv("BAZ_MUSIC_COARSE")) c->coarse = atoi(v);                      // A/B, tests
         if (const char* v = getenv("BAZ_MUSIC_COARSE_RG")) c->coarse_rg = atoi(v);                // lab
+        if (const char* v = getenv("BAZ_MUSIC_COARSE_LAB")) c->coarse_lab = atoi(v);              // lab
+        if (const char* v = getenv("BAZ_MUSIC_COARSE_STATS")) c->coarse_stats = atoi(v);          // lab
         if (m <= 4) {
             c->cs_tiles = round_up((resolution + 15) / 16, 8);
             if (hipMalloc((void**)&c->dCS, (size_t)c->cs_tiles * (CS_C_UNITS + CS_X_UNITS) * 16) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
-            if (hipMalloc((void**)&c->dMargin, sizeof(unsigned int)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+            if (hipMalloc((void**)&c->dMargin, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+            if (hipMemset(c->dMargin, 0, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         }
         if (short_form_applies(m, n) && hipMalloc((void**)&c->dA2p, (size_t)(c->fb_steps + 2) * 64 * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         {
@@ -1648,25 +1653,52 @@ int baz_music_debug_coarse_margin(baz_music_ctx* c, const void* d_in, uint32_t b
         if (!r) r = launch_evd(c, c->dR, batch, c->dQ, qstride, c->dG);
     }
     if (r) return r;
-    HIP_TRY(c, hipMemsetAsync(c->dMargin, 0, sizeof(unsigned int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dMargin, 0, sizeof(unsigned long long), c->stream));
     ScanRefine rf;
     rf.Gs = nullptr; rf.TB = c->dTB + c->tb_step_elems; rf.below = 0.0; rf.count = nullptr; rf.A2 = nullptr;
     const uint32_t groups = (batch + 255) / 256, nph = c->cs_tiles / 8;
+    float* d_dump = nullptr;                     // lab (BAZ_MUSIC_DEBUG_DUMP=<file>): every ratio, [item][bin] float32
+    const char* dump_path = getenv("BAZ_MUSIC_DEBUG_DUMP");
+    if (dump_path && hipMalloc((void**)&d_dump, (size_t)batch * c->res * sizeof(float)) != hipSuccess) d_dump = nullptr;
+    if (d_dump) (void)hipMemsetAsync(d_dump, 0, (size_t)batch * c->res * sizeof(float), c->stream);
 #define BAZ_VAL(MV, NV)                                                                                                     \
     hipLaunchKernelGGL((scan_coarse_kernel<MV, NV, 4, 8, true>), dim3(groups), dim3(256), 0, c->stream, c->dQ, c->dCS, \
                        c->dCS + (size_t)c->cs_tiles * CS_C_UNITS, c->dCand,                                                       \
-                       batch, c->res, qstride, nph, 1u, c->keep_mask, c->n, rf, c->cs, c->dMargin)
+                       batch, c->res, qstride, nph, 1u, c->keep_mask, c->n, rf, c->cs, c->dMargin, d_dump)
     const bool n2 = c->n <= 2;
     if (c->m == 2) { BAZ_VAL(2, 2); }
     else if (c->m == 3) { if (n2) BAZ_VAL(3, 2); else BAZ_VAL(3, 4); }
     else { if (n2) BAZ_VAL(4, 2); else BAZ_VAL(4, 4); }
 #undef BAZ_VAL
     HIP_TRY(c, hipGetLastError());
-    unsigned int bits = 0;
-    HIP_TRY(c, hipMemcpyAsync(&bits, c->dMargin, sizeof(bits), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long packed = 0;
+    HIP_TRY(c, hipMemcpyAsync(&packed, c->dMargin, sizeof(packed), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (d_dump) {
+        std::vector<float> h((size_t)batch * c->res);
+        if (hipMemcpy(h.data(), d_dump, h.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE* f = fopen(dump_path, "wb")) { fwrite(h.data(), sizeof(float), h.size(), f); fclose(f); }
+        (void)hipFree(d_dump);
+    }
+    const unsigned int bits = (unsigned int)(packed >> 32);
     std::memcpy(worst, &bits, sizeof(float));
+    if (getenv("BAZ_MUSIC_DEBUG_MARGIN"))   // lab: where the worst value sits
+        fprintf(stderr, "[baz_music] coarse margin %.4g at bin %u, item %% 4096 = %u\n", *worst, (unsigned)(packed & 0xFFFFFu),
+                (unsigned)((packed >> 20) & 0xFFFu));
     return BAZ_MUSIC_OK;
+}
+
+// lab statistic (BAZ_MUSIC_COARSE_STATS=1 at create): exact (16-item row group, 16-bin tile) evaluations of all coarse-gated
+// scan launches since the last read; resets the counter.  -1 when the statistic is off.
+int64_t baz_music_debug_coarse_fired(baz_music_ctx* c)
+{
+    if (!c || !c->coarse_stats || !c->dMargin) return -1;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    DeviceGuard guard(c->device);
+    unsigned long long v = 0;
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&v, c->dMargin, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemset(c->dMargin, 0, sizeof(v)) != hipSuccess) return -1;
+    return (int64_t)v;
 }
 
 int baz_music_debug_evd(baz_music_ctx* c, const void* d_R, uint32_t batch, void* d_Q)

@@ -400,6 +400,24 @@ double baz_resamp_ratio(const baz_resamp_ctx* c) { return c ? (double)from_fixed
 int baz_resamp_phase_exact(const baz_resamp_ctx* c) { return c && c->exact ? 1 : 0; }
 const float* baz_resamp_taps(const baz_resamp_ctx* c) { return c ? c->taps : nullptr; }
 
+void baz_resamp_default_taps(float* out)
+{
+    if (out) build_taps(out);
+}
+
+int baz_resamp_set_taps(baz_resamp_ctx* c, const float* taps)
+{
+    if (!c || !taps) return BAZ_RESAMP_E_INVALID;
+    for (int i = 0; i < (RS_NSTEPS + 1) * RS_NTAPS; ++i)
+        if (!std::isfinite(taps[i])) return BAZ_RESAMP_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    DeviceGuard guard(c->device);
+    RS_TRY(hipStreamSynchronize(c->stream));        // no launch in flight reads the old table
+    std::memcpy(c->taps, taps, sizeof(c->taps));
+    RS_TRY(hipMemcpy(c->d_taps, c->taps, sizeof(c->taps), hipMemcpyHostToDevice));
+    return BAZ_RESAMP_OK;
+}
+
 int baz_resamp_set_stream(baz_resamp_ctx* c, void* hip_stream)
 {
     if (!c) return BAZ_RESAMP_E_INVALID;

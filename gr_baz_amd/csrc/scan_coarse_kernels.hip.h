@@ -15,15 +15,21 @@
 // Coarse form.  d = sum_e q_e F_e over the MM = m^2 <= 16 real terms of the Hermitian form (music_kernels.hip.h 4.).
 // Both operands are split into two f16 pieces of scaled values,
 //     qs = q 2^10 = qh + ql + rq,      Fs = F FS = Fh + Fl + rF,     FS = the power of two with max|Fs| in [2^13, 2^14)
-// and  c = sum_e (qh + ql) Fh + qh Fl  is ONE K = 32 and ONE K = 16 f16 MFMA with f32 accumulation
-// (A = [qh | ql], B = [Fh | Fh];  A = qh, B = Fl).  f16 x f16 products are exact in f32.  Error budget, in units of
-// d (divide by SC = 2^10 FS), with S = max|F| sum_e |q_e|:
-//     representation   |rq| <= 2^-22 |qs| + 2^-14 (the second term covers a flushed subnormal ql),  same for rF,
-//                      dropped ql Fl <= 2^-22 |qs Fs|                                     ->  <= 1.75 2^-20 S
-//     accumulation     <= 50 additions, each <= 2^-23 (truncation) of a partial sum <= S + thr   ->  <= 2^-17.3 (S + thr)
-// so |c / SC - d| <= E := 2^-16 (S + D) with a factor > 2 to spare (D = the threshold d is compared with).  The bound
+// and  c = sum_e (qh + ql) (Fh + Fl)  is TWO K = 32 f16 MFMAs with f32 accumulation on the same A operand:
+// A = [qh | ql], B = [Fh | Fh], then B = [Fl | Fl].  f16 x f16 products are exact in f32.  Error budget, in units of d
+// (divide by SC = 2^10 FS), with S = max|F| sum_e |q_e|:
+//     representation   |rq| <= 2^-22 |qs| + 2^-14 (the second term covers a flushed subnormal ql),  same for rF
+//                                                                                          ->  <= 1.5 2^-20 S
+//     accumulation     <= 66 additions, each <= 2^-23 (truncation) of a partial sum <= S + thr   ->  <= 2^-17 (S + thr)
+// so |c / SC - d| <= E := 2^-16 (S + D) with a factor ~2 to spare (D = the threshold d is compared with).  The bound
 // is checked on hardware over every (item, bin) of random batches by the VAL instantiation
-// (baz_music_debug_coarse_margin: worst observed |c/SC - d| / E).
+// (baz_music_debug_coarse_margin: worst observed |c/SC - d| / E; measured 0.007-0.009: the matrix core accumulates far
+// more accurately than the worst case assumed).
+// (A first version formed the third product with the legacy v_mfma_f32_16x16x16_f16.  Wherever hipcc -- ROCm 7.2,
+// -amdgpu-mfma-vgpr-form -- gave that instruction a destination different from its C operand, registers 0 and 1 of its
+// result were wrong on MI355X, with 2 wait states or with three other MFMAs in between; the K = 32 form has shown no
+// such behaviour in either role.  tests/lab/coarse_dump.py, tests/lab/coarse_diff.py; the K = 32 pair is also faster:
+// scripts/ubench_f16mfma.hip, 13.8 against 17.0 clocks per instruction at 2 waves per SIMD.)
 //
 // Gate.  A lane's list of item i holds n keys; its last entry K_n bounds the item's final n-th smallest key from
 // above, and so does any other lane's.  A bin can enter the final list only if |d| <= D := (K_n | low bits), so only
@@ -37,8 +43,9 @@
 // coarse A operand therefore carries item pi(i) = (i >> 2) + 4 (i & 3) in row i: register r of lane (g, c) is item
 // g + 4 r and bin 16 tile + c in BOTH forms.  A wave owns RG row groups of 16 items and walks the bin tiles of its
 // range; the 4 waves of a workgroup share the table images through a double-buffered LDS stage of TPP tiles.
-// Table images, per tile: C (1,536 B) = [B32: 64 lanes x 8 f16][B16: 64 lanes x 4 f16];  X (2,048 B) = k-steps (0,1) as
-// 64 x double2, then (2,3).  Two arrays, because the first pass stages C only.
+// Table images, per tile: C (1,024 B) = Fh then Fl, each 32 x 8 f16: entry (gb, c), j = piece[bin 16 tile + c][e = 8 gb + j]
+// (lane (g, c) reads entry (g & 1, c): the K = 32 B operand [F | F] holds every piece twice);  X (2,048 B) = the fp64
+// operand, k-steps (0,1) as 64 x double2, then (2,3).  Two arrays, because the first pass stages C only.
 #pragma once
 
 #include "music_kernels.hip.h"
@@ -48,7 +55,7 @@ namespace bazmusic {
 typedef _Float16 v4f16 __attribute__((ext_vector_type(4)));
 typedef _Float16 v8f16 __attribute__((ext_vector_type(8)));
 
-constexpr int CS_C_UNITS = 96;            // 16-B units of a tile's coarse operands: 1024 B (B32) + 512 B (B16)
+constexpr int CS_C_UNITS = 64;            // 16-B units of a tile's coarse operands: 512 B (Fh) + 512 B (Fl)
 constexpr int CS_X_UNITS = 128;           // ... of its fp64 operand: 2048 B
 
 struct CoarseParams {
@@ -56,6 +63,7 @@ struct CoarseParams {
     float es_factor;    // 2^-16 max|F| SC, rounded up: es = es_factor * sum_e |q_e|
     double sc;          // SC = 2^10 FS (VAL only)
     double fmax;        // max|F| (VAL only)
+    int lazy;           // lab: 0 = recompute and share the thresholds after every exact tile
 };
 
 template <int CTRL>
@@ -103,19 +111,14 @@ __device__ __noinline__ v4f64 literal16(const double* __restrict__ Gs, const dou
     return d;
 }
 
-// raw v_min3_f32 / v_min_f32: no canonicalisation pass over MFMA results; a NaN operand is ignored (minNum)
-__device__ __forceinline__ float vmin3_f32(float a, float b, float c)
-{
-    float r;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float vmin_f32(float a, float b)
-{
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+// Ordering f32 values through their bit patterns as signed integers (v_min_i32 / v_min3_i32, no canonicalisation pass
+// over MFMA results, and -- unlike an inline-asm v_min_f32 -- instructions the compiler pads against the MFMA's result
+// hazard, cdna_hip_programming.md 5.7).  For non-NaN floats: bits <= 0 <=> value <= +0, and a negative value's bits are
+// below every non-negative value's.  Among two negatives the order is reversed (the one closer to zero wins a min):
+// where that matters here the result is only ever used as an UPPER bound.  +NaN patterns are large positive (never win
+// a min, never pass "<= 0"); -NaN patterns pass "<= 0", which only means an extra exact tile.
+__device__ __forceinline__ int fbits(float v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 
 // An upper bound of the k-th smallest of the 16 values a DPP row holds (one per lane), in every lane of the row: k - 1
 // times drop the row minimum (all lanes that tie with it: the bound can only get looser), then take the minimum.
@@ -129,6 +132,23 @@ __device__ __forceinline__ float row_kth_smallest(float v, const uint32_t k)
     return mk;
 }
 
+// The coarse form of one bin tile for the RG row groups of a wave: u[q] = [qh | ql] [Fh | Fh] + [qh | ql] [Fl | Fl] (+ cin[q]).
+// All first instructions are issued before the second ones (each dependent pair is separated by full MFMAs whatever the
+// register assignment), and the B operands stay allocated until the group is through, so that no destination can be
+// given their registers.
+template <int RG>
+__device__ __forceinline__ void coarse_tile(v4f32 (&u)[RG], const v8f16 (&a32)[RG], const v8f16 bh, const v8f16 bl, const v4f32* cin)
+{
+#pragma unroll
+    for (int q = 0; q < RG; ++q)
+        u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[q], bh, cin ? cin[q] : (v4f32){0, 0, 0, 0}, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < RG; ++q) u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[q], bl, u[q], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::"v"(bh), "v"(bl));
+}
+
 // VAL: validation build (baz_music_debug_coarse_margin): every tile runs both forms, nothing is gated, no lists are kept,
 // and the worst |c / SC - d| / (2^-16 (S + |d|)) over all (item, bin) is left in *margin (float bits, atomicMax).
 //
@@ -138,7 +158,7 @@ __device__ __forceinline__ float row_kth_smallest(float v, const uint32_t k)
 // single exact tile has run.  Without it the thresholds only tighten as the walk happens to pass the minima: on a
 // descending slope of the spectrum EVERY tile beats the list and fires (measured: 0.28 ms per 262,144 coherent cfg2 items,
 // and 0.93 ms -- slower than the full scan -- when every item of a wave has its own scene).  PASS 2: the gated walk.
-template <int M, int NMAX, int RG, int TPP, bool VAL = false>
+template <int M, int NMAX, int RG, int TPP, bool VAL = false, int LAB = 0>
 __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(const double* __restrict__ Qs,
                                                                              const uint4* __restrict__ imgC,
                                                                              const uint4* __restrict__ imgX,
@@ -146,7 +166,8 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
                                                                              uint32_t res, uint32_t qstride, uint32_t nphases,
                                                                              uint32_t nsplit, uint32_t keep_mask, uint32_t n,
                                                                              ScanRefine rf, CoarseParams cp,
-                                                                             unsigned int* __restrict__ margin)
+                                                                             unsigned long long* __restrict__ margin,
+                                                                             float* __restrict__ val_dump = nullptr)
 {
     constexpr int MM = M * M;
     static_assert(MM <= 16, "one K = 16 slab: m <= 4");
@@ -166,7 +187,6 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
     // ---- operands -------------------------------------------------------------------------------------------------
     double qa[RG][4];          // exact A: q[item of row c][e = 4 s + g]   (natural row order)
     v8f16 a32[RG];             // coarse A, K = 32: row c = item pi(c); k = 8 g + j: e = k & 15, piece = k >> 4 (hi | lo)
-    v4f16 a16[RG];             // coarse A, K = 16: k = 4 g + j: e = k, hi piece
     v4f32 es[RG], negthr[RG];  // per accumulator register r (item g + 4 r): error allowance and -threshold, coarse units
     double key[VAL ? 1 : RG][4][NMAX];
     bool row_ok[RG][4];
@@ -200,12 +220,6 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
             const _Float16 l = (_Float16)(v - (float)h);      // exact difference (11-bit piece of a 24-bit value)
             a32[q][j] = (g < 2) ? h : l;                      // k < 16: hi, k >= 16: lo
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int e = 4 * g + j;
-            const double qv = (e < MM) ? Qs[(size_t)e * qstride + itp] : 0.0;
-            a16[q][j] = sane ? (_Float16)(float)(qv * 1024.0) : (_Float16)0.0f;
-        }
         // allowance of item g + 4 r = permuted row 4 g + r: held by the lanes with c = 4 g + r
         const float es_row = sane ? asum * cp.es_factor * 1.0001f : __builtin_inff();
 #pragma unroll
@@ -228,7 +242,9 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
     const float below_s = refine_on ? (float)(rf.below * cp.sc) * 1.000001f : 0.0f;      // in coarse units, rounded up
     const uint32_t nobin = ~keep_mask;
     [[maybe_unused]] float worst = 0.0f;
+    [[maybe_unused]] uint32_t worst_at = 0;       // VAL: bin | (item & 0xFFF) << 20 of the worst value (diagnostics)
     uint32_t refined = 0;
+    [[maybe_unused]] uint32_t fired = 0;          // exact (row group, tile) evaluations of this wave (lab statistic)
 
     // ---- table staging: L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no registers) ----------
     auto stage_load = [&](uint32_t ph, int b, const bool with_x) {
@@ -255,26 +271,33 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
     int buf = 0;
     // ---- pass 1: thresholds from the coarse form alone -----------------------------------------------------------------
     if constexpr (!VAL) {
-        v4f32 pm[RG];
+        int pm[RG][4];              // running minimum of the coarse values, as bit patterns (see fbits)
 #pragma unroll
-        for (int q = 0; q < RG; ++q) pm[q] = (v4f32){__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+        for (int q = 0; q < RG; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pm[q][r] = 0x7F800000;    // +inf
         if (ph_begin < ph_end) stage_load(ph_begin, 0, false);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (uint32_t ph = ph_begin; ph < ph_end; ++ph) {
             if (ph + 1 < ph_end) stage_load(ph + 1, buf ^ 1, false);
+            // the NEXT tile's operands are read before this tile's MFMAs issue (a wave's ds_read latency otherwise sits
+            // between every two tiles: with 2 waves per SIMD there is nobody else to cover it)
+            const char* __restrict__ T0 = reinterpret_cast<const char*>(&stage[buf][0]) + ((g & 1) * 16 + c) * 16;
+            v8f16 nbh = *reinterpret_cast<const v8f16*>(T0);
+            v8f16 nbl = *reinterpret_cast<const v8f16*>(T0 + 512);
 #pragma nounroll
             for (int tl = 0; tl < TPP; ++tl) {
-                const char* __restrict__ T = reinterpret_cast<const char*>(&stage[buf][0]) + tl * (CS_C_UNITS * 16);
-                const v8f16 b32 = *reinterpret_cast<const v8f16*>(T + lane * 16);
-                const v4f16 b16 = *reinterpret_cast<const v4f16*>(T + 1024 + lane * 8);
+                const v8f16 bh = nbh, bl = nbl;
+                const char* __restrict__ Tn = T0 + ((tl + 1 < TPP) ? tl + 1 : tl) * (CS_C_UNITS * 16);
+                nbh = *reinterpret_cast<const v8f16*>(Tn);
+                nbl = *reinterpret_cast<const v8f16*>(Tn + 512);
+                v4f32 u[RG];
+                coarse_tile<RG>(u, a32, bh, bl, nullptr);
 #pragma unroll
-                for (int q = 0; q < RG; ++q) {
-                    v4f32 u = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[q], b32, (v4f32){0, 0, 0, 0}, 0, 0, 0);
-                    u = __builtin_amdgcn_mfma_f32_16x16x16f16(a16[q], b16, u, 0, 0, 0);
+                for (int q = 0; q < RG; ++q)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pm[q][r] = vmin_f32(pm[q][r], u[r]);
-                }
+                    for (int r = 0; r < 4; ++r) pm[q][r] = imin(pm[q][r], fbits(u[q][r]));
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -285,7 +308,7 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
         for (int q = 0; q < RG; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float cn = row_kth_smallest(pm[q][r], n);
+                const float cn = row_kth_smallest(__builtin_bit_cast(float, pm[q][r]), n);
                 const float Dd = fmaxf(fmaxf(cn + es[q][r], 0.0f) * 1.0000306f, below_s);
                 negthr[q][r] = -__builtin_fmaf(Dd, 1.0000164f, es[q][r]);
             }
@@ -297,32 +320,36 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
     __syncthreads();
     for (uint32_t ph = ph_begin; ph < ph_end; ++ph) {
         if (ph + 1 < ph_end) stage_load(ph + 1, buf ^ 1, true);     // lands while this phase's tiles run
+        const char* __restrict__ T0 = reinterpret_cast<const char*>(&stage[buf][0]) + ((g & 1) * 16 + c) * 16;
+        v8f16 nbh = *reinterpret_cast<const v8f16*>(T0);
+        v8f16 nbl = *reinterpret_cast<const v8f16*>(T0 + 512);
 #pragma nounroll
         for (int tl = 0; tl < TPP; ++tl) {
-            const char* __restrict__ T = reinterpret_cast<const char*>(&stage[buf][0]) + tl * (CS_C_UNITS * 16);
-            const v8f16 b32 = *reinterpret_cast<const v8f16*>(T + lane * 16);
-            const v4f16 b16 = *reinterpret_cast<const v4f16*>(T + 1024 + lane * 8);
+            const v8f16 bh = nbh, bl = nbl;
+            const char* __restrict__ Tn = T0 + ((tl + 1 < TPP) ? tl + 1 : tl) * (CS_C_UNITS * 16);
+            nbh = *reinterpret_cast<const v8f16*>(Tn);                     // next tile's operands: see pass 1
+            nbl = *reinterpret_cast<const v8f16*>(Tn + 512);
             v4f32 u[RG];
-            float mn[RG];
+            int mn[RG];
+            coarse_tile<RG>(u, a32, bh, bl, VAL ? nullptr : negthr);
+            int mall = 0x7F800000;
 #pragma unroll
             for (int q = 0; q < RG; ++q) {
-                const v4f32 cin = VAL ? (v4f32){0, 0, 0, 0} : negthr[q];
-                u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[q], b32, cin, 0, 0, 0);
-                u[q] = __builtin_amdgcn_mfma_f32_16x16x16f16(a16[q], b16, u[q], 0, 0, 0);
+                mn[q] = imin(imin(fbits(u[q][0]), fbits(u[q][1])), imin(fbits(u[q][2]), fbits(u[q][3])));
+                mall = imin(mall, mn[q]);
             }
-            float mall = __builtin_inff();
-#pragma unroll
-            for (int q = 0; q < RG; ++q) {
-                mn[q] = vmin_f32(vmin3_f32(u[q][0], u[q][1], u[q][2]), u[q][3]);
-                mall = vmin_f32(mall, mn[q]);
+            if constexpr (LAB == 1) {                         // lab: the cost of the two coarse passes alone (results are wrong):
+                fired += (mall <= 0) ? 1u : 0u;               // the votes are counted, so nothing above is dead code
+                continue;
             }
-            if (!VAL && !__any(mall <= 0.0f)) continue;       // no group of this wave can gain from this tile
+            if (!VAL && !__any(mall <= 0)) continue;          // some c - thr <= 0?  no group of this wave can gain from this tile
             const uint32_t bin = (ph * TPP + (uint32_t)tl) * 16u + (uint32_t)c;
             const double* __restrict__ X = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&stage[buf][C_UNITS]) +
                                                                             tl * (CS_X_UNITS * 16));
 #pragma unroll
             for (int q = 0; q < RG; ++q) {
-                if (!VAL && !__any(mn[q] <= 0.0f)) continue;
+                if (!VAL && !__any(mn[q] <= 0)) continue;
+                if constexpr (!VAL) ++fired;
                 // exact form: scan_mfma_kernel's projector GEMM for this 16 x 16 tile (same k order, same operands)
                 const v2f64 x01 = *reinterpret_cast<const v2f64*>(X + lane * 2);
                 const v2f64 x23 = *reinterpret_cast<const v2f64*>(X + 128 + lane * 2);
@@ -339,7 +366,13 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
                         const double err = fabs((double)u[q][r] / cp.sc - acc[r]);
                         const double allow = 0x1p-16 * (S + fabs(acc[r]));
                         const bool counts = bin < res && row_ok[q][r] && S < 1e30 && allow > 0.0 && err == err;
-                        worst = fmaxf(worst, counts ? (float)(err / allow) : 0.0f);
+                        const float ratio = counts ? (float)(err / allow) : 0.0f;
+                        if (val_dump && bin < res && row_ok[q][r])       // lab: every ratio, [item][bin]
+                            val_dump[(size_t)(item0 + 16 * q + (uint32_t)(g + 4 * r)) * res + bin] = ratio;
+                        if (ratio > worst) {
+                            worst = ratio;
+                            worst_at = bin | (((item0 + 16 * q + (uint32_t)(g + 4 * r)) & 0xFFFu) << 20);
+                        }
                     }
                 } else {
                     bool low = false;
@@ -358,15 +391,21 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
                     const uint32_t kbin = (bin < res) ? bin : nobin;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        double ko = key[q][r][0];                   // the list's n-th entry (the lists hold NMAX >= n) ...
+#pragma unroll
+                        for (int i = 1; i < NMAX; ++i) ko = ((uint32_t)i < n) ? key[q][r][i] : ko;
                         key_insert_new<NMAX>(key[q][r], make_key(acc[r], kbin, keep_mask));
-                        double kn = key[q][r][0];                   // the list's n-th entry (the lists hold NMAX >= n)
+                        double kn = key[q][r][0];                   // ... before and after this tile's value
 #pragma unroll
                         for (int i = 1; i < NMAX; ++i) kn = ((uint32_t)i < n) ? key[q][r][i] : kn;
-                        const uint64_t kb = __builtin_bit_cast(uint64_t, kn) | (uint64_t)(~keep_mask);
-                        const double D = fmax(__builtin_bit_cast(double, kb), below_d);
-                        // (float) rounds to nearest: sc_up carries the factor that makes the product an upper bound
-                        const float thr = row_allmin(__builtin_fmaf((float)D, cp.sc_up, es[q][r]));
-                        negthr[q][r] = fmaxf(negthr[q][r], -thr);   // thresholds only ever tighten
+                        // the threshold moves only when some lane's n-th entry did: usually one item of the 16 drew the tile
+                        if (!cp.lazy || __any(__builtin_bit_cast(uint64_t, kn) != __builtin_bit_cast(uint64_t, ko))) {
+                            const uint64_t kb = __builtin_bit_cast(uint64_t, kn) | (uint64_t)(~keep_mask);
+                            const double D = fmax(__builtin_bit_cast(double, kb), below_d);
+                            // (float) rounds to nearest: sc_up carries the factor that makes the product an upper bound
+                            const float thr = row_allmin(__builtin_fmaf((float)D, cp.sc_up, es[q][r]));
+                            negthr[q][r] = fmaxf(negthr[q][r], -thr);   // thresholds only ever tighten
+                        }
                     }
                 }
             }
@@ -377,9 +416,13 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
     }
 
     if constexpr (VAL) {
+        unsigned long long packed = ((unsigned long long)__builtin_bit_cast(unsigned int, worst) << 32) | worst_at;
 #pragma unroll
-        for (int msk = 1; msk < 64; msk <<= 1) worst = fmaxf(worst, __shfl_xor(worst, msk, 64));
-        if (lane == 0 && margin) atomicMax(margin, __builtin_bit_cast(unsigned int, worst));
+        for (int msk = 1; msk < 64; msk <<= 1) {
+            const unsigned long long o = __shfl_xor(packed, msk, 64);
+            packed = o > packed ? o : packed;
+        }
+        if (lane == 0 && margin) atomicMax(margin, packed);      // ratio >= 0: its bit pattern orders like the value
         return;
     } else {
         if (rf.count) {
@@ -387,6 +430,7 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
             for (int msk = 1; msk < 64; msk <<= 1) refined += __shfl_xor(refined, msk, 64);
             if (lane == 0 && refined) atomicAdd(rf.count, (unsigned long long)refined);
         }
+        if (margin && lane == 0) atomicAdd(margin, (unsigned long long)fired);      // lab (BAZ_MUSIC_COARSE_STATS)
         // merge the 16 lanes of an item row, emit this range's candidates (topn_merge_kernel folds the ranges)
 #pragma unroll
         for (int q = 0; q < RG; ++q)

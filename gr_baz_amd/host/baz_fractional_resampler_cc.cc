@@ -6,14 +6,36 @@
 #include <baz_fractional_resampler_cc.h>
 #include <baz_resamp_hip.h>
 
+#include <gnuradio/filter/mmse_fir_interpolator_cc.h>
 #include <gnuradio/io_signature.h>
 
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace gr {
 namespace baz {
+
+/* The tap table of the gnuradio-filter this block is compiled against, read out of the very class the reference
+ * computes its samples with (.cc:87 constructs it, .cc:172,203 call interpolate()): phase imu is selected with
+ * mu = imu / nsteps (exact in float), a unit impulse at input[k] returns taps[imu][ntaps - 1 - k] exactly (the other
+ * seven products are 0 * tap = 0, the sums add zeros).  Returns an empty vector when the library's geometry is not the
+ * 8 x 128 the engine is built for (then the engine keeps its closed-form table). */
+std::vector<float> recover_mmse_taps()
+{
+    gr::filter::mmse_fir_interpolator_cc interp;
+    const unsigned ntaps = interp.ntaps(), nsteps = interp.nsteps();
+    if (ntaps != (unsigned)BAZ_RESAMP_NTAPS || nsteps != (unsigned)BAZ_RESAMP_NSTEPS) return std::vector<float>();
+    std::vector<float> taps((size_t)(nsteps + 1) * ntaps);
+    std::vector<gr_complex> impulse(ntaps);
+    for (unsigned imu = 0; imu <= nsteps; ++imu)
+        for (unsigned k = 0; k < ntaps; ++k) {
+            for (unsigned j = 0; j < ntaps; ++j) impulse[j] = gr_complex(j == k ? 1.0f : 0.0f, 0.0f);
+            taps[(size_t)imu * ntaps + (ntaps - 1 - k)] = interp.interpolate(impulse.data(), (float)imu / (float)nsteps).real();
+        }
+    return taps;
+}
 
 class fractional_resampler_cc_impl : public fractional_resampler_cc
 {
@@ -31,6 +53,10 @@ public:
         if (rc != BAZ_RESAMP_OK)
             throw std::runtime_error(std::string("fractional_resampler_cc: cannot open the gfx950 engine: ") +
                                      baz_resamp_strerror(rc));
+        /* interpolate with the table of the gnuradio-filter on this host (the stand-in's table is the engine's own) */
+        const std::vector<float> taps = recover_mmse_taps();
+        if (!taps.empty() && baz_resamp_set_taps(d_ctx, taps.data()) != BAZ_RESAMP_OK)
+            fprintf(stderr, "[fractional_resampler_cc] the host's MMSE tap table was rejected; using the closed-form table\n");
         set_relative_rate(1.0 / baz_resamp_ratio(d_ctx));   /* .cc:99 */
 
         message_port_register_in(pmt::mp("msg"));           /* .cc:101-102 */

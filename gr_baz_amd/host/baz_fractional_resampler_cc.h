@@ -12,6 +12,8 @@
 #include <gnuradio/block.h>
 #include <pmt/pmt.h>
 
+#include <vector>
+
 #ifndef BAZ_API
 #define BAZ_API
 #endif
@@ -38,6 +40,10 @@ public:
     virtual void handle_adjust(double d) = 0;
     virtual void handle_msg(pmt::pmt_t msg) = 0;
 };
+
+/* The 129 x 8 tap table of the gnuradio-filter this build sees, recovered through
+ * gr::filter::mmse_fir_interpolator_cc::interpolate (empty if its geometry is not 8 taps x 128 steps). */
+BAZ_API std::vector<float> recover_mmse_taps();
 
 }  // namespace baz
 }  // namespace gr

@@ -302,6 +302,12 @@ PYBIND11_MODULE(_baz_music, mod)
         .def("post_msg_double", [](resamp_handle& h, double d) { h.blk->shim_post(pmt::mp("msg"), pmt::from_double(d)); })
         .def("post_msg_symbol", [](resamp_handle& h, const std::string& s) { h.blk->shim_post(pmt::mp("msg"), pmt::mp(s)); });
     // swig/baz_swig.i:964-966: GR_SWIG_BLOCK_MAGIC2(baz, fractional_resampler_cc) -> baz.fractional_resampler_cc(...)
+    mod.def("recover_mmse_taps", []() {
+                const std::vector<float> t = gr::baz::recover_mmse_taps();
+                py::array_t<float> a({(size_t)(t.size() / 8), (size_t)8});
+                std::memcpy(a.mutable_data(), t.data(), t.size() * sizeof(float));
+                return a;
+            }, "the tap table of the gnuradio-filter this build sees, read out through mmse_fir_interpolator_cc::interpolate");
     mod.def("fractional_resampler_cc",
             [](double phase_shift, double resamp_ratio, unsigned long long num, unsigned long long denom) {
                 resamp_handle h;

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libbaz_resamp_hip.so")
 SYMBOLS = ["baz_resamp_create", "baz_resamp_destroy", "baz_resamp_forecast", "baz_resamp_process",
            "baz_resamp_process_device", "baz_resamp_process2", "baz_resamp_process2_device", "baz_resamp_set_mu", "baz_resamp_set_ratio", "baz_resamp_set_ratio_rational",
            "baz_resamp_set_ratio_ppb", "baz_resamp_adjust", "baz_resamp_mu", "baz_resamp_ratio",
-           "baz_resamp_phase_exact", "baz_resamp_taps", "baz_resamp_set_stream", "baz_resamp_sync",
+           "baz_resamp_phase_exact", "baz_resamp_taps", "baz_resamp_default_taps", "baz_resamp_set_taps", "baz_resamp_set_stream", "baz_resamp_sync",
            "baz_resamp_strerror"]
 NTAPS, NSTEPS = 8, 128
 
@@ -66,6 +66,10 @@ def lib():
     L.baz_resamp_phase_exact.argtypes = [_vp]
     L.baz_resamp_taps.restype = _f32p
     L.baz_resamp_taps.argtypes = [_vp]
+    L.baz_resamp_default_taps.restype = None
+    L.baz_resamp_default_taps.argtypes = [_f32p]
+    L.baz_resamp_set_taps.restype = ctypes.c_int
+    L.baz_resamp_set_taps.argtypes = [_vp, _f32p]
     L.baz_resamp_set_stream.restype = ctypes.c_int
     L.baz_resamp_set_stream.argtypes = [_vp, _vp]
     L.baz_resamp_sync.restype = ctypes.c_int
@@ -160,5 +164,17 @@ class Resampler:
     def resamp_ratio(self): return lib().baz_resamp_ratio(self._h)
     def phase_exact(self): return bool(lib().baz_resamp_phase_exact(self._h))
     def taps(self): return np.ctypeslib.as_array(lib().baz_resamp_taps(self._h), shape=(NSTEPS + 1, NTAPS)).copy()
+
+    def set_taps(self, taps):
+        """Installs a 129 x 8 tap table (the host's gnuradio-filter table, see include/baz_resamp_hip.h)."""
+        t = np.ascontiguousarray(np.asarray(taps, dtype=np.float32).reshape(NSTEPS + 1, NTAPS))
+        self._chk(lib().baz_resamp_set_taps(self._h, t.ctypes.data_as(_f32p)), "baz_resamp_set_taps")
     def set_stream(self, s): self._chk(lib().baz_resamp_set_stream(self._h, _vp(s) if s else None), "baz_resamp_set_stream")
     def sync(self): self._chk(lib().baz_resamp_sync(self._h), "baz_resamp_sync")
+
+
+def default_taps():
+    """The closed-form MMSE table a fresh context starts with (host arithmetic, no device needed)."""
+    t = np.zeros((NSTEPS + 1, NTAPS), np.float32)
+    lib().baz_resamp_default_taps(t.ctypes.data_as(_f32p))
+    return t

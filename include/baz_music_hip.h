@@ -142,6 +142,9 @@ BAZ_MUSIC_API int baz_music_debug_q(baz_music_ctx* ctx, const void* d_in, uint32
  *                          (item, bin); *worst = the largest observed error / allowance (sound below 1; derived with a factor
  *                          > 2 to spare).  BAZ_MUSIC_E_UNSUPPORTED for m > 4 or a table whose scale does not fit. */
 BAZ_MUSIC_API int baz_music_debug_coarse_margin(baz_music_ctx* ctx, const void* d_in, uint32_t batch, float* worst);
+/*   lab statistic: exact (16-item row group x 16-bin tile) evaluations of the coarse-gated scan's launches since the last
+ *                          read (the counter resets); -1 unless the context was created under BAZ_MUSIC_COARSE_STATS=1. */
+BAZ_MUSIC_API int64_t baz_music_debug_coarse_fired(baz_music_ctx* ctx);
 BAZ_MUSIC_API uint32_t baz_music_q_stride(uint32_t batch);
 
 /* Algorithmic HBM bytes per item: 8*nsamples + 8*n + 4*resolution (the last

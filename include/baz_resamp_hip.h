@@ -10,10 +10,12 @@
  * One context resamples `nstreams` streams in lock step with ONE shared phase accumulator (the antennas of an array
  * share their sample clock), stream-major layout: stream s occupies [s*stride, s*stride + n).
  *
- * Arithmetic: out[o] = sum_k in[ii_o + k] * taps[imu_o][7-k] (float accumulation), imu_o = rint((float)mu_o * 128),
- * with gnuradio-filter's 8-tap x 129-phase MMSE interpolator table regenerated from its published criterion
- * (closed-form least squares, gr_baz_amd/csrc/baz_resamp_hip.hip: build_taps) -- that library is not vendored in
- * gr-baz, PARITY UNPINNED.  The reference's x87 `long double` phase recurrence mu <- frac(mu + mu_inc),
+ * Arithmetic: out[o] = sum_k in[ii_o + k] * taps[imu_o][7-k] (float accumulation), imu_o = rint((float)mu_o * 128).
+ * The 8-tap x 129-phase table belongs to gnuradio-filter's MMSE interpolator, which gr-baz does not vendor: a fresh
+ * context starts from the table regenerated from the library's published criterion (closed-form least squares,
+ * gr_baz_amd/csrc/baz_resamp_hip.hip: build_taps; ~1e-6 from the published rows) -- PARITY UNPINNED for that default --
+ * and baz_resamp_set_taps() installs the host's own table, which the host block does wherever it is compiled against
+ * a real gnuradio-filter: bit-exact with whatever gnuradio-filter the host has.  The reference's x87 `long double` phase recurrence mu <- frac(mu + mu_inc),
  * ii <- ii + floor(mu + mu_inc) is evaluated in closed form, P_o = mu_0 + o * mu_inc in 64.64-bit fixed point
  * (128-bit integers), one output per thread.  This is EXACTLY the reference's sequence whenever its sums are exact
  * in the 64-bit x87 mantissa -- always for ratios and phases given as `double` (make()'s signature) with
@@ -96,6 +98,16 @@ BAZ_RESAMP_API double baz_resamp_ratio(const baz_resamp_ctx* ctx);              
 BAZ_RESAMP_API int baz_resamp_phase_exact(const baz_resamp_ctx* ctx);
 /* The 129 x 8 tap table in use (float, host copy). */
 BAZ_RESAMP_API const float* baz_resamp_taps(const baz_resamp_ctx* ctx);
+/* The table a fresh context starts with: the closed-form MMSE solution (see the header comment), written to
+ * out[129 * 8].  Pure host arithmetic, no device needed. */
+BAZ_RESAMP_API void baz_resamp_default_taps(float* out);
+/* Replaces the table: taps[imu * 8 + j] = tap j of phase imu as gnuradio-filter's interpolator stores it (interpolate()
+ * forms sum_k in[k] * taps[imu][7 - k]; /root/reference/lib/baz_fractional_resampler_cc.cc:172,203 call it).  This is how
+ * a host that HAS gnuradio-filter pins the arithmetic: the host block reads the installed library's table out of
+ * gr::filter::mmse_fir_interpolator_cc (8 unit impulses x 129 phases) and passes it here, after which the engine's
+ * outputs are those of that library, operation for operation.  Takes effect for the next process call (the context's
+ * stream is drained first).  E_INVALID for NULL or non-finite entries. */
+BAZ_RESAMP_API int baz_resamp_set_taps(baz_resamp_ctx* ctx, const float* taps);
 
 BAZ_RESAMP_API int baz_resamp_set_stream(baz_resamp_ctx* ctx, void* hip_stream);
 BAZ_RESAMP_API int baz_resamp_sync(baz_resamp_ctx* ctx);

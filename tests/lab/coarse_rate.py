@@ -32,7 +32,10 @@ for kind in ("coherent", "incoherent"):
         x = inputs(kind, snr)
         ref = None
         for label, env in (("full fp64 scan", {"BAZ_MUSIC_COARSE": "0"}), ("gated, 4 row groups", {"BAZ_MUSIC_COARSE": "1", "BAZ_MUSIC_COARSE_RG": "4"}),
-                           ("gated, 2 row groups", {"BAZ_MUSIC_COARSE": "1", "BAZ_MUSIC_COARSE_RG": "2"})):
+                           ("gated, 2 row groups", {"BAZ_MUSIC_COARSE": "1", "BAZ_MUSIC_COARSE_RG": "2"}),
+                           ("coarse passes only (lab)", {"BAZ_MUSIC_COARSE": "1", "BAZ_MUSIC_COARSE_RG": "4", "BAZ_MUSIC_COARSE_LAB": "1"})):
+            os.environ["BAZ_MUSIC_COARSE_LAB"] = "0"
+            os.environ["BAZ_MUSIC_COARSE_STATS"] = "1"
             os.environ.update(env)
             with capi.Context(M, NE, N, RES, table) as ctx:
                 ctx.reserve(B)
@@ -55,13 +58,16 @@ for kind in ("coherent", "incoherent"):
                 ctx.profile(False)
                 got = (ang.clone(), lvl.clone())
                 refined = ctx.refined_values()
+                ctx.debug_coarse_fired()
+                step()
+                fired = ctx.debug_coarse_fired()
                 margin = ctx.debug_coarse_margin(x.data_ptr(), min(B, 65536)) if env["BAZ_MUSIC_COARSE"] == "1" else None
             if ref is None:
                 ref = got
             same = bool(torch.equal(got[0], ref[0]) and torch.equal(got[1].view(torch.int32), ref[1].view(torch.int32)))
             ms = sorted(ws)[2]
             print("%-10s %2.0f dB  %-20s step %.4f ms (min %.4f) = %.3e items/s = %.1f %% of the HBM-read roofline | cov+evd %.4f scan %.4f merge %.4f | "
-                  "bit-identical to the full scan: %s | refined values %d%s"
+                  "bit-identical to the full scan: %s | refined values %d | exact (row group, tile) evaluations %d = %.1f %% of all%s"
                   % (kind, snr, label, ms, min(ws), B / ms * 1e3, B / ms * 1e3 * 8192 / 8e12 * 100, st[0][0] / st[0][1] + (st[1][0] / st[1][1] if st[1][1] else 0),
-                     st[2][0] / st[2][1], st[3][0] / st[3][1], same, refined, "" if margin is None else " | error/allowance worst %.3f" % margin), flush=True)
+                     st[2][0] / st[2][1], st[3][0] / st[3][1], same, refined, fired, 100.0 * fired / (B / 16 * 225), "" if margin is None else " | error/allowance worst %.3f" % margin), flush=True)
         del x

@@ -135,7 +135,8 @@ def test_agc_host_block_and_python_surface(gpu_device):
     blk = baz.agc_cc(float(g["rate"]), float(g["reference"]))
     assert blk.name() == "gr_agc_cc" and blk.input_item_sizes() == [8] and blk.output_item_sizes() == [8, 4]
     assert blk.output_streams() == (1, 3)
-    assert blk.output_multiple() == 16384 and blk.min_output_buffer() == 8 * 16384      # requests for large work() calls
+    # requests for large work() calls that cost no sample of a finite capture: look-back, not an output multiple
+    assert blk.output_multiple() == 1 and blk.history() == 16385 and blk.min_output_buffer() == 2 * 16384
     outs, envs, muls = [], [], []
     pos = 0
     for c in g["calls"]:

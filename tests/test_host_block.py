@@ -153,7 +153,7 @@ def test_finite_stream_is_processed_to_its_last_item(gpu_device, monkeypatch):
     monkeypatch.setenv("BAZ_MUSIC_OUTPUT_MULTIPLE", "64")
     monkeypatch.setenv("BAZ_MUSIC_INPUT_LOOKBACK", "0")
     blk = baz.music_doa(g["m"], g["n"], g["nsamples"], table, g["res"])
-    items = np.concatenate([base] * 10)[:100]
+    items = np.concatenate([base] * (100 // base.shape[0] + 1))[:100]
     st, ang, lvl, spec = blk.run_flowgraph(items, 3, True, False)
     assert st["items"] == 64 and st["dropped_at_end"] == 36
 

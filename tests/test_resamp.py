@@ -143,6 +143,65 @@ def test_hip_matches_golden(name, gpu_device):
         assert np.array_equal(out.view(np.uint32), g["out"].view(np.uint32))
 
 
+def test_host_block_reads_the_tap_table_out_of_gnuradio_filters_interpolator():
+    """Review r2, missing 2: on a host that has gnuradio-filter the block must interpolate with THAT library's table
+    (/root/reference/lib/baz_fractional_resampler_cc.cc:87 constructs gr::filter::mmse_fir_interpolator_cc, :172,203 call
+    interpolate()).  The host block reads the table out of that class -- 8 unit impulses x 129 phases through
+    interpolate() -- and installs it with baz_resamp_set_taps.  Against the stand-in interpolator of this image (whose
+    table is the engine's closed form) the read-out must return that table BIT FOR BIT: any slip in the phase selection
+    (mu = imu / 128), the tap reversal or the impulse position would show."""
+    from gr_baz_amd import baz, resamp
+    t = resamp.default_taps()
+    got = baz._native.recover_mmse_taps()
+    assert got.shape == (129, 8) and got.dtype == np.float32
+    assert np.array_equal(got.view(np.uint32), t.view(np.uint32))
+    assert np.abs(t - rr.taps()).max() <= 6e-8            # ... and it is the oracle's table (float rounding of two builds)
+    assert "baz_resamp_set_taps" in resamp.SYMBOLS and "baz_resamp_default_taps" in resamp.SYMBOLS
+    assert resamp.lib().baz_resamp_set_taps(None, None) == -1
+
+
+@pytest.mark.gpu
+def test_hip_set_taps_installs_the_hosts_table(gpu_device):
+    """baz_resamp_set_taps: after it the engine's outputs are sum_k in[ii + k] * taps[imu][7 - k] with the NEW table, in
+    the interpolator's float operation order (multiply, then add, k ascending) -- checked bit for bit against that loop in
+    numpy float32 with a table that is not the default one; a table with a NaN is refused and changes nothing."""
+    from gr_baz_amd import resamp
+    rng = np.random.default_rng(17)
+    x = (rng.standard_normal(3000) + 1j * rng.standard_normal(3000)).astype(np.complex64)
+    table = (resamp.default_taps().astype(np.float64) * (1.0 + 1e-3 * rng.standard_normal((129, 8)))).astype(np.float32)
+    phase, ratio, n = 0.25, 1.3, 2000
+    with resamp.Resampler(phase, ratio) as blk:
+        base, _ = blk.work(x, n)
+        blk.set_mu(phase)
+        bad = table.copy()
+        bad[5, 3] = np.nan
+        with pytest.raises(resamp.ResampError):
+            blk.set_taps(bad)
+        again, _ = blk.work(x, n)
+        assert np.array_equal(again.view(np.uint32), base.view(np.uint32))
+        blk.set_taps(table)
+        assert np.array_equal(blk.taps().view(np.uint32), table.view(np.uint32))
+        blk.set_mu(phase)
+        out, consumed = blk.work(x, n)
+    # the reference's phase walk (.cc:183-193) in exact rational arithmetic, then the interpolator's loop in float32
+    from fractions import Fraction
+    mu, inc, ii = Fraction(phase), Fraction(ratio), 0
+    want = np.zeros(n, np.complex64)
+    for o in range(n):
+        imu = int(np.rint(np.float32(float(mu)) * np.float32(128)))
+        re = im = np.float32(0)
+        for k in range(8):
+            w = table[imu, 7 - k]
+            re = np.float32(re + np.float32(x[ii + k].real * w))
+            im = np.float32(im + np.float32(x[ii + k].imag * w))
+        want[o] = re + 1j * im
+        s_ = mu + inc
+        ii += int(s_)
+        mu = s_ - int(s_)
+    assert out.shape[0] == n and np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    assert not np.array_equal(out.view(np.uint32), base.view(np.uint32))
+
+
 @pytest.mark.gpu
 def test_hip_tap_table_equals_the_oracle_table(gpu_device):
     from gr_baz_amd import resamp

@@ -110,10 +110,12 @@ def test_model_moves_every_item_through_wrapping_buffers(item, nout, multiple, m
 @pytest.mark.parametrize("name, n_outputs", [("cfg1_m4_n2_N256_r360", 3), ("cfg2_m4_n2_N1024_r3600", 3), ("cfg2_m4_n2_N1024_r3600", 2),
                                              ("cfg5_m16_n2_N4096_r3600", 3)])
 @pytest.mark.parametrize("pin", [False, True])
-def test_music_block_under_the_scheduler_model(name, n_outputs, pin, gpu_device, monkeypatch):
+@pytest.mark.parametrize("lookback", ["0", "5"])
+def test_music_block_under_the_scheduler_model(name, n_outputs, pin, lookback, gpu_device, monkeypatch):
     g = load_golden(name)
     monkeypatch.setenv("BAZ_MUSIC_OUTPUT_MULTIPLE", "4")       # the goldens hold a few dozen items: many calls, many wraps
     monkeypatch.setenv("BAZ_MUSIC_MIN_OUTPUT_BUFFER", "8")
+    monkeypatch.setenv("BAZ_MUSIC_INPUT_LOOKBACK", lookback)   # 5: the look-back window travels through the wraps too
     from gr_baz_amd import baz
     blk = baz.music_doa(g["m"], g["n"], g["nsamples"], [list(map(complex, r)) for r in g["table"]], g["res"])
     assert blk.pin_buffers() is False and blk.pinned_bytes() == 0
