@@ -22,9 +22,10 @@ roofline : dominant kernel = the scan (scan_mfma_kernel); achieved = its algorit
            bytes per launch from the rocprofv3 PMC passes kept under profiles/ -- used ONLY when that profile was
            taken on the kernel sources this run executes (sha256 over gr_baz_amd/csrc + include), else null and
            "traffic_stale": true.
-extras   : config.extra carries three secondary, clearly labelled measurements (rank 0, N=1): cfg2 WITHOUT the
-           spectrum port (the GRC default wiring), cfg3 (8 ant, 4096 samp, 36000 bins: fp64-matrix bound) and the cfg5
-           chain (16 ant: resampler -> AGC -> MUSIC on one stream), each with its own ms, bound and fraction.
+extras   : config.extra carries secondary, clearly labelled measurements (rank 0, N=1): cfg2 WITHOUT the spectrum port
+           (the GRC default wiring), the unfavourable cfg2 cases (an incoherent batch with and without the spectrum port,
+           60 dB SNR), cfg3 (8 ant, 4096 samp, 36000 bins: fp64-matrix bound) and the cfg5 chain (16 ant: resampler ->
+           AGC -> MUSIC on one stream), each with its own ms, bound and fraction.
 cpu_baseline : rank 0, N=1 only: oracle/_ref (the reference's own baz_music_doa.cc compiled in place, kind
            "reference") when its prebuilt .so is present, else the plain-C restatement (oracle/music_ref.c, kind
            "port"); one work() per item like the GNU Radio scheduler drives the reference, on all host cores
@@ -173,12 +174,18 @@ def timed_loop(torch, step, sync, min_seconds, chunk=5, max_steps=2000):
     return (time.perf_counter() - t0) / n * 1e3, n
 
 
-def extra_music(torch, np, capi, synth, dev, stream, m, nsamples, res, batch, with_spectrum, seconds):
-    """One secondary MUSIC configuration on the bench stream: ms/step, per-stage ms, dominant-kernel rooflines."""
+def extra_music(torch, np, capi, synth, dev, stream, m, nsamples, res, batch, with_spectrum, seconds, scene="coherent", snr_db=20.0):
+    """One secondary MUSIC configuration on the bench stream: ms/step, per-stage ms, dominant-kernel rooflines.
+    scene "coherent": 8 streams, every item of a stream sees the same two emitters (the headline's inputs);
+    scene "incoherent": the emitter angles are drawn per ITEM (the unfavourable case for everything the scan decides per
+    wave of 16 items: the top-n gate, the literal-form refinement, the coarse-gated scan's tile votes)."""
     arr, table = helper_table(np, synth, m, res)
     per = batch // 8
-    x = torch.cat([synth.synth_stream(torch, dev, per, m, nsamples, arr, FREQUENCY, SPACING, seed=1000 + 3 + s)
-                   for s in range(8)], dim=0)
+    if scene == "incoherent":
+        x = synth.synth_scenes(torch, dev, batch, m, nsamples, arr, FREQUENCY, SPACING, N_EMIT, snr_db=snr_db, seed=1000 + 7)
+    else:
+        x = torch.cat([synth.synth_stream(torch, dev, per, m, nsamples, arr, FREQUENCY, SPACING, snr_db=snr_db, seed=1000 + 3 + s)
+                       for s in range(8)], dim=0)
     ang = torch.zeros(batch, N_EMIT, dtype=torch.float32, device=dev)
     lvl = torch.zeros_like(ang)
     spec = torch.zeros(batch, res, dtype=torch.float32, device=dev) if with_spectrum else None
@@ -194,6 +201,8 @@ def extra_music(torch, np, capi, synth, dev, stream, m, nsamples, res, batch, wi
         stream.synchronize()
         st = [ctx.stage_ms(s) for s in range(capi.NUM_STAGES)]
         ctx.profile(False)
+        step()
+        refined = ctx.refined_values()
         bpi = ctx.bytes_per_item(with_spectrum)
         ctx.set_stream(None)
     stage = {nm: st[s][0] / max(st[s][1], 1) for s, nm in enumerate(("cov", "evd", "scan", "merge"))}
@@ -201,9 +210,20 @@ def extra_music(torch, np, capi, synth, dev, stream, m, nsamples, res, batch, wi
     mm = m * m
     scan_tf = 2.0 * mm * res * batch / scan_s / 1e12 if scan_s > 0 else 0.0
     out = {"items_per_step": batch, "ms_per_step": ms, "steps_timed": n, "snapshots_per_s": batch / ms * 1e3,
+           "scene": scene, "snr_db": snr_db, "values_recomputed_in_literal_form_per_step": refined,
            "algorithmic_bytes_per_item": bpi, "pipeline_hbm_fraction_of_8TBs": batch / ms * 1e3 * bpi / 8e12,
-           "stage_ms_per_launch": stage,
-           "scan_fp64_tflops": scan_tf, "scan_frac_of_fp64_matrix_peak": scan_tf / FP64_MFMA_PEAK_TF}
+           "stage_ms_per_launch": stage}
+    if with_spectrum or m > 4:     # (without the spectrum port and m <= 4 the scan is the coarse-gated one: its fp64 work is a few tiles)
+        out["scan_fp64_tflops"] = scan_tf
+        out["scan_frac_of_fp64_matrix_peak"] = scan_tf / FP64_MFMA_PEAK_TF
+    else:
+        # two coarse passes of 2 x K = 32 f16 MFMAs per 16 x 16 tile (64 MACs per item, bin and pass), bins padded to 16 x 8
+        tiles = -(-res // 128) * 8
+        f16_tf = 2.0 * 2 * 64 * 16 * tiles * batch / scan_s / 1e12 if scan_s > 0 else 0.0
+        out["scan_kernel"] = "scan_coarse_kernel (f16-matrix-core coarse form gates the fp64 tiles; ang / lvl bit-identical to the full scan)"
+        out["scan_f16_tflops"] = f16_tf
+        out["scan_frac_of_f16_matrix_peak_2500TF"] = f16_tf / 2500.0
+        out["hbm_read_fraction_of_8TBs"] = batch / ms * 1e3 * 8.0 * nsamples / 8e12
     if with_spectrum:
         wr = (4 * res + 8 * N_EMIT) * batch / scan_s / 1e9 if scan_s > 0 else 0.0
         out["scan_write_GBs"] = wr
@@ -494,8 +514,18 @@ def main():
             torch.cuda.empty_cache()
             for name, fn in (
                     ("cfg2_without_spectrum_port", lambda: dict(extra_music(torch, np, capi, synth, dev, stream, 4, 1024, 3600, 262144, False, 0.4),
-                                                                bound="fp64 matrix issue (no stores); HBM read for the covariance",
+                                                                bound="HBM read (covariance + EVD kernel, 63 % of the step) + f16 matrix (the scan's two coarse passes)",
                                                                 workload="cfg2 with only ang/lvl wired (music_doa_helper's default output_spectrum=False)")),
+                    ("cfg2_incoherent_scene", lambda: dict(extra_music(torch, np, capi, synth, dev, stream, 4, 1024, 3600, 262144, True, 0.4, scene="incoherent"),
+                                                           workload="cfg2, spectrum port wired, emitter angles drawn per ITEM: the top-n gate of the scan fires in "
+                                                                    "nearly every step")),
+                    ("cfg2_incoherent_scene_without_spectrum_port", lambda: dict(
+                        extra_music(torch, np, capi, synth, dev, stream, 4, 1024, 3600, 262144, False, 0.4, scene="incoherent"),
+                        workload="cfg2, ang/lvl only, emitter angles drawn per ITEM: ~22 % of the (16-item, 16-bin) tiles still run the exact "
+                                 "form (the union over a wave's 16 unrelated items), which costs what the coarse passes save")),
+                    ("cfg2_snr60", lambda: dict(extra_music(torch, np, capi, synth, dev, stream, 4, 1024, 3600, 262144, True, 0.4, snr_db=60.0),
+                                                workload="cfg2, spectrum port wired, 60 dB SNR: near-null values are recomputed in the reference's "
+                                                         "literal form inside the scan")),
                     ("cfg3", lambda: dict(extra_music(torch, np, capi, synth, dev, stream, 8, 4096, 36000, 16384, True, 0.5),
                                           bound="fp64 matrix (scan: 2*m^2 flop per item and bin)",
                                           workload="BASELINE configs[2]: m=8 n=2 nsamples=4096 (K=512) resolution=36000, spectrum wired")),

@@ -289,12 +289,14 @@ bool build_coarse_image(const std::vector<double>& F, uint32_t m, uint32_t res, 
     cp.sc_up = std::nextafter((float)(SC * (1.0 + 0x1p-16) * (1.0 + 0x1p-20)), INFINITY);
     cp.es_factor = std::nextafter((float)(0x1p-16 * fmax * SC), INFINITY);
     const size_t cbytes = (size_t)CS_C_UNITS * 16, xbytes = (size_t)CS_X_UNITS * 16;
-    img.assign((size_t)tiles * (cbytes + xbytes), 0);        // [C of every tile][X of every tile]
-    for (uint32_t t = 0; t < tiles; ++t) {
+    // [C of every tile and of one more (the kernel stages the first tile of the NEXT phase with every phase)][X of every tile]
+    img.assign((size_t)(tiles + 1) * cbytes + (size_t)tiles * xbytes, 0);
+    for (uint32_t t = 0; t <= tiles; ++t) {
         uint8_t* T = img.data() + (size_t)t * cbytes;
         uint16_t* fh = reinterpret_cast<uint16_t*>(T);
         uint16_t* fl = reinterpret_cast<uint16_t*>(T + 512);
-        double* X = reinterpret_cast<double*>(img.data() + (size_t)tiles * cbytes + (size_t)t * xbytes);
+        std::vector<double> xpad(256);
+        double* X = (t < tiles) ? reinterpret_cast<double*>(img.data() + (size_t)(tiles + 1) * cbytes + (size_t)t * xbytes) : xpad.data();
         for (uint32_t c = 0; c < 16; ++c) {
             const uint32_t bin = 16 * t + c;
             for (uint32_t e = 0; e < 16; ++e) {
@@ -569,10 +571,11 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             rf.count = c->dRefined + c->stat_parity;
             rf.A2 = nullptr;
             unsigned long long* stats = c->coarse_stats ? c->dMargin : nullptr;     // lab: exact tile evaluations, summed over launches
-#define BAZ_COARSE_ARGS dim3(CG.groups * CG.nsplit), dim3(256), 0, c->stream, dQ, c->dCS, c->dCS + (size_t)c->cs_tiles * CS_C_UNITS, \
+#define BAZ_COARSE_ARGS dim3(CG.groups * CG.nsplit), dim3(256), 0, c->stream, dQ, c->dCS, c->dCS + (size_t)(c->cs_tiles + 1) * CS_C_UNITS, \
                         c->dCand, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, stats, nullptr
             if (CG.tpp == 4) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 2, 4>), BAZ_COARSE_ARGS);
             else if (c->coarse_lab == 1) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8, false, 1>), BAZ_COARSE_ARGS);
+            else if (c->coarse_lab == 2) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8, false, 2>), BAZ_COARSE_ARGS);
             else hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8>), BAZ_COARSE_ARGS);
 #undef BAZ_COARSE_ARGS
             HIP_TRY(c, hipGetLastError());
@@ -1234,7 +1237,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (const char* v = getenv("BAZ_MUSIC_COARSE_STATS")) c->coarse_stats = atoi(v);          // lab
         if (m <= 4) {
             c->cs_tiles = round_up((resolution + 15) / 16, 8);
-            if (hipMalloc((void**)&c->dCS, (size_t)c->cs_tiles * (CS_C_UNITS + CS_X_UNITS) * 16) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+            if (hipMalloc((void**)&c->dCS, ((size_t)(c->cs_tiles + 1) * CS_C_UNITS + (size_t)c->cs_tiles * CS_X_UNITS) * 16) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMalloc((void**)&c->dMargin, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMemset(c->dMargin, 0, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         }
@@ -1663,7 +1666,7 @@ int baz_music_debug_coarse_margin(baz_music_ctx* c, const void* d_in, uint32_t b
     if (d_dump) (void)hipMemsetAsync(d_dump, 0, (size_t)batch * c->res * sizeof(float), c->stream);
 #define BAZ_VAL(MV, NV)                                                                                                     \
     hipLaunchKernelGGL((scan_coarse_kernel<MV, NV, 4, 8, true>), dim3(groups), dim3(256), 0, c->stream, c->dQ, c->dCS, \
-                       c->dCS + (size_t)c->cs_tiles * CS_C_UNITS, c->dCand,                                                       \
+                       c->dCS + (size_t)(c->cs_tiles + 1) * CS_C_UNITS, c->dCand,                                                       \
                        batch, c->res, qstride, nph, 1u, c->keep_mask, c->n, rf, c->cs, c->dMargin, d_dump)
     const bool n2 = c->n <= 2;
     if (c->m == 2) { BAZ_VAL(2, 2); }

@@ -132,23 +132,6 @@ __device__ __forceinline__ float row_kth_smallest(float v, const uint32_t k)
     return mk;
 }
 
-// The coarse form of one bin tile for the RG row groups of a wave: u[q] = [qh | ql] [Fh | Fh] + [qh | ql] [Fl | Fl] (+ cin[q]).
-// All first instructions are issued before the second ones (each dependent pair is separated by full MFMAs whatever the
-// register assignment), and the B operands stay allocated until the group is through, so that no destination can be
-// given their registers.
-template <int RG>
-__device__ __forceinline__ void coarse_tile(v4f32 (&u)[RG], const v8f16 (&a32)[RG], const v8f16 bh, const v8f16 bl, const v4f32* cin)
-{
-#pragma unroll
-    for (int q = 0; q < RG; ++q)
-        u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[q], bh, cin ? cin[q] : (v4f32){0, 0, 0, 0}, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < RG; ++q) u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[q], bl, u[q], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::"v"(bh), "v"(bl));
-}
-
 // VAL: validation build (baz_music_debug_coarse_margin): every tile runs both forms, nothing is gated, no lists are kept,
 // and the worst |c / SC - d| / (2^-16 (S + |d|)) over all (item, bin) is left in *margin (float bits, atomicMax).
 //
@@ -171,7 +154,10 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
 {
     constexpr int MM = M * M;
     static_assert(MM <= 16, "one K = 16 slab: m <= 4");
-    constexpr int C_UNITS = TPP * CS_C_UNITS, X_UNITS = TPP * CS_X_UNITS;   // 16-B units per phase, both multiples of 64
+    // 16-B units per staged phase, both multiples of 64: the C operands of TPP + 1 tiles -- the phase's own and the FIRST tile
+    // of the next phase, whose MFMAs are issued while this phase's last tile is reduced (the software pipeline below runs
+    // across the phase boundary) -- and the X operands of TPP tiles
+    constexpr int C_UNITS = (TPP + 1) * CS_C_UNITS, X_UNITS = TPP * CS_X_UNITS;
     constexpr int C_CHUNKS = C_UNITS / 64, X_CHUNKS = X_UNITS / 64;         // 1-KiB wave loads per phase
     __shared__ uint4 stage[2][C_UNITS + X_UNITS];                            // per buffer: [B32 | B16 of TPP tiles][X of TPP tiles]
 
@@ -248,7 +234,7 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
 
     // ---- table staging: L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no registers) ----------
     auto stage_load = [&](uint32_t ph, int b, const bool with_x) {
-        const uint4* __restrict__ sc = imgC + (size_t)ph * C_UNITS + lane;
+        const uint4* __restrict__ sc = imgC + (size_t)ph * (TPP * CS_C_UNITS) + lane;      // (the C array carries one tile of padding)
 #pragma unroll
         for (int i = 0; i < (C_CHUNKS + 3) / 4; ++i) {
             const int j = i * 4 + wave;                        // wave-uniform: chunk j of the phase
@@ -269,6 +255,31 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
     };
 
     int buf = 0;
+    // Software pipeline of both passes: the MFMAs of tile t + 1 are issued BEFORE the integer reduction of tile t's results,
+    // and the scheduler is told to interleave them (one MFMA, two VALU): a wave issues in order, so VALU work placed between
+    // two MFMAs runs while the matrix pipe is busy, and VALU work placed behind them waits for them.  Two register sets (A,
+    // B) alternate, so nothing is copied.  (Measured before: MFMA pipe 49 % busy, 30 % of the wave cycles in issue stalls;
+    // profiles/r03_coarse_scan_pmc_first.txt.)
+    auto ld_b = [&](const char* __restrict__ T0, int t, v8f16& bh, v8f16& bl) __attribute__((always_inline)) {
+        const char* __restrict__ T = T0 + t * (CS_C_UNITS * 16);
+        bh = *reinterpret_cast<const v8f16*>(T);
+        bl = *reinterpret_cast<const v8f16*>(T + 512);
+    };
+    auto issue = [&](v4f32 (&u)[RG], const v8f16 bh, const v8f16 bl, const bool with_thr) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < RG; ++q)
+            u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[q], bh, with_thr ? negthr[q] : (v4f32){0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < RG; ++q) u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[q], bl, u[q], 0, 0, 0);
+    };
+    auto interleave = [&]() __attribute__((always_inline)) {      // 2 RG MFMAs, two VALU instructions behind each
+#pragma unroll
+        for (int i = 0; i < 2 * RG; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+    };
+
     // ---- pass 1: thresholds from the coarse form alone -----------------------------------------------------------------
     if constexpr (!VAL) {
         int pm[RG][4];              // running minimum of the coarse values, as bit patterns (see fbits)
@@ -276,28 +287,40 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
         for (int q = 0; q < RG; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) pm[q][r] = 0x7F800000;    // +inf
+        auto reduce1 = [&](const v4f32 (&u)[RG]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < RG; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pm[q][r] = imin(pm[q][r], fbits(u[q][r]));
+                    // opaque from here: otherwise the compiler folds this tile's and the next tile's reduction into one
+                    // v_min3 that waits (s_nop 7) for the NEXT tile's MFMAs -- the opposite of the pipeline
+                    asm volatile("" : "+v"(pm[q][r]));
+                }
+        };
         if (ph_begin < ph_end) stage_load(ph_begin, 0, false);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        v8f16 bhA, blA, bhB, blB;
+        v4f32 uA[RG], uB[RG];
         for (uint32_t ph = ph_begin; ph < ph_end; ++ph) {
             if (ph + 1 < ph_end) stage_load(ph + 1, buf ^ 1, false);
-            // the NEXT tile's operands are read before this tile's MFMAs issue (a wave's ds_read latency otherwise sits
-            // between every two tiles: with 2 waves per SIMD there is nobody else to cover it)
             const char* __restrict__ T0 = reinterpret_cast<const char*>(&stage[buf][0]) + ((g & 1) * 16 + c) * 16;
-            v8f16 nbh = *reinterpret_cast<const v8f16*>(T0);
-            v8f16 nbl = *reinterpret_cast<const v8f16*>(T0 + 512);
+            if (ph == ph_begin) {                                              // prologue of the pass: tile 0
+                ld_b(T0, 0, bhA, blA);
+                issue(uA, bhA, blA, false);
+            }
+            ld_b(T0, 1, bhB, blB);
 #pragma nounroll
-            for (int tl = 0; tl < TPP; ++tl) {
-                const v8f16 bh = nbh, bl = nbl;
-                const char* __restrict__ Tn = T0 + ((tl + 1 < TPP) ? tl + 1 : tl) * (CS_C_UNITS * 16);
-                nbh = *reinterpret_cast<const v8f16*>(Tn);
-                nbl = *reinterpret_cast<const v8f16*>(Tn + 512);
-                v4f32 u[RG];
-                coarse_tile<RG>(u, a32, bh, bl, nullptr);
-#pragma unroll
-                for (int q = 0; q < RG; ++q)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pm[q][r] = imin(pm[q][r], fbits(u[q][r]));
+            for (int tl = 0; tl < TPP; tl += 2) {
+                issue(uB, bhB, blB, false);                                    // tile tl + 1 ...
+                ld_b(T0, tl + 2, bhA, blA);
+                reduce1(uA);                                                   // ... while tile tl is reduced
+                interleave();
+                issue(uA, bhA, blA, false);                                    // tile tl + 2 (= tile 0 of the next phase at the end) ...
+                ld_b(T0, (tl + 3 <= TPP) ? tl + 3 : TPP, bhB, blB);
+                reduce1(uB);                                                   // ... while tile tl + 1 is reduced
+                interleave();
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -315,100 +338,110 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
     }
 
     // ---- pass 2: the gated walk ------------------------------------------------------------------------------------------
-    if (ph_begin < ph_end) stage_load(ph_begin, buf, true);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (uint32_t ph = ph_begin; ph < ph_end; ++ph) {
-        if (ph + 1 < ph_end) stage_load(ph + 1, buf ^ 1, true);     // lands while this phase's tiles run
-        const char* __restrict__ T0 = reinterpret_cast<const char*>(&stage[buf][0]) + ((g & 1) * 16 + c) * 16;
-        v8f16 nbh = *reinterpret_cast<const v8f16*>(T0);
-        v8f16 nbl = *reinterpret_cast<const v8f16*>(T0 + 512);
-#pragma nounroll
-        for (int tl = 0; tl < TPP; ++tl) {
-            const v8f16 bh = nbh, bl = nbl;
-            const char* __restrict__ Tn = T0 + ((tl + 1 < TPP) ? tl + 1 : tl) * (CS_C_UNITS * 16);
-            nbh = *reinterpret_cast<const v8f16*>(Tn);                     // next tile's operands: see pass 1
-            nbl = *reinterpret_cast<const v8f16*>(Tn + 512);
-            v4f32 u[RG];
-            int mn[RG];
-            coarse_tile<RG>(u, a32, bh, bl, VAL ? nullptr : negthr);
-            int mall = 0x7F800000;
+    // one tile whose vote fired: the exact form for the row groups that asked for it (u = that tile's coarse results)
+    auto exact_tile = [&](const v4f32 (&u)[RG], const uint32_t tile, const char* __restrict__ Xt) __attribute__((always_inline)) {
+        const uint32_t bin = tile * 16u + (uint32_t)c;
+        const double* __restrict__ X = reinterpret_cast<const double*>(Xt);
 #pragma unroll
-            for (int q = 0; q < RG; ++q) {
-                mn[q] = imin(imin(fbits(u[q][0]), fbits(u[q][1])), imin(fbits(u[q][2]), fbits(u[q][3])));
-                mall = imin(mall, mn[q]);
-            }
-            if constexpr (LAB == 1) {                         // lab: the cost of the two coarse passes alone (results are wrong):
-                fired += (mall <= 0) ? 1u : 0u;               // the votes are counted, so nothing above is dead code
-                continue;
-            }
-            if (!VAL && !__any(mall <= 0)) continue;          // some c - thr <= 0?  no group of this wave can gain from this tile
-            const uint32_t bin = (ph * TPP + (uint32_t)tl) * 16u + (uint32_t)c;
-            const double* __restrict__ X = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&stage[buf][C_UNITS]) +
-                                                                            tl * (CS_X_UNITS * 16));
+        for (int q = 0; q < RG; ++q) {
+            const int mnq = imin(imin(fbits(u[q][0]), fbits(u[q][1])), imin(fbits(u[q][2]), fbits(u[q][3])));
+            if (!VAL && !__any(mnq <= 0)) continue;
+            if constexpr (!VAL) ++fired;
+            // exact form: scan_mfma_kernel's projector GEMM for this 16 x 16 tile (same k order, same operands)
+            const v2f64 x01 = *reinterpret_cast<const v2f64*>(X + lane * 2);
+            const v2f64 x23 = *reinterpret_cast<const v2f64*>(X + 128 + lane * 2);
+            v4f64 acc = {0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][0], x01.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][1], x01.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][2], x23.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][3], x23.y, acc, 0, 0, 0);
+            if constexpr (VAL) {
 #pragma unroll
-            for (int q = 0; q < RG; ++q) {
-                if (!VAL && !__any(mn[q] <= 0)) continue;
-                if constexpr (!VAL) ++fired;
-                // exact form: scan_mfma_kernel's projector GEMM for this 16 x 16 tile (same k order, same operands)
-                const v2f64 x01 = *reinterpret_cast<const v2f64*>(X + lane * 2);
-                const v2f64 x23 = *reinterpret_cast<const v2f64*>(X + 128 + lane * 2);
-                v4f64 acc = {0, 0, 0, 0};
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][0], x01.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][1], x01.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][2], x23.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][3], x23.y, acc, 0, 0, 0);
-                if constexpr (VAL) {
+                for (int r = 0; r < 4; ++r) {
+                    // S of item g + 4 r in d units: es / (2^-16 SC 1.0001); allowance 2^-16 (S + |d|)
+                    const double S = (double)es[q][r] / (1.0001 * (double)cp.es_factor) * cp.fmax;
+                    const double err = fabs((double)u[q][r] / cp.sc - acc[r]);
+                    const double allow = 0x1p-16 * (S + fabs(acc[r]));
+                    const bool counts = bin < res && row_ok[q][r] && S < 1e30 && allow > 0.0 && err == err;
+                    const float ratio = counts ? (float)(err / allow) : 0.0f;
+                    if (val_dump && bin < res && row_ok[q][r])       // lab: every ratio, [item][bin]
+                        val_dump[(size_t)(item0 + 16 * q + (uint32_t)(g + 4 * r)) * res + bin] = ratio;
+                    if (ratio > worst) {
+                        worst = ratio;
+                        worst_at = bin | (((item0 + 16 * q + (uint32_t)(g + 4 * r)) & 0xFFFu) << 20);
+                    }
+                }
+            } else {
+                bool low = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) low |= (fabs(acc[r]) <= below_d);
+                if (refine_on && __any(low)) {                  // near-null tile: the reference's literal form, per value
+                    const uint32_t it_n = item0 + 16 * q + (uint32_t)c;
+                    const v4f64 d = literal16<M>(rf.Gs, rf.TB, (it_n < batch) ? it_n : (batch - 1), g, qstride, (int)M - (int)n, bin);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        // S of item g + 4 r in d units: es / (2^-16 SC 1.0001); allowance 2^-16 (S + |d|)
-                        const double S = (double)es[q][r] / (1.0001 * (double)cp.es_factor) * cp.fmax;
-                        const double err = fabs((double)u[q][r] / cp.sc - acc[r]);
-                        const double allow = 0x1p-16 * (S + fabs(acc[r]));
-                        const bool counts = bin < res && row_ok[q][r] && S < 1e30 && allow > 0.0 && err == err;
-                        const float ratio = counts ? (float)(err / allow) : 0.0f;
-                        if (val_dump && bin < res && row_ok[q][r])       // lab: every ratio, [item][bin]
-                            val_dump[(size_t)(item0 + 16 * q + (uint32_t)(g + 4 * r)) * res + bin] = ratio;
-                        if (ratio > worst) {
-                            worst = ratio;
-                            worst_at = bin | (((item0 + 16 * q + (uint32_t)(g + 4 * r)) & 0xFFFu) << 20);
-                        }
+                        const bool redo = (fabs(acc[r]) <= rf.below) && (bin < res);
+                        acc[r] = redo ? d[r] : acc[r];
+                        refined += (redo && row_ok[q][r]) ? 1u : 0u;
                     }
-                } else {
-                    bool low = false;
+                }
+                const uint32_t kbin = (bin < res) ? bin : nobin;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) low |= (fabs(acc[r]) <= below_d);
-                    if (refine_on && __any(low)) {                  // near-null tile: the reference's literal form, per value
-                        const uint32_t it_n = item0 + 16 * q + (uint32_t)c;
-                        const v4f64 d = literal16<M>(rf.Gs, rf.TB, (it_n < batch) ? it_n : (batch - 1), g, qstride, (int)M - (int)n, bin);
+                for (int r = 0; r < 4; ++r) {
+                    double ko = key[q][r][0];                   // the list's n-th entry (the lists hold NMAX >= n) ...
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const bool redo = (fabs(acc[r]) <= rf.below) && (bin < res);
-                            acc[r] = redo ? d[r] : acc[r];
-                            refined += (redo && row_ok[q][r]) ? 1u : 0u;
-                        }
-                    }
-                    const uint32_t kbin = (bin < res) ? bin : nobin;
+                    for (int i = 1; i < NMAX; ++i) ko = ((uint32_t)i < n) ? key[q][r][i] : ko;
+                    key_insert_new<NMAX>(key[q][r], make_key(acc[r], kbin, keep_mask));
+                    double kn = key[q][r][0];                   // ... before and after this tile's value
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        double ko = key[q][r][0];                   // the list's n-th entry (the lists hold NMAX >= n) ...
-#pragma unroll
-                        for (int i = 1; i < NMAX; ++i) ko = ((uint32_t)i < n) ? key[q][r][i] : ko;
-                        key_insert_new<NMAX>(key[q][r], make_key(acc[r], kbin, keep_mask));
-                        double kn = key[q][r][0];                   // ... before and after this tile's value
-#pragma unroll
-                        for (int i = 1; i < NMAX; ++i) kn = ((uint32_t)i < n) ? key[q][r][i] : kn;
-                        // the threshold moves only when some lane's n-th entry did: usually one item of the 16 drew the tile
-                        if (!cp.lazy || __any(__builtin_bit_cast(uint64_t, kn) != __builtin_bit_cast(uint64_t, ko))) {
-                            const uint64_t kb = __builtin_bit_cast(uint64_t, kn) | (uint64_t)(~keep_mask);
-                            const double D = fmax(__builtin_bit_cast(double, kb), below_d);
-                            // (float) rounds to nearest: sc_up carries the factor that makes the product an upper bound
-                            const float thr = row_allmin(__builtin_fmaf((float)D, cp.sc_up, es[q][r]));
-                            negthr[q][r] = fmaxf(negthr[q][r], -thr);   // thresholds only ever tighten
-                        }
+                    for (int i = 1; i < NMAX; ++i) kn = ((uint32_t)i < n) ? key[q][r][i] : kn;
+                    // the threshold moves only when some lane's n-th entry did: usually one item of the 16 drew the tile
+                    if (!cp.lazy || __any(__builtin_bit_cast(uint64_t, kn) != __builtin_bit_cast(uint64_t, ko))) {
+                        const uint64_t kb = __builtin_bit_cast(uint64_t, kn) | (uint64_t)(~keep_mask);
+                        const double D = fmax(__builtin_bit_cast(double, kb), below_d);
+                        // (float) rounds to nearest: sc_up carries the factor that makes the product an upper bound
+                        const float thr = row_allmin(__builtin_fmaf((float)D, cp.sc_up, es[q][r]));
+                        negthr[q][r] = fmaxf(negthr[q][r], -thr);   // thresholds only ever tighten
                     }
                 }
             }
+        }
+    };
+    // the vote of one tile: some c - thr <= 0 among the wave's 16 RG values per lane?
+    auto vote = [&](const v4f32 (&u)[RG]) __attribute__((always_inline)) -> int {
+        int m = 0x7F800000;
+#pragma unroll
+        for (int q = 0; q < RG; ++q) m = imin(m, imin(imin(fbits(u[q][0]), fbits(u[q][1])), imin(fbits(u[q][2]), fbits(u[q][3]))));
+        return m;
+    };
+    if (ph_begin < ph_end) stage_load(ph_begin, buf, LAB != 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    v8f16 bhA, blA, bhB, blB;
+    v4f32 uA[RG], uB[RG];
+    for (uint32_t ph = ph_begin; ph < ph_end; ++ph) {
+        if (ph + 1 < ph_end) stage_load(ph + 1, buf ^ 1, LAB != 2);   // lands while this phase's tiles run (lab 2: no X operands)
+        const char* __restrict__ T0 = reinterpret_cast<const char*>(&stage[buf][0]) + ((g & 1) * 16 + c) * 16;
+        const char* __restrict__ X0 = reinterpret_cast<const char*>(&stage[buf][C_UNITS]);
+        if (ph == ph_begin) {                                                  // prologue of the pass: tile 0
+            ld_b(T0, 0, bhA, blA);
+            issue(uA, bhA, blA, !VAL);
+        }
+        ld_b(T0, 1, bhB, blB);
+#pragma nounroll
+        for (int tl = 0; tl < TPP; tl += 2) {
+            issue(uB, bhB, blB, !VAL);                                         // tile tl + 1 (with the thresholds as they are now)
+            ld_b(T0, tl + 2, bhA, blA);
+            const int mA = vote(uA);
+            interleave();
+            if constexpr (LAB >= 1) fired += (mA <= 0) ? 1u : 0u;              // lab: the cost of the coarse passes alone (results are wrong)
+            else if (VAL || __any(mA <= 0)) exact_tile(uA, ph * TPP + (uint32_t)tl, X0 + tl * (CS_X_UNITS * 16));
+            issue(uA, bhA, blA, !VAL);                                         // tile tl + 2 (= tile 0 of the next phase at the end)
+            ld_b(T0, (tl + 3 <= TPP) ? tl + 3 : TPP, bhB, blB);
+            const int mB = vote(uB);
+            interleave();
+            if constexpr (LAB >= 1) fired += (mB <= 0) ? 1u : 0u;
+            else if (VAL || __any(mB <= 0)) exact_tile(uB, ph * TPP + (uint32_t)tl + 1u, X0 + (tl + 1) * (CS_X_UNITS * 16));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
