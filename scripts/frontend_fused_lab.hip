@@ -1,4 +1,4 @@
-// Lab harness (not product, NOT YET RUN ON A GPU -- written at the end of round 2 with the GPU budget spent; it compiles):
+// Lab harness (not product; run twice in round 3: profiles/r03_frontend_fused_lab.txt -- bit-identical, and NOT faster):
 // the config-5 front-end with the resampler folded INTO the AGC's two tile passes.
 //
 // Today: resamp_kernel writes the resampled streams (read 8 B / 1.25 + write 8 B per output sample), then
@@ -48,6 +48,32 @@ __device__ __forceinline__ float2 resamp_sample(const float2* __restrict__ xs, c
     return make_float2(re, im);
 }
 
+// the same arithmetic with the 8 input samples taken from an LDS copy of the tile's input window (win[0] = sample w0)
+__device__ __forceinline__ float2 resamp_sample_win(const float2* __restrict__ win, uint64_t w0, const PhaseParams& p, uint32_t o,
+                                                    const float* __restrict__ st)
+{
+    uint64_t ii, frac;
+    phase_of(p, o, ii, frac);
+    const float mu = __ull2float_rn(frac) * 5.42101086242752217e-20f;
+    const int imu = __float2int_rn(mu * (float)RS_NSTEPS);
+    const float* t = st + imu * RS_NTAPS;
+    const float2* x = win + (uint32_t)(ii - w0);
+    float re = 0.0f, im = 0.0f;
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int k = 0; k < RS_NTAPS; ++k) {
+            const float2 v = x[k];
+            const float w = t[RS_NTAPS - 1 - k];
+            re = re + v.x * w;
+            im = im + v.y * w;
+        }
+    }
+    return make_float2(re, im);
+}
+
+constexpr int FW_MAX = 448;       // samples of input window per stream and tile the LDS form holds (ratio <= ~1.7)
+
 // state "before sample 0" of every stream when the call starts the stream (agc_carry_kernel's first != 0 rule), from
 // the resampled sample 0: lets agc_carry_kernel run unchanged with first = 0
 __global__ void fused_first_kernel(const float2* __restrict__ raw, uint64_t raw_stride, PhaseParams p,
@@ -63,7 +89,10 @@ __global__ void fused_first_kernel(const float2* __restrict__ raw, uint64_t raw_
 //                 lane: ~3x the L1 line requests of resamp_kernel);
 // STAGED = true:  the wave evaluates its 256 outputs with lane = output mod 64 (resamp_kernel's coalesced pattern), parks
 //                 them in a wave-private 2-KiB LDS row and reads back AGC_IE consecutive ones per lane.
-template <int MODE, bool STAGED>
+// STAGE = 2: the wave first copies its tile's INPUT window (<= FW_MAX samples, 16-B loads, every input byte once) into LDS and
+//            every lane then evaluates its own AGC_IE consecutive outputs from there: no 8-byte gathers through the L1
+//            (resamp_kernel issues 8 of them per output: 64 addresses per instruction, the address path sets its pace).
+template <int MODE, int STAGE>
 __global__ __launch_bounds__(1024) void fused_tile_kernel(const float2* __restrict__ raw, uint64_t raw_stride, PhaseParams p,
                                                            const float* __restrict__ taps, uint64_t n, AgcParams P,
                                                            double2* __restrict__ chunk_pair, const double* __restrict__ carry_in,
@@ -83,7 +112,27 @@ __global__ __launch_bounds__(1024) void fused_tile_kernel(const float2* __restri
     const float2* __restrict__ xs = raw + (size_t)stream * raw_stride;
     float2 x[AGC_IE];
     double mag[AGC_IE];
-    if constexpr (STAGED) {
+    if constexpr (STAGE == 2) {
+        float2* __restrict__ win = tile + (MODE == 1 ? (size_t)nstreams * (AGC_IT + 1) : 0) + (size_t)stream * FW_MAX;
+        uint64_t ii0, ii1, fr;
+        phase_of(p, (uint32_t)base, ii0, fr);
+        phase_of(p, (uint32_t)(base + valid - 1), ii1, fr);
+        const uint64_t w0 = ii0 & ~1ull;                                    // 16-B aligned start
+        const uint32_t nq = (uint32_t)((ii1 + RS_NTAPS - w0 + 1) >> 1);     // float4s to copy (<= FW_MAX / 2)
+        const float4* __restrict__ src4 = reinterpret_cast<const float4*>(xs + w0);
+        float4* __restrict__ dst4 = reinterpret_cast<float4*>(win);
+#pragma unroll
+        for (int u = 0; u < (FW_MAX / 2 + 63) / 64; ++u) {
+            const uint32_t i4 = (uint32_t)u * 64u + (uint32_t)lane;
+            if (i4 < nq) dst4[i4] = src4[i4];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < AGC_IE; ++j)
+            x[j] = (j < cnt) ? resamp_sample_win(win, w0, p, (uint32_t)(base + i0 + j), st) : make_float2(0.f, 0.f);
+    } else if constexpr (STAGE == 1) {
         float2* __restrict__ park = tile + (MODE == 1 ? (size_t)nstreams * (AGC_IT + 1) : 0) + (size_t)stream * AGC_IT;
 #pragma unroll
         for (int j = 0; j < AGC_IE; ++j) {
@@ -221,20 +270,29 @@ int main(int argc, char** argv)
                            (float*)nullptr, (float*)nullptr);
     };
     const size_t park = (size_t)S * AGC_IT * sizeof(float2);
+    const size_t winb = (size_t)S * FW_MAX * sizeof(float2);
+    auto fused_win = [&]() {
+        hipLaunchKernelGGL((fused_tile_kernel<0, 2>), dim3(ntiles), tile_block, winb, 0, raw, raw_n, p, d_taps, n, P, pair,
+                           (const double*)nullptr, ntiles, (float2*)nullptr, (double*)nullptr, S);
+        hipLaunchKernelGGL(fused_first_kernel, dim3(1), dim3(64), 0, 0, raw, raw_n, p, d_taps, env, S);
+        hipLaunchKernelGGL(agc_carry_kernel, dim3(S), dim3(AGC_CARRY_THREADS), 0, 0, raw, raw_n, pair, carry, ntiles, env, 0);
+        hipLaunchKernelGGL((fused_tile_kernel<1, 2>), dim3(ntiles), tile_block, lds + winb, 0, raw, raw_n, p, d_taps, n, P, pair, carry,
+                           ntiles, items_fused, env, S);
+    };
     auto fused = [&](bool staged) {
         if (staged)
-            hipLaunchKernelGGL((fused_tile_kernel<0, true>), dim3(ntiles), tile_block, park, 0, raw, raw_n, p, d_taps, n, P, pair,
+            hipLaunchKernelGGL((fused_tile_kernel<0, 1>), dim3(ntiles), tile_block, park, 0, raw, raw_n, p, d_taps, n, P, pair,
                                (const double*)nullptr, ntiles, (float2*)nullptr, (double*)nullptr, S);
         else
-            hipLaunchKernelGGL((fused_tile_kernel<0, false>), dim3(ntiles), tile_block, 0, 0, raw, raw_n, p, d_taps, n, P, pair,
+            hipLaunchKernelGGL((fused_tile_kernel<0, 0>), dim3(ntiles), tile_block, 0, 0, raw, raw_n, p, d_taps, n, P, pair,
                                (const double*)nullptr, ntiles, (float2*)nullptr, (double*)nullptr, S);
         hipLaunchKernelGGL(fused_first_kernel, dim3(1), dim3(64), 0, 0, raw, raw_n, p, d_taps, env, S);
         hipLaunchKernelGGL(agc_carry_kernel, dim3(S), dim3(AGC_CARRY_THREADS), 0, 0, raw, raw_n, pair, carry, ntiles, env, 0);
         if (staged)
-            hipLaunchKernelGGL((fused_tile_kernel<1, true>), dim3(ntiles), tile_block, lds + park, 0, raw, raw_n, p, d_taps, n, P, pair, carry,
+            hipLaunchKernelGGL((fused_tile_kernel<1, 1>), dim3(ntiles), tile_block, lds + park, 0, raw, raw_n, p, d_taps, n, P, pair, carry,
                                ntiles, items_fused, env, S);
         else
-            hipLaunchKernelGGL((fused_tile_kernel<1, false>), dim3(ntiles), tile_block, lds, 0, raw, raw_n, p, d_taps, n, P, pair, carry, ntiles,
+            hipLaunchKernelGGL((fused_tile_kernel<1, 0>), dim3(ntiles), tile_block, lds, 0, raw, raw_n, p, d_taps, n, P, pair, carry, ntiles,
                                items_fused, env, S);
     };
 
@@ -242,15 +300,23 @@ int main(int argc, char** argv)
     CK(hipGetLastError());
     unsigned long long h_ndiff = 0;
     printf("config-5 front-end, %u items (16 antennas x %llu output samples, ratio 1.25)\n", items, (unsigned long long)n);
-    for (int staged = 0; staged < 2; ++staged) {
+    {
+        const void* fn0 = reinterpret_cast<const void*>(fused_tile_kernel<0, 2>);
+        const void* fn1 = reinterpret_cast<const void*>(fused_tile_kernel<1, 2>);
+        CK(hipFuncSetAttribute(fn0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)winb));
+        CK(hipFuncSetAttribute(fn1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + winb)));
+        const void* fn2 = reinterpret_cast<const void*>(fused_tile_kernel<1, 1>);
+        CK(hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + park)));
+    }
+    for (int staged = 0; staged < 3; ++staged) {
         CK(hipMemset(items_fused, 0xFF, (size_t)S * n * 8));
-        fused(staged != 0);
+        if (staged == 2) fused_win(); else fused(staged != 0);
         CK(hipGetLastError());
         CK(hipMemset(ndiff, 0, 8));
         hipLaunchKernelGGL(diff_kernel, dim3(4096), dim3(256), 0, 0, (const uint2*)items_ref, (const uint2*)items_fused, (size_t)S * n, ndiff);
         unsigned long long d = ~0ull;
         CK(hipMemcpy(&d, ndiff, 8, hipMemcpyDeviceToHost));
-        printf("  fused (%s) vs three engines: %llu of %llu floats differ\n", staged ? "staged through LDS" : "lane-local", d,
+        printf("  fused (%s) vs three engines: %llu of %llu floats differ\n", staged == 2 ? "input window in LDS" : (staged ? "staged through LDS" : "lane-local"), d,
                (unsigned long long)(2 * S * n));
         h_ndiff += d;
     }
@@ -258,10 +324,11 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int which = 0; which < 3; ++which) {
-        for (int w = 0; w < 5; ++w) which ? fused(which == 2) : three_engines();
+    for (int which = 0; which < 4; ++which) {
+        auto run = [&]() { if (which == 3) fused_win(); else if (which) fused(which == 2); else three_engines(); };
+        for (int w = 0; w < 5; ++w) run();
         CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < iters; ++i) which ? fused(which == 2) : three_engines();
+        for (int i = 0; i < iters; ++i) run();
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -269,7 +336,7 @@ int main(int argc, char** argv)
         const double per = ms / iters;
         const double bytes = which ? (2.0 * S * raw_n * 8 + (double)S * n * 8) : ((double)S * raw_n * 8 + 4.0 * S * n * 8);
         printf("  %-44s %.3f ms per step, %.0f GB/s of the %.2f GB it must move\n",
-               which == 2 ? "fused, staged through LDS:" : (which ? "fused, lane-local:" : "resamp_kernel + agc_tile<0> + carry + agc_tile<1>:"), per,
+               which == 3 ? "fused, input window in LDS:" : (which == 2 ? "fused, staged through LDS:" : (which ? "fused, lane-local:" : "resamp_kernel + agc_tile<0> + carry + agc_tile<1>:")), per,
                bytes / per / 1e6, bytes / 1e9);
     }
     return h_ndiff == 0 ? 0 : 1;
