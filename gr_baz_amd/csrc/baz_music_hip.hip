@@ -123,6 +123,7 @@ struct baz_music_ctx {
     uint64_t pin_limit = 4096ull << 20;                  // BAZ_MUSIC_PIN_LIMIT_MIB
     int auto_pin = 0;                                    // baz_music_set_host_pinning
     int zero_copy = 1;                                   // small calls on page-locked memory: no copies (BAZ_MUSIC_ZERO_COPY=0: lab)
+    int single_limit_mib = 64;                           // page-locked calls below this much traffic run as ONE chunk (BAZ_MUSIC_SINGLE_MIB)
     StageProf prof[BAZ_MUSIC_NUM_STAGES];
     std::string stage_name[BAZ_MUSIC_NUM_STAGES];
     char hip_err[256] = {0};
@@ -1166,6 +1167,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     if (const char* v = getenv("BAZ_MUSIC_CHUNK_MIB")) c->chunk_bytes = (size_t)std::max(1, std::min(1024, atoi(v))) << 20;
     if (const char* v = getenv("BAZ_MUSIC_PIN_LIMIT_MIB")) c->pin_limit = (uint64_t)std::max(0, atoi(v)) << 20;
     if (const char* v = getenv("BAZ_MUSIC_ZERO_COPY")) c->zero_copy = atoi(v) != 0;
+    if (const char* v = getenv("BAZ_MUSIC_SINGLE_MIB")) c->single_limit_mib = std::max(1, std::min(1024, atoi(v)));
     DeviceGuard guard(dev);
     int r = BAZ_MUSIC_OK;
     do {
@@ -1415,8 +1417,10 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
     // in two ran at 0.41-0.53 ms, as one chunk on one stream at 0.20-0.22 ms; pageable 2,048-item calls (46 MB) in four
     // chunks were SLOWER per item than 512-item calls in one (the runtime stages pageable copies and blocks in them, so
     // little overlaps).  Hence:
-    //   page-locked caller memory   below 16 MiB of traffic ONE chunk on ONE stream (copy in, three launches, copies
-    //                               out, one synchronize); above, >= 4 chunks of >= 8 MiB and <= 32 MiB each;
+    //   page-locked caller memory   below 64 MiB of traffic (BAZ_MUSIC_SINGLE_MIB) ONE chunk on ONE stream -- without copies
+    //                               when zero-copy applies: a 1,024-item config-2 call (23 MB) ran at 2.06e6 items/s that way and
+    //                               at 1.53e6 cut into three pipelined chunks (round 3, scripts/gpu/r03l.sh); above, >= 4 chunks of
+    //                               >= 8 MiB and <= 32 MiB each;
     //   pageable caller memory      one chunk up to 64 MiB, 64-MiB chunks beyond (profiles/r01h_hostfed_chunk_sweep.txt);
     //   BAZ_MUSIC_CHUNK_MIB         forces the chunk size (tests, lab).
     const size_t per_item = (size_t)c->nsamples * 8 + (size_t)c->res * 4 + (size_t)c->n * 8;
@@ -1428,9 +1432,7 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
         chunk = (uint32_t)std::min<size_t>(batch, std::max<size_t>(64, c->chunk_bytes / per_item));
     } else if (!locked) {
         chunk = (uint32_t)std::min<size_t>(batch, std::max<size_t>(64, (64u << 20) / per_item));
-    } else if ((size_t)batch * per_item < (spectrum ? (16u << 20) : (64u << 20))) {
-        // (without the spectrum port there is nothing to overlap on the way out: 2,048-item calls, 16.8 MB in and 16 KB
-        // out, ran at 4.2e6 items/s as one chunk and at 2.9e6 cut in four -- profiles/r02_flowgraph_model_rates.txt (B))
+    } else if ((size_t)batch * per_item < (size_t)c->single_limit_mib << 20) {
         chunk = batch;
     } else {
         const size_t floor_items = std::max<size_t>(64, (8u << 20) / per_item);

@@ -60,3 +60,23 @@ def test_bench_rejects_a_world_size_that_is_not_gpus():
                        text=True, timeout=240, cwd=ROOT, env=e)
     assert r.returncode != 0 and "does not match --gpus 8" in (r.stderr + r.stdout)
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_64_block_instances_on_their_own_threads(gpu_device):
+    """Config 4 as ONE flowgraph process: 64 music_doa blocks, a host thread each (GNU Radio's thread-per-
+    block scheduler), dealt over the visible devices by the host block (instance i -> device i mod G).  Every stream must
+    equal its single-threaded run -- 64 contexts with their own streams, tables and workspaces do not disturb each other --
+    and the harness reports the whole-process rate."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "deal_harness.py"), "64", "128", "3"], capture_output=True,
+                       text=True, timeout=540, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stderr[-2000:]
+    d = json.loads(lines[-1])
+    assert d["blocks"] == 64 and d["streams_identical_to_single_threaded_run"] is True
+    per_dev = d["instances_per_device"]
+    assert sum(per_dev.values()) == 64 and len(per_dev) == d["devices_visible"]
+    assert max(per_dev.values()) - min(per_dev.values()) <= 1                      # dealt evenly
+    assert d["items_per_s_all_blocks"] > 1e5
+
