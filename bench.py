@@ -471,7 +471,7 @@ def main():
         fused = "cov4_evd" in cov_name
         cov_mfma = {"kernel": cov_name,
                     "kernel_also_does": "the batched 4x4 Hermitian EVD of the same items: ~0.08 ms of fp64 VALU phases during "
-                                        "which HBM idles (DESIGN.md 5.2a); the rates below divide by the WHOLE kernel's "
+                                        "which HBM idles (DESIGN.md 5.1); the rates below divide by the WHOLE kernel's "
                                         "time, the stream alone runs at ~7 TB/s" if fused else None, "useful_tflops": cov_tf, "fp64_matrix_peak_tflops": FP64_MFMA_PEAK_TF,
                     "frac_of_peak": cov_tf / FP64_MFMA_PEAK_TF, "issued_over_useful": 4.0 / 3.0 if x4 else 2.0,
                     "hbm_read_GBs": 8.0 * NSAMPLES * batch / cov_s / 1e9 if cov_s > 0 else 0.0,

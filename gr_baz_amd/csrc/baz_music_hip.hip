@@ -625,7 +625,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
 #define BAZ_SCAN_LAUNCH(SPEC, VEC4, ABLV, AUXV)                                                                    \
     hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4, ABLV, AUXV>), dim3(G.blocks), dim3(256), 0, c->stream, \
                        BAZ_SCAN_ARGS)
-    if constexpr (M == 4 && NMAX == 2) {   // lab switches for the A/Bs in DESIGN.md 5.3 (BAZ_MUSIC_SCAN_VARIANT)
+    if constexpr (M == 4 && NMAX == 2) {   // lab switches for the A/Bs in profiles/HISTORY_r01_r02.md 5.3 (BAZ_MUSIC_SCAN_VARIANT)
         if (spec && vec4 && c->lab_variant) {
             switch (c->lab_variant) {
                 case 2: BAZ_SCAN_LAUNCH(true, true, 64, (1 | 2 | 16)); break;   // ungated top-n network (round 1)
