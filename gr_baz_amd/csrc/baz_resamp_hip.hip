@@ -187,6 +187,9 @@ int64_t process2_device_locked(baz_resamp_ctx* c, const void* d_in, uint64_t in_
     WalkResult w;
     RS_TRY(hipMemcpyAsync(&w, c->d_walk, sizeof(w), hipMemcpyDeviceToHost, c->stream));
     RS_TRY(hipStreamSynchronize(c->stream));
+    // the window STARTS on an unusable ratio sample: the previous call stopped here and nothing was consumed since.  The
+    // one output this call could emit is the one already delivered; report it instead of looping
+    if (w.status == 1 && w.ii == 0 && w.n <= 1) return BAZ_RESAMP_E_INVALID;
     c->mu = (u128)w.frac;
     if (w.last_bits) {                                              // d_mu_inc = the last ratio sample read (.cc:207,215)
         float r;

@@ -85,9 +85,15 @@ __global__ __launch_bounds__(RS_BLOCK) void resamp_kernel(const float2* __restri
 // so that flowgraphs which wire the port connect and produce the reference's stream, not for throughput: ONE lane walks
 // the phase chain over an LDS window of the ratio input (the other lanes of the workgroup only fetch that window) and
 // records (ii_o, imu_o) per output; the interpolation itself then runs in parallel from that table
-// (resamp_table_kernel).  A float ratio (24-bit significand, >= 2^-11) and a phase with <= 64 fractional bits add
-// exactly in 64.64 fixed point, i.e. this IS the reference's x87 sequence.  The walk stops early -- fewer outputs,
-// like a short input -- at a ratio sample that is not a finite number in [2^-11, 2^31].
+// (resamp_table_kernel).  A float ratio >= 2^-41 (24-bit significand: its last bit is >= 2^-64) and a phase with <= 64
+// fractional bits add exactly in 64.64 fixed point; that equals the reference's x87 sequence whenever the x87 sum
+// s = mu + inc is itself exact in its 64-bit significand -- always for ratios below 1, and for larger ones as long as
+// mu + inc needs no more than 64 significant bits (a ratio >= 1 pushes mu's last bits out: the two then differ by
+// < 2^-63 in mu, which moves imu only when mu * 128 sits that close to a rounding boundary).  Smaller ratios
+// (0 < r < 2^-41) are truncated to 2^-64 (the x87 sum rounds them instead).  The walk stops early -- fewer outputs, like a
+// short input -- at a ratio sample that is not a finite number in (0, 2^31]: zero, negative, NaN, inf (the reference
+// would stand still, walk backwards or index with garbage there); a call that STARTS on such a sample is an error
+// (baz_resamp_process2: BAZ_RESAMP_E_INVALID), not an endless one-output / zero-consumed loop.
 // -------------------------------------------------------------------------------------------------------------
 struct WalkResult {
     uint64_t n;          // outputs produced
@@ -124,11 +130,11 @@ __global__ __launch_bounds__(256) void resamp_walk_kernel(const float* __restric
                 imu_out[o] = (uint32_t)__float2int_rn(mu * (float)RS_NSTEPS);
                 ++o;
                 const float r = win[ii - w0];                                          // d_mu_inc = rr[ii], .cc:207
-                if (!(r >= 1.0f / 2048.0f && r <= 2147483648.0f)) { s_stop = 1; s_status = 1; break; }
+                if (!(r > 0.0f && r <= 2147483648.0f)) { s_stop = 1; s_status = 1; break; }
                 last = __float_as_uint(r);
                 const double rd = (double)r;
                 const uint64_t ip = (uint64_t)rd;
-                const uint64_t fr = (uint64_t)((rd - (double)ip) * 18446744073709551616.0);   // exact: <= 24 significant bits
+                const uint64_t fr = (uint64_t)((rd - (double)ip) * 18446744073709551616.0);   // exact from 2^-41 up (<= 24 significant bits), else truncated
                 const uint64_t nf = frac + fr;
                 ii += ip + (nf < frac ? 1u : 0u);                                      // s = mu + inc; ii += floor(s), .cc:209-213
                 frac = nf;                                                             // d_mu = s - floor(s)

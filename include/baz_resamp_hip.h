@@ -75,7 +75,9 @@ BAZ_RESAMP_API int64_t baz_resamp_process_device(baz_resamp_ctx* ctx, const void
 /* The two-input branch of general_work() (.cc:205-217): `ratio` is the second input port, one float per INPUT sample
  * (at least ninput of them), shared by the nstreams lock-stepped streams; after output o the ratio sample at the
  * current input index becomes d_mu_inc.  Same return / *consumed convention; production also stops -- like at the end
- * of the input -- at a ratio sample that is not a finite number in [2^-11, 2^31].  The pending set_mu / set_ratio /
+ * of the input -- at a ratio sample that is not a finite number in (0, 2^31] (the output AT that sample is still produced,
+ * *consumed points at it); a call whose window STARTS on such a sample returns BAZ_RESAMP_E_INVALID (the host block then
+ * ends with a message) instead of repeating one output and consuming nothing for ever.  The pending set_mu / set_ratio /
  * adjustment requests stay pending (the reference only honours them in the one-input branch).  The device form
  * synchronises the context's stream before returning (the counts depend on the data). */
 BAZ_RESAMP_API int64_t baz_resamp_process2(baz_resamp_ctx* ctx, const float* in_ri, uint64_t in_stride, uint64_t ninput,

@@ -1,4 +1,4 @@
-"""Builds profiles/r02_scan_pmc_traffic.json from two rocprofv3 --pmc passes (WRITE_SIZE, FETCH_SIZE: separate runs,
+"""Builds profiles/<round>_scan_pmc_traffic.json from two rocprofv3 --pmc passes (WRITE_SIZE, FETCH_SIZE: separate runs,
 MI355X_MICROARCH.md 'rocprofv3 PMC slots') of bench.py: HBM bytes per launch of the dominant kernel (the scan), tied to
 the kernel sources it was measured on (bench.kernel_sources_sha) so that bench.py only reports it for the same code.
 argv: write_csv fetch_csv out_json [git_head]"""

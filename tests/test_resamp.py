@@ -303,6 +303,15 @@ def test_hip_two_input_branch_stops_at_the_end_of_the_input_and_at_unusable_rati
         out, k = blk.work(x, 500, rr=bad)
         o, _ = rr.Resampler(0.0, 1.0).work(x, 21, rr=ratio)
         assert out.shape[0] == 21 and k == 30 and np.array_equal(out.view(np.uint32), o.view(np.uint32))
+        # the scheduler would now call again with the window advanced by 30: it starts ON the unusable sample.  That is an
+        # error, not a one-output / zero-consumed loop
+        with pytest.raises(resamp.ResampError):
+            blk.work(x[30:], 500, rr=bad[30:])
+    tiny = np.full(4000, 2.0 ** -20, np.float32)              # valid tiny ratios (< 2^-11) keep running, like the reference
+    with resamp.Resampler(0.0, 1.0) as blk:
+        out, k = blk.work(x, 300, rr=tiny)
+        o, ko = rr.Resampler(0.0, 1.0).work(x, 300, rr=tiny)
+        assert out.shape[0] == 300 and k == ko == 0 and np.array_equal(out.view(np.uint32), o.view(np.uint32))
     with resamp.Resampler(0.25, 1.0, nstreams=2) as blk:      # device buffers
         xd = torch.from_numpy(np.stack([x, x[::-1].copy()]).view(np.float32)).to(gpu_device)
         rd = torch.from_numpy(ratio).to(gpu_device)
