@@ -388,6 +388,11 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
                 const uint32_t kbin = (bin < res) ? bin : nobin;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    // Only accumulator registers in which some lane's value passed the coarse test can change a list: a
+                    // value with c > thr cannot be among the final n (the argument of the gate itself), so the other
+                    // registers' values need not be offered at all.  In a batch of unrelated items the tile was usually
+                    // drawn by ONE of the 16 items: three of the four insert / threshold blocks are skipped.
+                    if (!__any(fbits(u[q][r]) <= 0)) continue;
                     double ko = key[q][r][0];                   // the list's n-th entry (the lists hold NMAX >= n) ...
 #pragma unroll
                     for (int i = 1; i < NMAX; ++i) ko = ((uint32_t)i < n) ? key[q][r][i] : ko;
