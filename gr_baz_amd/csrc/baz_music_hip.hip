@@ -91,6 +91,9 @@ struct baz_music_ctx {
     double2* dSw = nullptr;        // signal eigenvectors, [items][n][m] (the scan's short form where 2n <= m)
     double* dA2 = nullptr;         // ||a||^2 per bin
     int wide_literal_only = 0;     // lab (BAZ_MUSIC_WIDE_LITERAL=1): no short form in scan_wide_kernel
+    uint32_t wide_cov_blocks = 512;
+    int wide_cov_mfma = 0;         // 17 <= m <= 32: cov_wide_mfma_kernel (BAZ_MUSIC_WIDE_COV_MFMA=0: lab)
+    int wide_mfma = 0;             // 17 <= m <= 32, n <= 2: the scan on the fp64 matrix core (scan_wide_mfma_kernel; BAZ_MUSIC_WIDE_MFMA=0: lab)
     uint32_t wide_cap = 0;         // items the three buffers above (and dR) hold
     double* dSs = nullptr;         // short_form_applies(): coefficient vectors of the scan's short form, [2n * 2m][q_stride]
     double* dA2p = nullptr;        // ... and ||a||^2 per bin, padded like dFB (fb_steps + 2 steps of 64)
@@ -782,6 +785,13 @@ int ensure_wide_workspace(baz_music_ctx* c, uint32_t items)
 int launch_cov_wide(baz_music_ctx* c, const float* d_in, uint32_t nb, double2* dR)
 {
     ProfScope ps(c, BAZ_MUSIC_STAGE_COV);
+    if (c->wide_cov_mfma) {         // 17 <= m <= 32: one wave per item on the fp64 matrix core, 2 workgroups per CU at most
+        const uint32_t blocks = std::min<uint32_t>((nb + 3) / 4, c->wide_cov_blocks);
+        hipLaunchKernelGGL(bazwide::cov_wide_mfma_kernel, dim3(blocks), dim3(256), 0, c->stream,
+                           reinterpret_cast<const float2*>(d_in), dR, nb, c->m, c->K);
+        HIP_TRY(c, hipGetLastError());
+        return BAZ_MUSIC_OK;
+    }
     hipLaunchKernelGGL(bazwide::cov_wide_kernel, dim3(nb), dim3(bazwide::WB), (size_t)bazwide::COV_TC * c->m * sizeof(float2),
                        c->stream, reinterpret_cast<const float2*>(d_in), dR, c->m, c->K);
     HIP_TRY(c, hipGetLastError());
@@ -817,6 +827,36 @@ int process_wide_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void
             hipLaunchKernelGGL(bazwide::evd_wide_kernel, dim3(nb), dim3(bazwide::WB), wide_evd_lds(c->m), c->stream, c->dR,
                                c->dGw, c->dSw, c->m, c->n, only);
             HIP_TRY(c, hipGetLastError());
+        }
+        if (c->wide_mfma && !c->wide_literal_only) {
+            // 17 <= m <= 32, n <= 2: the short form on the fp64 matrix core, candidates per bin range, bazmusic's merge
+            const uint32_t groups = (nb + 15) / 16;                                     // workgroups of 4 waves x 4 items
+            const uint32_t nsplit = std::max(1u, std::min((1024u + groups - 1) / groups, std::min(c->fb_steps, 16u)));
+            r = ensure_candidates(c, (size_t)nb * nsplit * 2);
+            if (r) return r;
+            float* sp = spec ? spec + (size_t)off * c->res : nullptr;
+            {
+                ProfScope ps(c, BAZ_MUSIC_STAGE_SCAN);
+                const bool vec4 = sp && (c->res % 4u) == 0 && (reinterpret_cast<uintptr_t>(sp) % 16u) == 0;
+#define BAZ_WIDE_ARGS dim3(groups * nsplit), dim3(256), 0, c->stream, c->dSw, c->dGw, c->dTB + c->tb_step_elems, c->dA2p + 64, c->dTA, sp, \
+                      c->dCand, nb, c->m, c->n, c->res, nsplit, c->keep_mask, c->refine_below, c->dRefined + c->stat_parity
+                if (sp && vec4) hipLaunchKernelGGL((bazwide::scan_wide_mfma_kernel<true, true>), BAZ_WIDE_ARGS);
+                else if (sp) hipLaunchKernelGGL((bazwide::scan_wide_mfma_kernel<true, false>), BAZ_WIDE_ARGS);
+                else hipLaunchKernelGGL((bazwide::scan_wide_mfma_kernel<false, false>), BAZ_WIDE_ARGS);
+#undef BAZ_WIDE_ARGS
+                HIP_TRY(c, hipGetLastError());
+            }
+            c->last_nsplit = nsplit;
+            {
+                ProfScope ps(c, BAZ_MUSIC_STAGE_MERGE);
+                // the statistic counter of the NEXT call is cleared by the last pass's merge only (the passes of one call add up)
+                unsigned long long* next_stat = (off + nb >= batch) ? c->dRefined + (c->stat_parity ^ 1) : nullptr;
+                hipLaunchKernelGGL((topn_merge_kernel<2>), dim3((nb + 255) / 256), dim3(256), 0, c->stream, c->dCand, sp,
+                                   ang + (size_t)off * c->n, lvl ? lvl + (size_t)off * c->n : nullptr, nb, c->res, c->n, nsplit,
+                                   c->keep_mask, next_stat);
+                HIP_TRY(c, hipGetLastError());
+            }
+            continue;
         }
         {
             ProfScope ps(c, BAZ_MUSIC_STAGE_SCAN);
@@ -864,6 +904,14 @@ int upload_table_wide(baz_music_ctx* c, const float* table_ri)
     HIP_TRY(c, hipMemcpy(c->dTA, ta.data(), ta.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->dA2, a2.data(), a2.size() * sizeof(double), hipMemcpyHostToDevice));
     c->refine_below = amax2 * (double)c->m * 1e-8;        // the threshold of the specialised kernels' refinement
+    if (c->wide_mfma) {       // raw-table B-operand image and ||a||^2 per bin, padded like the specialised kernels' (huge outside)
+        std::vector<double> TB;
+        build_TB(table_ri, c->m, c->res, c->fb_steps, TB);
+        HIP_TRY(c, hipMemcpy(c->dTB, TB.data(), TB.size() * sizeof(double), hipMemcpyHostToDevice));
+        std::vector<double> a2p((size_t)(c->fb_steps + 2) * 64, 1e300);
+        for (uint32_t b = 0; b < c->res; ++b) a2p[64 + b] = a2[b];
+        HIP_TRY(c, hipMemcpy(c->dA2p, a2p.data(), a2p.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     return BAZ_MUSIC_OK;
 }
 
@@ -1199,6 +1247,18 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
             if (const char* v = getenv("BAZ_MUSIC_WIDE_LITERAL")) c->wide_literal_only = atoi(v);   // lab / tests
             if (hipMalloc((void**)&c->dRefined, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMemset(c->dRefined, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
+            c->wide_cov_mfma = (m <= 32) ? 1 : 0;
+            c->wide_cov_blocks = 2u * (uint32_t)std::max(1, prop.multiProcessorCount);
+            if (const char* v = getenv("BAZ_MUSIC_WIDE_COV_MFMA")) c->wide_cov_mfma = (c->wide_cov_mfma && atoi(v)) ? 1 : 0;   // lab / tests
+            c->wide_mfma = (m <= 32 && n <= 2) ? 1 : 0;
+            if (const char* v = getenv("BAZ_MUSIC_WIDE_MFMA")) c->wide_mfma = (c->wide_mfma && atoi(v)) ? 1 : 0;   // lab / tests
+            if (c->wide_mfma) {
+                c->fb_steps = (resolution + 63) / 64;
+                c->keep_mask = (resolution <= (1u << 16)) ? 0xFFFF0000u : 0xFFF00000u;
+                c->tb_step_elems = (size_t)2 * ((2 * m + 3) / 4) * 64;
+                if (hipMalloc((void**)&c->dTB, (size_t)(c->fb_steps + 2) * c->tb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+                if (hipMalloc((void**)&c->dA2p, (size_t)(c->fb_steps + 2) * 64 * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+            }
             r = upload_table(c, table_ri);
             break;
         }
@@ -1261,10 +1321,10 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         return r;
     }
     if (wide) {
-        c->stage_name[BAZ_MUSIC_STAGE_COV] = "bazwide::cov_wide_kernel";
+        c->stage_name[BAZ_MUSIC_STAGE_COV] = c->wide_cov_mfma ? "bazwide::cov_wide_mfma_kernel" : "bazwide::cov_wide_kernel";
         c->stage_name[BAZ_MUSIC_STAGE_EVD] = "bazwide::evd_wide_kernel";
-        c->stage_name[BAZ_MUSIC_STAGE_SCAN] = "bazwide::scan_wide_kernel";
-        c->stage_name[BAZ_MUSIC_STAGE_MERGE] = "bazwide::topn_wide_kernel";
+        c->stage_name[BAZ_MUSIC_STAGE_SCAN] = c->wide_mfma ? "bazwide::scan_wide_mfma_kernel" : "bazwide::scan_wide_kernel";
+        c->stage_name[BAZ_MUSIC_STAGE_MERGE] = c->wide_mfma ? "bazmusic::topn_merge_kernel<2>" : "bazwide::topn_wide_kernel";
         *out = c;
         return BAZ_MUSIC_OK;
     }

@@ -71,6 +71,118 @@ __global__ __launch_bounds__(WB) void cov_wide_kernel(const float2* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 1b. The covariance on the fp64 matrix core for 17 <= m <= 32 (round 3).  One wave per item.  The item is split into four
+//     16-row real operands by ANTENNA BLOCK and PART -- Re0 / Im0 = real / imaginary parts of antennas 0..15, Re1 / Im1 of
+//     antennas 16..31 -- so that lane (i, kk) fetches one complex sample (8 B; a wave instruction = 4 runs of 128 B) per block
+//     and k-step, and the four real Grams that make up one entry of R sit in the SAME lane and register of four accumulators:
+//         R[a][b] K = (Re_a Re_b^T + Im_a Im_b^T) + i (Im_a Re_b^T - Re_a Im_b^T)
+//     block (1, 0): 4 products; blocks (0, 0) and (1, 1): 3 each (Re Re^T, Im Im^T, Im Re^T; Re Im^T is the transpose of the
+//     last, fetched through LDS once per item) -> 10 v_mfma_f64_16x16x4 per k-step of 4 time columns.  Only entries a >= b
+//     are formed; R[b][a] is written as the bitwise conjugate.  Rows of antennas >= m re-read antenna m - 1: row r of an
+//     operand only reaches row / column r of a product, which is not stored.  fp32 x fp32 products are exact in fp64, the
+//     sums are fp64 (.cc:77-85); their order differs from cov_wide_kernel's (last-bit differences in R).
+//     The load ring (CH k-steps, re-armed slot by slot) runs across the chunks AND items of a wave.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void cov_wide_mfma_kernel(const float2* __restrict__ in, double2* __restrict__ R,
+                                                               uint32_t batch, uint32_t m, uint32_t K)
+{
+    using bazmusic::v4f64;
+    constexpr int CH = 8;
+    __shared__ double tr[4][2][16 * 17];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, kk = lane >> 4;
+    const uint32_t a0 = (uint32_t)i, a1 = (16u + (uint32_t)i < m) ? 16u + (uint32_t)i : m - 1;
+    const uint32_t mm = m * m;
+    const uint32_t steps = (K + 3) >> 2;            // k-steps of 4 time columns
+    const uint32_t chunks = (K >> 2) / CH;          // whole chunks of CH full k-steps: the ring; the rest one by one
+    const uint32_t stride = gridDim.x * 4;
+    const double dK = (double)K;
+    uint32_t item = blockIdx.x * 4 + wave;
+    if (item >= batch) return;
+    const size_t item_elems = (size_t)K * m;
+    const size_t step_elems = (size_t)4 * m;
+    const float2* __restrict__ src = in + (size_t)item * item_elems + (size_t)kk * m;
+    float2 p0[CH], p1[CH];
+    if (chunks) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            p0[u] = src[(size_t)u * step_elems + a0];
+            p1[u] = src[(size_t)u * step_elems + a1];
+        }
+    }
+    for (; item < batch; item += stride) {
+        const uint32_t nitem = (item + stride < batch) ? item + stride : item;
+        const float2* __restrict__ nsrc = in + (size_t)nitem * item_elems + (size_t)kk * m;
+        v4f64 c00 = {0, 0, 0, 0}, c11 = c00, c10 = c00, d00 = c00, d11 = c00, d10 = c00, err = c00, eii = c00, eir = c00, eri = c00;
+        auto kstep = [&](double r0, double i0, double r1, double i1) {
+            c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(r0, r0, c00, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(i0, i0, c11, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(i0, r0, c10, 0, 0, 0);
+            d00 = __builtin_amdgcn_mfma_f64_16x16x4f64(r1, r1, d00, 0, 0, 0);
+            d11 = __builtin_amdgcn_mfma_f64_16x16x4f64(i1, i1, d11, 0, 0, 0);
+            d10 = __builtin_amdgcn_mfma_f64_16x16x4f64(i1, r1, d10, 0, 0, 0);
+            err = __builtin_amdgcn_mfma_f64_16x16x4f64(r1, r0, err, 0, 0, 0);
+            eii = __builtin_amdgcn_mfma_f64_16x16x4f64(i1, i0, eii, 0, 0, 0);
+            eir = __builtin_amdgcn_mfma_f64_16x16x4f64(i1, r0, eir, 0, 0, 0);
+            eri = __builtin_amdgcn_mfma_f64_16x16x4f64(r1, i0, eri, 0, 0, 0);
+        };
+        for (uint32_t cg = 0; cg < chunks; ++cg) {
+            const float2* __restrict__ rearm = (cg + 1 < chunks) ? src + (size_t)(cg + 1) * CH * step_elems : nsrc;   // wave-uniform
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const double r0 = (double)p0[u].x, i0 = (double)p0[u].y, r1 = (double)p1[u].x, i1 = (double)p1[u].y;   // exact (.cc:77)
+                p0[u] = rearm[(size_t)u * step_elems + a0];
+                p1[u] = rearm[(size_t)u * step_elems + a1];
+                kstep(r0, i0, r1, i1);
+            }
+        }
+        for (uint32_t t = chunks * CH; t < steps; ++t) {                  // K not a multiple of 32: the last k-steps, columns >= K are zero
+            const bool ok = 4 * t + (uint32_t)kk < K;
+            const float2 z = make_float2(0.0f, 0.0f);
+            const float2 q0 = ok ? src[(size_t)t * step_elems + a0] : z;
+            const float2 q1 = ok ? src[(size_t)t * step_elems + a1] : z;
+            kstep((double)q0.x, (double)q0.y, (double)q1.x, (double)q1.y);
+        }
+        // Re Im^T of the two diagonal blocks = (Im Re^T)^T: through LDS (D layout: row = kk + 4 reg, col = i)
+        double* t0 = tr[wave][0];
+        double* t1 = tr[wave][1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            t0[(kk + 4 * r) * 17 + i] = c10[r];
+            t1[(kk + 4 * r) * 17 + i] = d10[r];
+        }
+        bazmusic::wave_lds_fence();
+        double2* __restrict__ Ri = R + (size_t)item * mm;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t row = (uint32_t)(kk + 4 * r), col = (uint32_t)i;
+            if (row >= col) {                                             // diagonal blocks: the lower triangle, mirrored
+                {
+                    const double re = (c00[r] + c11[r]) / dK, im = (c10[r] - t0[col * 17 + row]) / dK;     // .cc:85
+                    Ri[(size_t)row * m + col] = make_double2(re, im);
+                    if (row != col) Ri[(size_t)col * m + row] = make_double2(re, -im);
+                }
+                const uint32_t a = 16u + row, b = 16u + col;
+                if (a < m) {
+                    const double re = (d00[r] + d11[r]) / dK, im = (d10[r] - t1[col * 17 + row]) / dK;
+                    Ri[(size_t)a * m + b] = make_double2(re, im);
+                    if (row != col) Ri[(size_t)b * m + a] = make_double2(re, -im);
+                }
+            }
+            const uint32_t a = 16u + row;                                 // block (1, 0): a = 16 + row > b = col
+            if (a < m) {
+                const double re = (err[r] + eii[r]) / dK, im = (eir[r] - eri[r]) / dK;
+                Ri[(size_t)a * m + col] = make_double2(re, im);
+                Ri[(size_t)col * m + a] = make_double2(re, -im);
+            }
+        }
+        bazmusic::wave_lds_fence();
+        src = nsrc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // 2. EVD.  One workgroup per item; A and V (complex128, row stride m + 1) in LDS.  A sweep = ME - 1 rounds of the circle
 //    method (ME = m rounded up to even): the pairs of a round are disjoint, so all their rotations are computed at once
 //    (one thread per pair), applied to the columns of A and V (A J, V J), then to the rows of A (J^H (A J)).
@@ -506,6 +618,193 @@ __global__ __launch_bounds__(WB) void scan_wide_kernel(const double2* __restrict
         const double strength = 1.0 / (nrm * nrm);
         S[(size_t)item * res + b] = strength;
         if (spec) spec[(size_t)item * res + b] = (float)strength;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3b. The scan on the fp64 matrix core for 17 <= m <= 32, n <= 2 (round 3; scan_wide_kernel above stays for everything
+//     else).  Short form  d = ||a||^2 - sum_c |s_c^H a|^2  (music_kernels.hip.h, SIG): per (item, bin) 2n real inner products
+//     of length 2m -- Re and Im of s_c^H a against the table's real coordinates (re a_0, im a_0, re a_1, ...) -- as a
+//     GEMM [4 items x 4 outputs] x [2m] . [2m x 64 bins] on v_mfma_f64_16x16x4: tile row = item + 4 output, so that the
+//     four outputs of one (item, bin) land in the four accumulator registers of ONE lane (fp64 C/D: row = (lane >> 4) +
+//     4 reg) and d is formed in place.  B = the raw-table image TB (bazmusic's build_TB: columns permuted so that a lane
+//     holds 4 consecutive bins of a 64-bin step -> one 16-B spectrum store, 256 B contiguous per item row); the 4 waves
+//     of a workgroup take 4 x 4 items and share every slice of TB through a double-buffered LDS stage (phases of <= 8
+//     k-steps, KS = ceil(2m / 4) <= 16).  Where the difference is at or below `below` (near a null: it loses ~m eps ||a||^2
+//     absolutely) the reference's literal form sum_k |g_k^H a|^2 (.cc:110-119) runs for that value on the vector unit, from
+//     G as sub_wide / evd_wide wrote it.  Top-n: bazmusic's packed keys; candidates per bin range -> topn_merge_kernel.
+//     With one emitter two of the four outputs are zero rows (half the matrix work is idle; n = 1 is rare at these widths).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool SPEC, bool VEC4>
+__global__ __launch_bounds__(256) void scan_wide_mfma_kernel(const double2* __restrict__ Ssig, const double2* __restrict__ G,
+                                                             const double2* __restrict__ TB, const double* __restrict__ A2p,
+                                                             const float2* __restrict__ TA, float* __restrict__ spec,
+                                                             double* __restrict__ cand, uint32_t batch, uint32_t m, uint32_t n,
+                                                             uint32_t res, uint32_t nsplit, uint32_t keep_mask, double below,
+                                                             unsigned long long* __restrict__ count)
+{
+    using namespace bazmusic;
+    constexpr int SCH = 8;                         // k-steps per staged phase
+    __shared__ v2f64 stage[2][2 * SCH * 64];       // 2 x 16 KiB
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const uint32_t KS = (2 * m + 3) >> 2;          // 9 .. 16
+    const uint32_t pps = (KS + SCH - 1) / SCH;     // phases per step (2)
+    const uint32_t split = blockIdx.x % nsplit;
+    const uint32_t item0 = ((blockIdx.x / nsplit) * 4 + wave) * 4;          // this wave's 4 items
+    const uint32_t nsteps = (res + 63u) >> 6;
+    const uint32_t st_begin = (uint32_t)(((uint64_t)nsteps * split) / nsplit);
+    const uint32_t st_end = (uint32_t)(((uint64_t)nsteps * (split + 1)) / nsplit);
+
+    // A operand: tile row c = (item c & 3, output c >> 2); output o = 2 cI + part: Re (part 0) / Im (part 1) of s_cI^H a,
+    // as coefficients of the real coordinate e = 4 s + g = (antenna e >> 1, re / im)
+    double sa[16];
+    {
+        const uint32_t it_r = item0 + (uint32_t)(c & 3);
+        const uint32_t itr = (it_r < batch) ? it_r : (batch - 1);
+        const int o = c >> 2, cI = o >> 1, part = o & 1;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const uint32_t e = 4u * (uint32_t)s + (uint32_t)g, j = e >> 1;
+            double v = 0.0;
+            if ((uint32_t)s < KS && j < m && (uint32_t)cI < n) {
+                const double2 sv = Ssig[((size_t)itr * n + cI) * m + j];
+                v = part == 0 ? ((e & 1u) ? sv.y : sv.x) : ((e & 1u) ? sv.x : -sv.y);
+            }
+            sa[s] = v;
+        }
+    }
+    const uint32_t it_g = item0 + (uint32_t)g;                              // the item whose d this lane holds
+    const bool row_ok = it_g < batch;
+    const uint32_t itg = row_ok ? it_g : (batch - 1);
+    double key[2] = {key_empty(), key_empty()};
+    const uint32_t nobin = ~keep_mask;
+    uint32_t refined = 0;
+
+    // staging: chunk (2 sl + h) of phase (st, p) = TB chunk ((st * KS + p * SCH + sl) * 2 + h); 4 waves x up to 4 chunks
+    const v2f64* __restrict__ tb = reinterpret_cast<const v2f64*>(TB) + lane;
+    v2f64 sr0 = {0, 0}, sr1 = {0, 0}, sr2 = {0, 0}, sr3 = {0, 0};
+    auto phase_chunks = [&](uint32_t p) -> uint32_t { const uint32_t left = KS - p * SCH; return 2u * (left < (uint32_t)SCH ? left : (uint32_t)SCH); };
+    auto stage_load = [&](uint32_t st, uint32_t p) {
+        const uint32_t nch = phase_chunks(p);
+        const size_t ch0 = ((size_t)st * KS + (size_t)p * SCH) * 2;
+        const uint32_t w = (uint32_t)wave;
+        sr0 = tb[(ch0 + (w < nch ? w : nch - 1)) * 64];
+        sr1 = tb[(ch0 + (w + 4 < nch ? w + 4 : nch - 1)) * 64];
+        sr2 = tb[(ch0 + (w + 8 < nch ? w + 8 : nch - 1)) * 64];
+        sr3 = tb[(ch0 + (w + 12 < nch ? w + 12 : nch - 1)) * 64];
+    };
+    auto stage_store = [&](int b, uint32_t p) {
+        const uint32_t nch = phase_chunks(p);
+        const uint32_t w = (uint32_t)wave;
+        if (w < nch) stage[b][w * 64 + lane] = sr0;
+        if (w + 4 < nch) stage[b][(w + 4) * 64 + lane] = sr1;
+        if (w + 8 < nch) stage[b][(w + 8) * 64 + lane] = sr2;
+        if (w + 12 < nch) stage[b][(w + 12) * 64 + lane] = sr3;
+    };
+    if (st_begin < st_end) {
+        stage_load(st_begin, 0);
+        stage_store(0, 0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (uint32_t st = st_begin; st < st_end; ++st) {
+        v4f64 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0, 0, 0, 0};
+        for (uint32_t p = 0; p < pps; ++p) {
+            const bool last_p = p + 1 == pps;
+            const bool more = !last_p || (st + 1 < st_end);
+            if (more) stage_load(last_p ? st + 1 : st, last_p ? 0u : p + 1);
+            const uint32_t nks = phase_chunks(p) >> 1;                     // k-steps of this phase (wave-uniform)
+            if (p == 0) {
+#pragma unroll
+                for (int sl = 0; sl < SCH; ++sl) {
+                    const v2f64 f01 = stage[buf][(2 * sl) * 64 + lane], f23 = stage[buf][(2 * sl + 1) * 64 + lane];
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[sl], f01.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[sl], f01.y, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[sl], f23.x, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[sl], f23.y, acc[3], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int sl = 0; sl < SCH; ++sl) {
+                    if ((uint32_t)sl < nks) {
+                        const v2f64 f01 = stage[buf][(2 * sl) * 64 + lane], f23 = stage[buf][(2 * sl + 1) * 64 + lane];
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[SCH + sl], f01.x, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[SCH + sl], f01.y, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[SCH + sl], f23.x, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[SCH + sl], f23.y, acc[3], 0, 0, 0);
+                    }
+                }
+            }
+            if (more) stage_store(buf ^ 1, last_p ? 0u : p + 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        // d of (item g, bins 64 st + 4 c + t): ||a||^2 - sum of the four squared outputs
+        const uint32_t bin = st * 64u + 4u * (uint32_t)c;
+        const v4f64 a2v = *reinterpret_cast<const v4f64*>(A2p + (size_t)st * 64 + 4 * c);
+        double d[4];
+        bool low = false;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            d[t] = a2v[t] - ((acc[t][0] * acc[t][0] + acc[t][1] * acc[t][1]) + (acc[t][2] * acc[t][2] + acc[t][3] * acc[t][3]));
+            low |= !(d[t] > below) && (bin + t < res);        // (also a negative or NaN difference, like scan_wide_kernel)
+        }
+        if (__any(low)) {                      // near a null: the reference's literal form for those values (.cc:110-119)
+            const uint32_t nn = m - n;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (!(!(d[t] > below) && (bin + t < res))) continue;
+                double ss = 0.0;
+                for (uint32_t k = 0; k < nn; ++k) {
+                    double cr = 0.0, ci = 0.0;
+                    const double2* __restrict__ gk = G + ((size_t)itg * nn + k) * m;
+                    for (uint32_t i = 0; i < m; ++i) {
+                        const float2 af = TA[(size_t)i * res + bin + t];
+                        const double ar = (double)af.x, ai = (double)af.y;
+                        const double2 gv = gk[i];
+                        cr += gv.x * ar + gv.y * ai;                        // conj(g) a
+                        ci += gv.x * ai - gv.y * ar;
+                    }
+                    ss += cr * cr + ci * ci;
+                }
+                d[t] = ss;
+                refined += row_ok ? 1u : 0u;
+            }
+        }
+        v4f32 sv;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            sv[t] = strength_f32(fabs(d[t]));
+            key_insert_new<2>(key, make_key(d[t], (bin + t < res) ? bin + t : nobin, keep_mask));
+        }
+        if constexpr (SPEC) {
+            if (row_ok) {
+                float* __restrict__ dst = spec + (size_t)it_g * res + bin;
+                if (VEC4 && bin + 3 < res) *reinterpret_cast<v4f32*>(dst) = sv;
+                else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (bin + t < res) dst[t] = sv[t];
+                }
+            }
+        }
+    }
+    if (count) {
+#pragma unroll
+        for (int msk = 1; msk < 64; msk <<= 1) refined += __shfl_xor(refined, msk, 64);
+        if (lane == 0 && refined) atomicAdd(count, (unsigned long long)refined);
+    }
+    key_merge_xor<2>(key, 1);
+    key_merge_xor<2>(key, 2);
+    key_merge_xor<2>(key, 4);
+    key_merge_xor<2>(key, 8);
+    if (c == 0 && row_ok) {
+        cand[((size_t)it_g * nsplit + split) * 2 + 0] = key[0];
+        cand[((size_t)it_g * nsplit + split) * 2 + 1] = key[1];
     }
 }
 

@@ -5,7 +5,7 @@ import numpy as np, torch
 from gr_baz_amd import capi
 from oracle import music_oracle as mo
 dev = torch.device("cuda:0")
-for m, n, K, res, B in ((17, 2, 256, 3600, 4096), (32, 2, 128, 3600, 4096), (32, 2, 128, 3600, 16384), (64, 2, 64, 3600, 2048), (64, 8, 256, 720, 2048)):
+for m, n, K, res, B in ((17, 2, 256, 3600, 4096), (24, 2, 128, 3600, 4096), (32, 1, 128, 3600, 4096), (32, 2, 128, 3600, 4096), (32, 4, 128, 3600, 4096), (32, 2, 128, 3600, 16384), (64, 2, 64, 3600, 2048), (64, 8, 256, 720, 2048)):
     N = m * K
     arr = mo.array_geometry(m)
     table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
