@@ -119,9 +119,9 @@ struct baz_music_ctx {
     size_t peak_spec_cap = 0;     // floats
     size_t chunk_bytes = 0;   // host-fed path: traffic per pipelined chunk (BAZ_MUSIC_CHUNK_MIB); 0 = by buffer kind
     // host-fed path: page ranges of the caller's buffers this context has page-locked (baz_music_host_register)
-    struct HostPin { uintptr_t lo, hi; };                // [lo, hi): the caller's exact bytes
-    std::vector<HostPin> pins;                           // our registrations: disjoint, not touching
-    std::vector<HostPin> refused;                        // requests the runtime refused (not retried)
+    struct HostPin { uintptr_t lo, hi; uint32_t asked; };   // [lo, hi): the caller's exact bytes
+    std::vector<HostPin> pins;                           // the registrations we hold a share of (g_pins): disjoint, not touching
+    std::vector<HostPin> refused;                        // requests the runtime refused (`asked` again so many times since)
     uint64_t pinned_bytes = 0;
     uint64_t pin_limit = 4096ull << 20;                  // BAZ_MUSIC_PIN_LIMIT_MIB
     int auto_pin = 0;                                    // baz_music_set_host_pinning
@@ -1075,14 +1075,50 @@ hipError_t copy_host_range(void* dst, const void* src, size_t bytes, hipMemcpyKi
 // overlaps or touches earlier registrations replaces them by ONE registration of the union (a circular stream buffer
 // is covered after its first few calls); (iii) a request that cannot be locked as a whole (limit, refusal) leaves
 // nothing of itself locked: the registrations it touches are dropped.
+//
+// Registrations are PROCESS-wide objects with a count of the contexts that use them (g_pins): two blocks reading the
+// same stream buffer (a fan-out) share one registration, and it is released when the LAST of them lets go -- a context
+// that stops must not unmap memory another context's copies or kernels are still addressing.
+struct SharedPin { uintptr_t lo, hi; int refs; };
+std::mutex g_pin_mtx;
+std::vector<SharedPin> g_pins;
+constexpr uint32_t REFUSED_RETRY_AFTER = 1024;    // a refused range is tried again after this many requests for it
+
+void shared_pin_release(uintptr_t lo, uintptr_t hi)         // caller holds g_pin_mtx
+{
+    for (size_t i = 0; i < g_pins.size(); ++i)
+        if (g_pins[i].lo == lo && g_pins[i].hi == hi) {
+            if (--g_pins[i].refs <= 0) {
+                if (hipHostUnregister((void*)lo) != hipSuccess) (void)hipGetLastError();   // already unmapped
+                g_pins.erase(g_pins.begin() + i);
+            }
+            return;
+        }
+}
+
 int host_register_locked(baz_music_ctx* c, const void* p, size_t bytes)
 {
     if (!p || !bytes) return BAZ_MUSIC_OK;
     uintptr_t lo = (uintptr_t)p, hi = (uintptr_t)p + bytes;
     for (const auto& pin : c->pins)
         if (pin.lo <= lo && hi <= pin.hi) return BAZ_MUSIC_OK;                       // known (the per-call case)
-    for (const auto& r : c->refused)
-        if (r.lo < hi && lo < r.hi) return BAZ_MUSIC_E_HIP;                          // refused before: not retried
+    for (size_t i = 0; i < c->refused.size(); ++i) {
+        auto& r = c->refused[i];
+        if (r.lo < hi && lo < r.hi) {
+            if (++r.asked < REFUSED_RETRY_AFTER) return BAZ_MUSIC_E_HIP;             // refused not long ago
+            c->refused.erase(c->refused.begin() + i);                                // (a transient refusal must not last until stop())
+            break;
+        }
+    }
+    std::lock_guard<std::mutex> g(g_pin_mtx);
+    for (auto& sp : g_pins)
+        if (sp.lo <= lo && hi <= sp.hi) {                                            // another context's registration: share it
+            if (c->pinned_bytes + (sp.hi - sp.lo) > c->pin_limit) return BAZ_MUSIC_E_UNSUPPORTED;
+            ++sp.refs;
+            c->pins.push_back({sp.lo, sp.hi, 0});
+            c->pinned_bytes += sp.hi - sp.lo;
+            return BAZ_MUSIC_OK;
+        }
     std::vector<size_t> touch;
     uint64_t held = 0;
     for (size_t i = 0; i < c->pins.size(); ++i)
@@ -1096,27 +1132,38 @@ int host_register_locked(baz_music_ctx* c, const void* p, size_t bytes)
         lo = std::min(lo, c->pins[i].lo);
         hi = std::max(hi, c->pins[i].hi);
     }
+    // the union replaces what it touches -- possible only where nobody else holds those registrations, and where no
+    // registration of another context lies inside the union (the runtime would refuse the overlap)
+    for (const auto& sp : g_pins) {
+        if (!(sp.lo < hi && lo < sp.hi)) continue;
+        bool ours = false;
+        for (size_t i : touch) ours = ours || (c->pins[i].lo == sp.lo && c->pins[i].hi == sp.hi);
+        if (!ours || sp.refs > 1) return BAZ_MUSIC_E_UNSUPPORTED;                    // (the copy path splits at the boundaries)
+    }
     const bool fits = c->pinned_bytes - held + (hi - lo) <= c->pin_limit;
     for (size_t k = touch.size(); k-- > 0;) {                                         // back to front: indices stay valid
-        if (hipHostUnregister((void*)c->pins[touch[k]].lo) != hipSuccess) (void)hipGetLastError();
+        shared_pin_release(c->pins[touch[k]].lo, c->pins[touch[k]].hi);
         c->pins.erase(c->pins.begin() + touch[k]);
     }
     c->pinned_bytes -= held;
     if (!fits) return BAZ_MUSIC_E_UNSUPPORTED;
     const hipError_t e = hipHostRegister((void*)lo, hi - lo, hipHostRegisterDefault);
     if (e == hipSuccess) {
-        c->pins.push_back({lo, hi});
+        g_pins.push_back({lo, hi, 1});
+        c->pins.push_back({lo, hi, 0});
         c->pinned_bytes += hi - lo;
         return BAZ_MUSIC_OK;
     }
-    c->refused.push_back({lo, hi});
+    c->refused.push_back({lo, hi, 0});
     return hip_fail(c, e, "hipHostRegister");
 }
 
 void host_unregister_all_locked(baz_music_ctx* c)
 {
-    for (const auto& pin : c->pins)
-        if (hipHostUnregister((void*)pin.lo) != hipSuccess) (void)hipGetLastError();   // already unmapped
+    {
+        std::lock_guard<std::mutex> g(g_pin_mtx);
+        for (const auto& pin : c->pins) shared_pin_release(pin.lo, pin.hi);
+    }
     c->pins.clear();
     c->refused.clear();
     c->pinned_bytes = 0;

@@ -187,16 +187,19 @@ BAZ_MUSIC_API int baz_music_device(const baz_music_ctx* ctx);
  *       registered piecewise, and may map the same physical pages twice like GNU Radio's circular buffers; every
  *       request ends up inside ONE registration, because the runtime rejects copies that are only partly inside one).
  *       0 when the range is locked (or already was, also by its owner: hipHostMalloc / torch pinned memory);
- *       BAZ_MUSIC_E_HIP when the runtime refuses it (remembered, not retried); BAZ_MUSIC_E_UNSUPPORTED when the
- *       context's limit (BAZ_MUSIC_PIN_LIMIT_MIB, default 4096) would be exceeded.  A range that cannot be locked as
- *       a whole is left entirely pageable (registrations it touches are dropped); process() works on it either way.
+ *       BAZ_MUSIC_E_HIP when the runtime refuses it (remembered; asked again after 1,024 further requests for it);
+ *       BAZ_MUSIC_E_UNSUPPORTED when the context's limit (BAZ_MUSIC_PIN_LIMIT_MIB, default 4096) would be exceeded or
+ *       the union would have to replace a registration another context shares.  A range that cannot be locked as
+ *       a whole is left entirely pageable (its own registrations it touches are dropped); process() works on it either way.
+ *       Registrations are process-wide and counted: a range inside another context's registration takes a share of
+ *       that one (two blocks on one stream buffer), and the memory is unlocked when the last holder lets go.
  *   baz_music_set_host_pinning(ctx, 1)       makes baz_music_process() do that for the input and spectrum ranges of
  *       every call before it copies (a lookup per call once they are known).  Default 0: the caller must guarantee that the
  *       memory outlives the registration -- true for scheduler buffers, not for temporaries.
- *   (A call below 16 MiB of traffic whose input and spectrum are page-locked -- by this or by their owner -- runs
+ *   (A call below 64 MiB of traffic (BAZ_MUSIC_SINGLE_MIB) whose input and spectrum are page-locked -- by this or by their owner -- runs
  *   without copies: the kernels address the caller's buffers over PCIe, hipHostGetDevicePointer; BAZ_MUSIC_ZERO_COPY=0
  *   keeps the copies.)
- *   baz_music_host_unregister_all(ctx)       undoes every registration of this context (also done by destroy);
+ *   baz_music_host_unregister_all(ctx)       gives up every registration (share) of this context (also done by destroy);
  *       call it before the buffers are unmapped (the host block does in stop()).
  *   baz_music_host_pinned_bytes(ctx)         bytes this context holds locked. */
 BAZ_MUSIC_API int baz_music_host_register(baz_music_ctx* ctx, const void* p, size_t bytes);

@@ -810,6 +810,36 @@ def test_partly_page_locked_ranges_take_the_copy_path(gpu_device):
         A.host_unregister_all()
 
 
+def test_registrations_are_shared_between_contexts(gpu_device):
+    """two blocks reading ONE stream buffer share its registration, and it survives until the last of
+    them lets go -- the first block's stop() must not unmap memory the second one still addresses over PCIe."""
+    c = mo.make_config("cfg1", 256, seed=36)
+    items = np.ascontiguousarray(c["items"])
+    with _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"]) as ref_ctx:
+        a0, l0, s0 = [x.copy() for x in ref_ctx.process(items)]
+    A = _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"])
+    Bc = _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"])
+    try:
+        assert A.host_register(items) == 0
+        assert Bc.host_register(items[64:192]) == 0                 # inside A's registration: B takes a share of it
+        assert A.host_pinned_bytes() == items.nbytes and Bc.host_pinned_bytes() == items.nbytes
+        A.host_unregister_all()                                      # "block A stops"
+        assert A.host_pinned_bytes() == 0 and Bc.host_pinned_bytes() == items.nbytes
+        for _ in range(3):                                           # B: still no copies, still right
+            a, l, s = Bc.process(items[64:192])
+            assert np.array_equal(a, a0[64:192]) and np.array_equal(l, l0[64:192]) and np.array_equal(s, s0[64:192])
+        assert A.host_register(items[:32]) == 0                      # A comes back: shares B's (whole) registration again
+        assert A.host_pinned_bytes() == items.nbytes
+        Bc.host_unregister_all()
+        a, l, s = A.process(items[:32])
+        assert np.array_equal(a, a0[:32]) and np.array_equal(s, s0[:32])
+        A.host_unregister_all()
+        assert A.host_register(items[:32]) == 0                      # nobody holds it any more: a fresh, exact registration
+        assert A.host_pinned_bytes() == items[:32].nbytes
+    finally:
+        A.close(); Bc.close()
+
+
 def test_caller_stream_ordering(gpu_device):
     """baz_music_set_stream: work is ordered on the caller's stream (here a torch side stream), so torch
     ops enqueued before/after on that stream see consistent data without extra synchronisation."""
