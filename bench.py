@@ -24,7 +24,7 @@ roofline : dominant kernel = the scan (scan_mfma_kernel); achieved = its algorit
            "traffic_stale": true.
 extras   : config.extra carries secondary, clearly labelled measurements (rank 0, N=1): cfg2 WITHOUT the spectrum port
            (the GRC default wiring), the unfavourable cfg2 cases (an incoherent batch with and without the spectrum port,
-           60 dB SNR), cfg3 (8 ant, 4096 samp, 36000 bins: fp64-matrix bound) and the cfg5 chain (16 ant: resampler ->
+           60 dB SNR), cfg3 (8 ant, 4096 samp, 36000 bins: fp64-matrix bound; and without port 2), 32 antennas, and the cfg5 chain (16 ant: resampler ->
            AGC -> MUSIC on one stream), each with its own ms, bound and fraction.
 cpu_baseline : rank 0, N=1 only: oracle/_ref (the reference's own baz_music_doa.cc compiled in place, kind
            "reference") when its prebuilt .so is present, else the plain-C restatement (oracle/music_ref.c, kind
@@ -213,13 +213,20 @@ def extra_music(torch, np, capi, synth, dev, stream, m, nsamples, res, batch, wi
            "scene": scene, "snr_db": snr_db, "values_recomputed_in_literal_form_per_step": refined,
            "algorithmic_bytes_per_item": bpi, "pipeline_hbm_fraction_of_8TBs": batch / ms * 1e3 * bpi / 8e12,
            "stage_ms_per_launch": stage}
-    if with_spectrum or m > 4:     # (without the spectrum port and m <= 4 the scan is the coarse-gated one: its fp64 work is a few tiles)
+    if m > 16:                     # run-time-m kernels; to 32 antennas the short form on the fp64 matrix core (n <= 2)
+        sf = 2.0 * 4 * N_EMIT * m * res * batch / scan_s / 1e12 if scan_s > 0 else 0.0
+        out["scan_form"] = "short form, 4*n*m FMA per (item, bin), scan_wide_mfma_kernel"
+        out["scan_fp64_tflops"] = sf
+        out["scan_frac_of_fp64_matrix_peak"] = sf / FP64_MFMA_PEAK_TF
+    elif with_spectrum or m > 8:   # (without the spectrum port and m <= 8 the scan is the coarse-gated one: its fp64 work is a few tiles)
         out["scan_fp64_tflops"] = scan_tf
         out["scan_frac_of_fp64_matrix_peak"] = scan_tf / FP64_MFMA_PEAK_TF
     else:
-        # two coarse passes of 2 x K = 32 f16 MFMAs per 16 x 16 tile (64 MACs per item, bin and pass), bins padded to 16 x 8
+        # two coarse passes of K = 32 f16 MFMAs per 16 x 16 tile -- 2 (m <= 4: [qh|ql] x [Fh|Fh], [Fl|Fl]) or 3 per group of 32
+        # terms (qh Fh, ql Fh, qh Fl) --, bins padded to 16 x 8
         tiles = -(-res // 128) * 8
-        f16_tf = 2.0 * 2 * 64 * 16 * tiles * batch / scan_s / 1e12 if scan_s > 0 else 0.0
+        nmfma = 2 if m <= 4 else 3 * -(-mm // 32)
+        f16_tf = 2.0 * 2 * 32 * nmfma * 16 * tiles * batch / scan_s / 1e12 if scan_s > 0 else 0.0
         out["scan_kernel"] = "scan_coarse_kernel (f16-matrix-core coarse form gates the fp64 tiles; ang / lvl bit-identical to the full scan)"
         out["scan_f16_tflops"] = f16_tf
         out["scan_frac_of_f16_matrix_peak_2500TF"] = f16_tf / 2500.0
@@ -529,6 +536,14 @@ def main():
                     ("cfg3", lambda: dict(extra_music(torch, np, capi, synth, dev, stream, 8, 4096, 36000, 16384, True, 0.5),
                                           bound="fp64 matrix (scan: 2*m^2 flop per item and bin)",
                                           workload="BASELINE configs[2]: m=8 n=2 nsamples=4096 (K=512) resolution=36000, spectrum wired")),
+                    ("cfg3_without_spectrum_port", lambda: dict(
+                        extra_music(torch, np, capi, synth, dev, stream, 8, 4096, 36000, 16384, False, 0.4),
+                        bound="f16 matrix + LDS (coarse passes of the gated scan); covariance 0.11 ms",
+                        workload="BASELINE configs[2]'s shape with only ang/lvl wired (the helper's default)")),
+                    ("wide_m32_n2", lambda: dict(extra_music(torch, np, capi, synth, dev, stream, 32, 4096, 3600, 4096, True, 0.3),
+                                                 bound="fp64 matrix (covariance and scan on v_mfma_f64_16x16x4; EVD: signal subspace by orthogonal iteration)",
+                                                 workload="32 antennas (run-time-m kernels; the reference has no antenna limit), n=2, "
+                                                          "nsamples=4096 (K=128), resolution=3600, spectrum wired, 4,096 items")),
                     ("cfg5_chain", lambda: dict(extra_cfg5(torch, np, capi, synth, dev, stream, 16384, 0.5),
                                                 workload="BASELINE configs[4] on one GPU: 16 antennas, fractional_resampler_cc "
                                                          "(ratio 1.25) -> agc_cc -> music_doa (m16 n2 N4096 res3600), one stream"))):

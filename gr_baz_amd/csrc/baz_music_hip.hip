@@ -103,7 +103,7 @@ struct baz_music_ctx {
     int fused_covevd = 0;          // m = 4, K % 256 == 0: covariance + EVD in one kernel (BAZ_MUSIC_FUSE=0: lab, two kernels)
     uint32_t covevd_blocks = 512u; // grid of cov4_evd_kernel: the workgroups resident at once (2 per CU)
     uint32_t cov4_resident_blocks = 256u;        // grid of cov4_x4_kernel (persistent waves): one workgroup per CU
-    // coarse-gated scan (scan_coarse_kernels.hip.h): m <= 4, spectrum port not wired
+    // coarse-gated scan (scan_coarse_kernels.hip.h): m <= 8, spectrum port not wired
     uint4* dCS = nullptr;          // per 16-bin tile: f16 hi/lo pieces of the scaled table (B32, B16) + the fp64 B operand (X)
     uint32_t cs_tiles = 0;         // tiles in the image (a multiple of 8)
     CoarseParams cs = {0.0f, 0.0f, 0.0, 0.0, 1};
@@ -290,20 +290,24 @@ bool build_coarse_image(const std::vector<double>& F, uint32_t m, uint32_t res, 
     const double FS = std::ldexp(1.0, fs_exp), SC = 1024.0 * FS;
     cp.sc = SC;
     cp.fmax = fmax;
-    cp.sc_up = std::nextafter((float)(SC * (1.0 + 0x1p-16) * (1.0 + 0x1p-20)), INFINITY);
-    cp.es_factor = std::nextafter((float)(0x1p-16 * fmax * SC), INFINITY);
-    const size_t cbytes = (size_t)CS_C_UNITS * 16, xbytes = (size_t)CS_X_UNITS * 16;
+    const uint32_t ng = (uint32_t)cs_groups((int)m);      // groups of 16 terms (fp64 operand)
+    const double nga = (double)cs_ng((int)m);             // the allowance E = nga 2^-16 (S + D)
+    cp.sc_up = std::nextafter((float)(SC * (1.0 + nga * 0x1p-16) * (1.0 + 0x1p-20)), INFINITY);
+    cp.es_factor = std::nextafter((float)(nga * 0x1p-16 * fmax * SC), INFINITY);
+    const bool wide = m > 4;                              // coarse operands in groups of 32 terms, Fh and Fl 1 KiB each
+    const size_t cbytes = (size_t)cs_c_units((int)m) * 16, xbytes = (size_t)ng * CS_X_UNITS * 16;
     // [C of every tile and of one more (the kernel stages the first tile of the NEXT phase with every phase)][X of every tile]
     img.assign((size_t)(tiles + 1) * cbytes + (size_t)tiles * xbytes, 0);
     for (uint32_t t = 0; t <= tiles; ++t) {
         uint8_t* T = img.data() + (size_t)t * cbytes;
-        uint16_t* fh = reinterpret_cast<uint16_t*>(T);
-        uint16_t* fl = reinterpret_cast<uint16_t*>(T + 512);
-        std::vector<double> xpad(256);
+        std::vector<double> xpad(256 * ng);
         double* X = (t < tiles) ? reinterpret_cast<double*>(img.data() + (size_t)(tiles + 1) * cbytes + (size_t)t * xbytes) : xpad.data();
         for (uint32_t c = 0; c < 16; ++c) {
             const uint32_t bin = 16 * t + c;
-            for (uint32_t e = 0; e < 16; ++e) {
+            for (uint32_t e = 0; e < 16 * ng; ++e) {
+                if (wide && e >= 32u * (uint32_t)cs_groups32((int)m)) continue;
+                uint16_t* fh = reinterpret_cast<uint16_t*>(T + (wide ? (size_t)(e >> 5) * 2048 : 0));          // group: Fh then Fl
+                uint16_t* fl = reinterpret_cast<uint16_t*>(T + (wide ? (size_t)(e >> 5) * 2048 + 1024 : 512));
                 uint16_t hi = 0, lo = 0;
                 if (e < mm) {
                     if (bin >= res) hi = ((e / m) == (e % m)) ? f16_bits(32768.0f) : 0;
@@ -313,12 +317,12 @@ bool build_coarse_image(const std::vector<double>& F, uint32_t m, uint32_t res, 
                         lo = f16_bits(fs - f16_value(hi));
                     }
                 }
-                const uint32_t gb = e >> 3, j = e & 7u;
+                const uint32_t gb = wide ? ((e >> 3) & 3u) : (e >> 3), j = e & 7u;       // entry (gb, c), j: k = 8 gb + j
                 fh[(gb * 16 + c) * 8 + j] = hi;
                 fl[(gb * 16 + c) * 8 + j] = lo;
             }
             for (uint32_t g = 0; g < 4; ++g)
-                for (uint32_t sidx = 0; sidx < 4; ++sidx) {
+                for (uint32_t sidx = 0; sidx < 4 * ng; ++sidx) {
                     const uint32_t e = 4 * sidx + g, lane = g * 16 + c;
                     double v = 0.0;
                     if (e < mm) v = (bin < res) ? F[(size_t)bin * mm + e] : (((e / m) == (e % m)) ? 1e300 : 0.0);
@@ -535,11 +539,15 @@ int ensure_candidates(baz_music_ctx* c, size_t entries)
     return BAZ_MUSIC_OK;
 }
 
-// The coarse-gated scan applies: spectrum port not wired, m <= 4, n <= 4, the table's scale representable.
+// The coarse-gated scan applies: spectrum port not wired, m <= 8, n <= 4, the table's scale representable.
 bool coarse_applies(const baz_music_ctx* c)
 {
-    return c->coarse && c->cs_ok && c->dCS && c->m <= 4 && c->n <= 4 && !c->lab_variant;
+    // (one emitter from 6 antennas on: the full scan is the SHORT form, a quarter of the projector GEMM's work, and the
+    // gated scan's exact tiles are the projector form -- not the same bits; that case keeps the full scan)
+    return c->coarse && c->cs_ok && c->dCS && c->m <= 8 && c->n <= 4 && !c->lab_variant && !short_form_applies(c->m, c->n);
 }
+
+constexpr int coarse_rg_wide(int m, int nmax) { return (cs_groups(m) == 4 && nmax > 2) ? 1 : 2; }   // (what the register file holds without spilling)
 
 // its launch geometry: a workgroup = 4 waves x RG x 16 items; ranges of table phases so that small batches still fill the chip
 constexpr uint32_t COARSE_WANT_BLOCKS = 1024;
@@ -550,8 +558,10 @@ CoarseGeom coarse_geometry(const baz_music_ctx* c, uint32_t batch)
 {
     CoarseGeom G;
     // four row groups per wave where the lists fit the register file beside them (n <= 2), else two
-    const uint32_t rg = (c->coarse_rg == 2 || c->n > 2) ? 2u : 4u;
-    G.tpp = (rg == 2) ? 4u : 8u;
+    // (m >= 5: 2 .. 4 operand groups per tile -- two row groups while the register file holds them, else one)
+    const uint32_t rg = (c->m > 4) ? (uint32_t)coarse_rg_wide((int)c->m, c->n <= 2 ? 2 : 4)
+                                   : ((c->coarse_rg == 2 || c->n > 2) ? 2u : 4u);
+    G.tpp = (rg <= 2) ? 4u : 8u;
     G.nphases = c->cs_tiles / G.tpp;
     G.groups = (batch + 64 * rg - 1) / (64 * rg);
     const uint32_t ns = (COARSE_WANT_BLOCKS + G.groups - 1) / G.groups;
@@ -564,7 +574,7 @@ template <int M, int NMAX>
 int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t batch, float* d_ang,
                   float* d_lvl, float* d_spec)
 {
-    if constexpr (M <= 4 && NMAX <= 4) {
+    if constexpr (M <= 8 && NMAX <= 4) {
         if (!d_spec && coarse_applies(c) && dQ == c->dQ) {
             const CoarseGeom CG = coarse_geometry(c, batch);
             if ((size_t)batch * CG.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;
@@ -575,9 +585,10 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             rf.count = c->dRefined + c->stat_parity;
             rf.A2 = nullptr;
             unsigned long long* stats = c->coarse_stats ? c->dMargin : nullptr;     // lab: exact tile evaluations, summed over launches
-#define BAZ_COARSE_ARGS dim3(CG.groups * CG.nsplit), dim3(256), 0, c->stream, dQ, c->dCS, c->dCS + (size_t)(c->cs_tiles + 1) * CS_C_UNITS, \
+#define BAZ_COARSE_ARGS dim3(CG.groups * CG.nsplit), dim3(256), 0, c->stream, dQ, c->dCS, c->dCS + (size_t)(c->cs_tiles + 1) * cs_c_units(M), \
                         c->dCand, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, stats, nullptr
-            if (CG.tpp == 4) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 2, 4>), BAZ_COARSE_ARGS);
+            if constexpr (M > 4) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, coarse_rg_wide(M, NMAX), 4>), BAZ_COARSE_ARGS);
+            else if (CG.tpp == 4) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 2, 4>), BAZ_COARSE_ARGS);
             else if (c->coarse_lab == 1) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8, false, 1>), BAZ_COARSE_ARGS);
             else if (c->coarse_lab == 2) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8, false, 2>), BAZ_COARSE_ARGS);
             else hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8>), BAZ_COARSE_ARGS);
@@ -678,7 +689,7 @@ uint32_t topn_list_len(uint32_t n) { return n <= 2 ? 2u : (n <= 4 ? 4u : (n <= 8
 size_t cand_entries(const baz_music_ctx* c, uint32_t nb)
 {
     size_t per_item = scan_geometry(nb, c->fb_steps, c->nclass, c->force_nsplit).nsplit;
-    if (c->m <= 4 && c->dCS) per_item = std::max<size_t>(per_item, coarse_geometry(c, nb).nsplit);
+    if (c->m <= 8 && c->dCS) per_item = std::max<size_t>(per_item, coarse_geometry(c, nb).nsplit);
     return (size_t)nb * per_item * topn_list_len(c->n);
 }
 
@@ -693,7 +704,7 @@ size_t cand_entries_upto(const baz_music_ctx* c, uint32_t batch)
     const size_t worst = std::min<size_t>((size_t)batch * cap_split, 16u * want_tasks + (size_t)batch);
     const size_t forced = c->force_nsplit > 0 ? (size_t)batch * std::min<size_t>((size_t)c->force_nsplit, cap_split) : 0;
     // the coarse-gated scan: nsplit = ceil(COARSE_WANT_BLOCKS / ceil(nb / 128)) <= 16  ->  nb * nsplit <= 128 * WANT + nb
-    const size_t coarse = (c->m <= 4) ? std::min<size_t>((size_t)batch * 16u, 128u * COARSE_WANT_BLOCKS + (size_t)batch) : 0;
+    const size_t coarse = (c->m <= 8) ? std::min<size_t>((size_t)batch * 16u, 128u * COARSE_WANT_BLOCKS + (size_t)batch) : 0;
     return std::max(std::max(std::max(worst, forced), coarse), (size_t)batch) * topn_list_len(c->n);
 }
 
@@ -1344,9 +1355,9 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (const char* v = getenv("BAZ_MUSIC_COARSE_RG")) c->coarse_rg = atoi(v);                // lab
         if (const char* v = getenv("BAZ_MUSIC_COARSE_LAB")) c->coarse_lab = atoi(v);              // lab
         if (const char* v = getenv("BAZ_MUSIC_COARSE_STATS")) c->coarse_stats = atoi(v);          // lab
-        if (m <= 4) {
+        if (m <= 8) {
             c->cs_tiles = round_up((resolution + 15) / 16, 8);
-            if (hipMalloc((void**)&c->dCS, ((size_t)(c->cs_tiles + 1) * CS_C_UNITS + (size_t)c->cs_tiles * CS_X_UNITS) * 16) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+            if (hipMalloc((void**)&c->dCS, ((size_t)(c->cs_tiles + 1) * cs_c_units((int)m) + (size_t)c->cs_tiles * CS_X_UNITS * cs_groups((int)m)) * 16) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMalloc((void**)&c->dMargin, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMemset(c->dMargin, 0, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         }
@@ -1753,7 +1764,7 @@ int baz_music_debug_coarse_margin(baz_music_ctx* c, const void* d_in, uint32_t b
     if (!c || !d_in || !worst || batch == 0) return BAZ_MUSIC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
-    if (c->wide || c->m > 4 || c->n > 4 || !c->cs_ok) return BAZ_MUSIC_E_UNSUPPORTED;
+    if (c->wide || c->m > 8 || c->n > 4 || !c->cs_ok) return BAZ_MUSIC_E_UNSUPPORTED;
     int r = ensure_workspace(c, batch);
     if (r) return r;
     r = reserve_candidates(c, batch);
@@ -1768,19 +1779,27 @@ int baz_music_debug_coarse_margin(baz_music_ctx* c, const void* d_in, uint32_t b
     HIP_TRY(c, hipMemsetAsync(c->dMargin, 0, sizeof(unsigned long long), c->stream));
     ScanRefine rf;
     rf.Gs = nullptr; rf.TB = c->dTB + c->tb_step_elems; rf.below = 0.0; rf.count = nullptr; rf.A2 = nullptr;
-    const uint32_t groups = (batch + 255) / 256, nph = c->cs_tiles / 8;
+    const bool big = c->m > 4;                   // (m >= 5: the RG = 2, TPP = 4 instantiation, like the scan's)
+    const uint32_t per_group = big ? 64u * (uint32_t)coarse_rg_wide((int)c->m, 2) : 256u;
+    const uint32_t groups = (batch + per_group - 1) / per_group, nph = c->cs_tiles / (big ? 4 : 8);
     float* d_dump = nullptr;                     // lab (BAZ_MUSIC_DEBUG_DUMP=<file>): every ratio, [item][bin] float32
     const char* dump_path = getenv("BAZ_MUSIC_DEBUG_DUMP");
     if (dump_path && hipMalloc((void**)&d_dump, (size_t)batch * c->res * sizeof(float)) != hipSuccess) d_dump = nullptr;
     if (d_dump) (void)hipMemsetAsync(d_dump, 0, (size_t)batch * c->res * sizeof(float), c->stream);
-#define BAZ_VAL(MV, NV)                                                                                                     \
-    hipLaunchKernelGGL((scan_coarse_kernel<MV, NV, 4, 8, true>), dim3(groups), dim3(256), 0, c->stream, c->dQ, c->dCS, \
-                       c->dCS + (size_t)(c->cs_tiles + 1) * CS_C_UNITS, c->dCand,                                                       \
+#define BAZ_VAL(MV, NV, RGV, TPV)                                                                                           \
+    hipLaunchKernelGGL((scan_coarse_kernel<MV, NV, RGV, TPV, true>), dim3(groups), dim3(256), 0, c->stream, c->dQ, c->dCS, \
+                       c->dCS + (size_t)(c->cs_tiles + 1) * cs_c_units(MV), c->dCand,                                                  \
                        batch, c->res, qstride, nph, 1u, c->keep_mask, c->n, rf, c->cs, c->dMargin, d_dump)
     const bool n2 = c->n <= 2;
-    if (c->m == 2) { BAZ_VAL(2, 2); }
-    else if (c->m == 3) { if (n2) BAZ_VAL(3, 2); else BAZ_VAL(3, 4); }
-    else { if (n2) BAZ_VAL(4, 2); else BAZ_VAL(4, 4); }
+    switch (c->m) {
+        case 2: BAZ_VAL(2, 2, 4, 8); break;
+        case 3: if (n2) BAZ_VAL(3, 2, 4, 8); else BAZ_VAL(3, 4, 4, 8); break;
+        case 4: if (n2) BAZ_VAL(4, 2, 4, 8); else BAZ_VAL(4, 4, 4, 8); break;
+        case 5: BAZ_VAL(5, 2, coarse_rg_wide(5, 2), 4); break;         // (the lists are not used by the validation build)
+        case 6: BAZ_VAL(6, 2, coarse_rg_wide(6, 2), 4); break;
+        case 7: BAZ_VAL(7, 2, coarse_rg_wide(7, 2), 4); break;
+        default: BAZ_VAL(8, 2, coarse_rg_wide(8, 2), 4); break;
+    }
 #undef BAZ_VAL
     HIP_TRY(c, hipGetLastError());
     unsigned long long packed = 0;

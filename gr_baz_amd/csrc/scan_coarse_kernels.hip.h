@@ -55,8 +55,19 @@ namespace bazmusic {
 typedef _Float16 v4f16 __attribute__((ext_vector_type(4)));
 typedef _Float16 v8f16 __attribute__((ext_vector_type(8)));
 
-constexpr int CS_C_UNITS = 64;            // 16-B units of a tile's coarse operands: 512 B (Fh) + 512 B (Fl)
-constexpr int CS_X_UNITS = 128;           // ... of its fp64 operand: 2048 B
+constexpr int CS_C_UNITS = 64;            // 16-B units of a tile's coarse operands per GROUP of 16 terms: 512 B (Fh) + 512 B (Fl)
+constexpr int CS_X_UNITS = 128;           // ... of its fp64 operand per group: 2048 B (4 k-steps)
+// m^2 <= 16 terms are one group.  5 <= m <= 8 (25 .. 64 terms): the exact form takes 4 cs_groups(m) fp64 k-steps, and the
+// coarse form works in NG = cs_groups32(m) groups of 32 terms with the two pieces of q as SEPARATE A operands:
+//     per group  qh Fh, ql Fh (one B operand [Fh of 32 terms], read from LDS once) and qh Fl   -- 3 NG MFMAs per tile,
+// all on one accumulator; ql Fl (<= 2^-22 S) is left to the budget.  Per tile 2 NG KiB of LDS reads against 4 NG KiB for
+// the [F | F] form, which made the LDS, not the matrix core, the bound (measured at m = 8: 0.52 ms against 0.26 ms of MFMA
+// issue).  Budget: representation <= 1.75 2^-20 S, accumulation <= (96 NG + 3 NG) 2^-23 (S + thr)  ->  E = NG 2^-16 (S + D).
+constexpr int CS_C32_UNITS = 128;         // 16-B units of a tile's coarse operands per group of 32 terms: 1 KiB (Fh) + 1 KiB (Fl)
+constexpr int cs_groups(int m) { return (m * m + 15) / 16; }
+constexpr int cs_groups32(int m) { return (m * m + 31) / 32; }
+constexpr int cs_c_units(int m) { return m <= 4 ? CS_C_UNITS : cs_groups32(m) * CS_C32_UNITS; }    // per tile
+constexpr int cs_ng(int m) { return m <= 4 ? 1 : cs_groups32(m); }                                  // the NG of the allowance
 
 struct CoarseParams {
     float sc_up;        // SC (1 + 2^-16) rounded up: threshold scale, d units -> coarse units
@@ -142,7 +153,7 @@ __device__ __forceinline__ float row_kth_smallest(float v, const uint32_t k)
 // descending slope of the spectrum EVERY tile beats the list and fires (measured: 0.28 ms per 262,144 coherent cfg2 items,
 // and 0.93 ms -- slower than the full scan -- when every item of a wave has its own scene).  PASS 2: the gated walk.
 template <int M, int NMAX, int RG, int TPP, bool VAL = false, int LAB = 0>
-__global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(const double* __restrict__ Qs,
+__global__ __launch_bounds__(256, (RG <= 2 && M <= 4) ? 3 : 2) void scan_coarse_kernel(const double* __restrict__ Qs,
                                                                              const uint4* __restrict__ imgC,
                                                                              const uint4* __restrict__ imgX,
                                                                              double* __restrict__ cand, uint32_t batch,
@@ -153,13 +164,20 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
                                                                              float* __restrict__ val_dump = nullptr)
 {
     constexpr int MM = M * M;
-    static_assert(MM <= 16, "one K = 16 slab: m <= 4");
+    constexpr int NGC = cs_groups(M);                  // groups of 16 terms (4 fp64 k-steps each)
+    constexpr bool WIDE = MM > 16;                     // 5 <= m <= 8: the coarse operands in groups of 32 terms (see above)
+    constexpr int NG2 = WIDE ? cs_groups32(M) : 1;
+    static_assert(MM <= 64, "m <= 8");
+    constexpr int TC_UNITS = WIDE ? NG2 * CS_C32_UNITS : CS_C_UNITS, TX_UNITS = NGC * CS_X_UNITS;   // per tile
+    // One group: the fp64 operands of the phase's tiles are staged through LDS beside the coarse ones.  More (m >= 5): an
+    // exact tile reads its 2 NG KiB from the image in L2 when it fires (a few per cent of the tiles; LDS holds C only).
+    constexpr bool XLDS = (NGC == 1);
     // 16-B units per staged phase, both multiples of 64: the C operands of TPP + 1 tiles -- the phase's own and the FIRST tile
     // of the next phase, whose MFMAs are issued while this phase's last tile is reduced (the software pipeline below runs
     // across the phase boundary) -- and the X operands of TPP tiles
-    constexpr int C_UNITS = (TPP + 1) * CS_C_UNITS, X_UNITS = TPP * CS_X_UNITS;
+    constexpr int C_UNITS = (TPP + 1) * TC_UNITS, X_UNITS = XLDS ? TPP * TX_UNITS : 0;
     constexpr int C_CHUNKS = C_UNITS / 64, X_CHUNKS = X_UNITS / 64;         // 1-KiB wave loads per phase
-    __shared__ uint4 stage[2][C_UNITS + X_UNITS];                            // per buffer: [B32 | B16 of TPP tiles][X of TPP tiles]
+    __shared__ uint4 stage[2][C_UNITS + X_UNITS];                            // per buffer: [Fh | Fl of TPP + 1 tiles][X of TPP tiles]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -171,8 +189,10 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
     const uint32_t ph_end = (uint32_t)(((uint64_t)nphases * (split + 1)) / nsplit);
 
     // ---- operands -------------------------------------------------------------------------------------------------
-    double qa[RG][4];          // exact A: q[item of row c][e = 4 s + g]   (natural row order)
-    v8f16 a32[RG];             // coarse A, K = 32: row c = item pi(c); k = 8 g + j: e = k & 15, piece = k >> 4 (hi | lo)
+    double qa[RG][XLDS ? 4 : 1];   // exact A: q[item of row c][e = 4 s + g]   (natural row order; m >= 5: fetched when a tile fires)
+    // coarse A, K = 32, row c = item pi(c), k = 8 g + j.  m <= 4: ONE operand [qh | ql], e = k & 15, piece = k >> 4 (ah[.][0]).
+    // m >= 5: per group G of 32 terms the two pieces as separate operands, e = 32 G + k (ah, al).
+    v8f16 ah[RG][NG2], al[RG][WIDE ? NG2 : 1];
     v4f32 es[RG], negthr[RG];  // per accumulator register r (item g + 4 r): error allowance and -threshold, coarse units
     double key[VAL ? 1 : RG][4][NMAX];
     bool row_ok[RG][4];
@@ -181,31 +201,38 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
         const uint32_t it_n = item0 + 16 * q + (uint32_t)c;                          // natural row c
         const uint32_t itn = (it_n < batch) ? it_n : (batch - 1);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < (XLDS ? 4 : 1); ++s) {
             const int e = 4 * s + g;
-            qa[q][s] = (e < MM) ? Qs[(size_t)e * qstride + itn] : 0.0;
+            qa[q][s] = (XLDS && e < MM) ? Qs[(size_t)e * qstride + itn] : 0.0;
         }
         const uint32_t it_p = item0 + 16 * q + (uint32_t)((c >> 2) + 4 * (c & 3));  // permuted row c
         const uint32_t itp = (it_p < batch) ? it_p : (batch - 1);
-        // this lane's 8 coefficients e = (8 g + j) & 15 of the permuted item; lanes g = 0, 1 together cover all 16
-        float qsf[8], asum = 0.0f;
+        // this lane's 8 coefficients per group of the permuted item: m <= 4: e = (8 g + j) & 15 (lanes g = 0, 1 together cover
+        // all 16); m >= 5: e = 32 G + 8 g + j (the four g cover a group)
+        float qsf[NG2][8], asum = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int e = (8 * g + j) & 15;
-            const double qv = (e < MM) ? Qs[(size_t)e * qstride + itp] : 0.0;
-            qsf[j] = (float)(qv * 1024.0);
-            asum += fabsf((float)qv);
-        }
-        asum += __shfl_xor(asum, 16, 64);                     // sum_e |q_e| of the permuted item (rows g = 0,1 / 2,3 agree)
+        for (int G = 0; G < NG2; ++G)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = WIDE ? 32 * G + 8 * g + j : ((8 * g + j) & 15);
+                const double qv = (e < MM) ? Qs[(size_t)e * qstride + itp] : 0.0;
+                qsf[G][j] = (float)(qv * 1024.0);
+                asum += fabsf((float)qv);
+            }
+        asum += __shfl_xor(asum, 16, 64);                     // sum_e |q_e| of the permuted item (m <= 4: rows g = 0,1 / 2,3 agree)
+        if constexpr (WIDE) asum += __shfl_xor(asum, 32, 64);
         // a projector's coefficients are <= 2 in magnitude; anything else (non-finite or garbage q) never gates
-        const bool sane = asum <= 64.0f;                      // false for NaN
+        const bool sane = asum <= 4.0f * (float)MM;           // false for NaN
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = sane ? qsf[j] : 0.0f;
-            const _Float16 h = (_Float16)v;
-            const _Float16 l = (_Float16)(v - (float)h);      // exact difference (11-bit piece of a 24-bit value)
-            a32[q][j] = (g < 2) ? h : l;                      // k < 16: hi, k >= 16: lo
-        }
+        for (int G = 0; G < NG2; ++G)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = sane ? qsf[G][j] : 0.0f;
+                const _Float16 h = (_Float16)v;
+                const _Float16 l = (_Float16)(v - (float)h);  // exact difference (11-bit piece of a 24-bit value)
+                if constexpr (WIDE) { ah[q][G][j] = h; al[q][G][j] = l; }
+                else ah[q][0][j] = (g < 2) ? h : l;           // k < 16: hi, k >= 16: lo
+            }
         // allowance of item g + 4 r = permuted row 4 g + r: held by the lanes with c = 4 g + r
         const float es_row = sane ? asum * cp.es_factor * 1.0001f : __builtin_inff();
 #pragma unroll
@@ -234,7 +261,7 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
 
     // ---- table staging: L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no registers) ----------
     auto stage_load = [&](uint32_t ph, int b, const bool with_x) {
-        const uint4* __restrict__ sc = imgC + (size_t)ph * (TPP * CS_C_UNITS) + lane;      // (the C array carries one tile of padding)
+        const uint4* __restrict__ sc = imgC + (size_t)ph * (TPP * TC_UNITS) + lane;        // (the C array carries one tile of padding)
 #pragma unroll
         for (int i = 0; i < (C_CHUNKS + 3) / 4; ++i) {
             const int j = i * 4 + wave;                        // wave-uniform: chunk j of the phase
@@ -242,7 +269,7 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sc + j * 64),
                                                  (__attribute__((address_space(3))) void*)(&stage[b][j * 64]), 16, 0, 0);
         }
-        if (with_x) {
+        if (XLDS && with_x) {
             const uint4* __restrict__ sx = imgX + (size_t)ph * X_UNITS + lane;
 #pragma unroll
             for (int i = 0; i < (X_CHUNKS + 3) / 4; ++i) {
@@ -260,21 +287,48 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
     // two MFMAs runs while the matrix pipe is busy, and VALU work placed behind them waits for them.  Two register sets (A,
     // B) alternate, so nothing is copied.  (Measured before: MFMA pipe 49 % busy, 30 % of the wave cycles in issue stalls;
     // profiles/r03_coarse_scan_pmc_first.txt.)
-    auto ld_b = [&](const char* __restrict__ T0, int t, v8f16& bh, v8f16& bl) __attribute__((always_inline)) {
-        const char* __restrict__ T = T0 + t * (CS_C_UNITS * 16);
-        bh = *reinterpret_cast<const v8f16*>(T);
-        bl = *reinterpret_cast<const v8f16*>(T + 512);
+    struct BOp { v8f16 h[1], l[1]; };
+    // One group: the B operands of the NEXT tile are fetched into a second register set a tile ahead (ld_b).  More groups:
+    // they are fetched inside issue(), group by group (8 .. 16 KiB of registers would not fit beside two row groups, and
+    // with one row group the LDS reads -- 2 NG KiB per wave and tile for 2 NG MFMAs -- bound the kernel, not the matrix core).
+    constexpr bool BAHEAD = !WIDE;
+    auto ld_b = [&](const char* __restrict__ T0, int t, BOp& b) __attribute__((always_inline)) {
+        if constexpr (BAHEAD) {
+            const char* __restrict__ T = T0 + t * (TC_UNITS * 16);
+            b.h[0] = *reinterpret_cast<const v8f16*>(T);
+            b.l[0] = *reinterpret_cast<const v8f16*>(T + 512);
+        }
     };
-    auto issue = [&](v4f32 (&u)[RG], const v8f16 bh, const v8f16 bl, const bool with_thr) __attribute__((always_inline)) {
+    auto issue = [&](v4f32 (&u)[RG], const BOp& b, const char* __restrict__ T0, int t, const bool with_thr) __attribute__((always_inline)) {
+        if constexpr (!WIDE) {
 #pragma unroll
-        for (int q = 0; q < RG; ++q)
-            u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[q], bh, with_thr ? negthr[q] : (v4f32){0, 0, 0, 0}, 0, 0, 0);
+            for (int q = 0; q < RG; ++q)
+                u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q][0], b.h[0], with_thr ? negthr[q] : (v4f32){0, 0, 0, 0}, 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < RG; ++q) u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[q], bl, u[q], 0, 0, 0);
+            for (int q = 0; q < RG; ++q) u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q][0], b.l[0], u[q], 0, 0, 0);
+        } else {
+            // per group: qh Fh, ql Fh on one B operand, then qh Fl (ql Fl is below the budget: <= 2^-22 S)
+            const char* __restrict__ T = T0 + t * (TC_UNITS * 16);
+#pragma unroll
+            for (int G = 0; G < NG2; ++G) {
+                const v8f16 bh = *reinterpret_cast<const v8f16*>(T + G * 2048);
+#pragma unroll
+                for (int q = 0; q < RG; ++q)
+                    u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q][G], bh, (G > 0) ? u[q] : (with_thr ? negthr[q] : (v4f32){0, 0, 0, 0}), 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < RG; ++q) u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[q][G], bh, u[q], 0, 0, 0);
+            }
+#pragma unroll
+            for (int G = 0; G < NG2; ++G) {
+                const v8f16 bl = *reinterpret_cast<const v8f16*>(T + G * 2048 + 1024);
+#pragma unroll
+                for (int q = 0; q < RG; ++q) u[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q][G], bl, u[q], 0, 0, 0);
+            }
+        }
     };
-    auto interleave = [&]() __attribute__((always_inline)) {      // 2 RG MFMAs, two VALU instructions behind each
+    auto interleave = [&]() __attribute__((always_inline)) {      // the tile's MFMAs, two VALU instructions behind each
 #pragma unroll
-        for (int i = 0; i < 2 * RG; ++i) {
+        for (int i = 0; i < (WIDE ? 3 * NG2 : 2) * RG; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
         }
@@ -301,24 +355,24 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
         if (ph_begin < ph_end) stage_load(ph_begin, 0, false);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        v8f16 bhA, blA, bhB, blB;
+        BOp bA, bB;
         v4f32 uA[RG], uB[RG];
         for (uint32_t ph = ph_begin; ph < ph_end; ++ph) {
             if (ph + 1 < ph_end) stage_load(ph + 1, buf ^ 1, false);
-            const char* __restrict__ T0 = reinterpret_cast<const char*>(&stage[buf][0]) + ((g & 1) * 16 + c) * 16;
+            const char* __restrict__ T0 = reinterpret_cast<const char*>(&stage[buf][0]) + (((WIDE ? g : (g & 1)) * 16 + c) * 16);
             if (ph == ph_begin) {                                              // prologue of the pass: tile 0
-                ld_b(T0, 0, bhA, blA);
-                issue(uA, bhA, blA, false);
+                ld_b(T0, 0, bA);
+                issue(uA, bA, T0, 0, false);
             }
-            ld_b(T0, 1, bhB, blB);
+            ld_b(T0, 1, bB);
 #pragma nounroll
             for (int tl = 0; tl < TPP; tl += 2) {
-                issue(uB, bhB, blB, false);                                    // tile tl + 1 ...
-                ld_b(T0, tl + 2, bhA, blA);
+                issue(uB, bB, T0, tl + 1, false);                              // tile tl + 1 ...
+                ld_b(T0, tl + 2, bA);
                 reduce1(uA);                                                   // ... while tile tl is reduced
                 interleave();
-                issue(uA, bhA, blA, false);                                    // tile tl + 2 (= tile 0 of the next phase at the end) ...
-                ld_b(T0, (tl + 3 <= TPP) ? tl + 3 : TPP, bhB, blB);
+                issue(uA, bA, T0, tl + 2, false);                              // tile tl + 2 (= tile 0 of the next phase at the end) ...
+                ld_b(T0, (tl + 3 <= TPP) ? tl + 3 : TPP, bB);
                 reduce1(uB);                                                   // ... while tile tl + 1 is reduced
                 interleave();
             }
@@ -348,20 +402,38 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
             if (!VAL && !__any(mnq <= 0)) continue;
             if constexpr (!VAL) ++fired;
             // exact form: scan_mfma_kernel's projector GEMM for this 16 x 16 tile (same k order, same operands)
-            const v2f64 x01 = *reinterpret_cast<const v2f64*>(X + lane * 2);
-            const v2f64 x23 = *reinterpret_cast<const v2f64*>(X + 128 + lane * 2);
             v4f64 acc = {0, 0, 0, 0};
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][0], x01.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][1], x01.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][2], x23.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][3], x23.y, acc, 0, 0, 0);
+            if constexpr (XLDS) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const v2f64 x = *reinterpret_cast<const v2f64*>(X + s2 * 128 + lane * 2);       // k-steps 2 s2, 2 s2 + 1
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][2 * s2], x.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][2 * s2 + 1], x.y, acc, 0, 0, 0);
+                }
+            } else {
+                // both operands from L2: the item's coefficients (natural row c) and the tile's fp64 image
+                const uint32_t it_n = item0 + 16 * q + (uint32_t)c;
+                const double* __restrict__ qp = Qs + ((it_n < batch) ? it_n : (batch - 1)) + (size_t)g * qstride;
+#pragma unroll
+                for (int s2 = 0; s2 < 2 * NGC; ++s2) {
+                    const v2f64 x = *reinterpret_cast<const v2f64*>(X + s2 * 128 + lane * 2);
+                    if (4 * (2 * s2) < MM) {
+                        const double a = (4 * (2 * s2) + g < MM) ? qp[(size_t)(4 * (2 * s2)) * qstride] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x.x, acc, 0, 0, 0);
+                    }
+                    if (4 * (2 * s2 + 1) < MM) {
+                        const double a = (4 * (2 * s2 + 1) + g < MM) ? qp[(size_t)(4 * (2 * s2 + 1)) * qstride] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x.y, acc, 0, 0, 0);
+                    }
+                }
+            }
             if constexpr (VAL) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // S of item g + 4 r in d units: es / (2^-16 SC 1.0001); allowance 2^-16 (S + |d|)
                     const double S = (double)es[q][r] / (1.0001 * (double)cp.es_factor) * cp.fmax;
                     const double err = fabs((double)u[q][r] / cp.sc - acc[r]);
-                    const double allow = 0x1p-16 * (S + fabs(acc[r]));
+                    const double allow = (double)NG2 * 0x1p-16 * (S + fabs(acc[r]));
                     const bool counts = bin < res && row_ok[q][r] && S < 1e30 && allow > 0.0 && err == err;
                     const float ratio = counts ? (float)(err / allow) : 0.0f;
                     if (val_dump && bin < res && row_ok[q][r])       // lab: every ratio, [item][bin]
@@ -422,31 +494,33 @@ __global__ __launch_bounds__(256, (RG <= 2) ? 3 : 2) void scan_coarse_kernel(con
     if (ph_begin < ph_end) stage_load(ph_begin, buf, LAB != 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    v8f16 bhA, blA, bhB, blB;
+    BOp bA, bB;
     v4f32 uA[RG], uB[RG];
     for (uint32_t ph = ph_begin; ph < ph_end; ++ph) {
         if (ph + 1 < ph_end) stage_load(ph + 1, buf ^ 1, LAB != 2);   // lands while this phase's tiles run (lab 2: no X operands)
-        const char* __restrict__ T0 = reinterpret_cast<const char*>(&stage[buf][0]) + ((g & 1) * 16 + c) * 16;
-        const char* __restrict__ X0 = reinterpret_cast<const char*>(&stage[buf][C_UNITS]);
+        const char* __restrict__ T0 = reinterpret_cast<const char*>(&stage[buf][0]) + (((WIDE ? g : (g & 1)) * 16 + c) * 16);
+        // the fp64 operands of this phase's tiles: staged (one group) or where the image has them (L2)
+        const char* __restrict__ X0 = XLDS ? reinterpret_cast<const char*>(&stage[buf][C_UNITS])
+                                           : reinterpret_cast<const char*>(imgX + (size_t)ph * (TPP * TX_UNITS));
         if (ph == ph_begin) {                                                  // prologue of the pass: tile 0
-            ld_b(T0, 0, bhA, blA);
-            issue(uA, bhA, blA, !VAL);
+            ld_b(T0, 0, bA);
+            issue(uA, bA, T0, 0, !VAL);
         }
-        ld_b(T0, 1, bhB, blB);
+        ld_b(T0, 1, bB);
 #pragma nounroll
         for (int tl = 0; tl < TPP; tl += 2) {
-            issue(uB, bhB, blB, !VAL);                                         // tile tl + 1 (with the thresholds as they are now)
-            ld_b(T0, tl + 2, bhA, blA);
+            issue(uB, bB, T0, tl + 1, !VAL);                                   // tile tl + 1 (with the thresholds as they are now)
+            ld_b(T0, tl + 2, bA);
             const int mA = vote(uA);
             interleave();
             if constexpr (LAB >= 1) fired += (mA <= 0) ? 1u : 0u;              // lab: the cost of the coarse passes alone (results are wrong)
-            else if (VAL || __any(mA <= 0)) exact_tile(uA, ph * TPP + (uint32_t)tl, X0 + tl * (CS_X_UNITS * 16));
-            issue(uA, bhA, blA, !VAL);                                         // tile tl + 2 (= tile 0 of the next phase at the end)
-            ld_b(T0, (tl + 3 <= TPP) ? tl + 3 : TPP, bhB, blB);
+            else if (VAL || __any(mA <= 0)) exact_tile(uA, ph * TPP + (uint32_t)tl, X0 + tl * (TX_UNITS * 16));
+            issue(uA, bA, T0, tl + 2, !VAL);                                   // tile tl + 2 (= tile 0 of the next phase at the end)
+            ld_b(T0, (tl + 3 <= TPP) ? tl + 3 : TPP, bB);
             const int mB = vote(uB);
             interleave();
             if constexpr (LAB >= 1) fired += (mB <= 0) ? 1u : 0u;
-            else if (VAL || __any(mB <= 0)) exact_tile(uB, ph * TPP + (uint32_t)tl + 1u, X0 + (tl + 1) * (CS_X_UNITS * 16));
+            else if (VAL || __any(mB <= 0)) exact_tile(uB, ph * TPP + (uint32_t)tl + 1u, X0 + (tl + 1) * (TX_UNITS * 16));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

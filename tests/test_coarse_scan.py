@@ -1,5 +1,5 @@
 """The coarse-gated scan (gr_baz_amd/csrc/scan_coarse_kernels.hip.h): what runs when the spectrum port is NOT wired
-(music_doa_helper's default output_spectrum=False, /root/reference/python/music_doa_helper.py:49,61-64) and m <= 4.
+(music_doa_helper's default output_spectrum=False, /root/reference/python/music_doa_helper.py:49,61-64) and m <= 8.
 Only the top-n list is observable then (lib/baz_music_doa.cc:97-99,129-155); the kernel skips bin tiles that provably
 cannot hold a member of it.  Three things are pinned here, all on the GPU through the C-ABI:
   1. ang / lvl are BIT-IDENTICAL to the full fp64 scan of the same build (BAZ_MUSIC_COARSE=0), on coherent and incoherent
@@ -58,7 +58,10 @@ def _both(monkeypatch, m, n, nsamples, res, table, items, gpu_device, env=None):
 @pytest.mark.parametrize("incoherent", [False, True])
 @pytest.mark.parametrize("snr", [0.0, 10.0, 20.0, 40.0, 70.0, 90.0])
 @pytest.mark.parametrize("m,n,nsamples,res,batch", [(4, 2, 1024, 3600, 333), (4, 1, 256, 360, 257), (4, 3, 256, 1000, 130),
-                                                    (3, 2, 96, 721, 200), (3, 1, 96, 64, 70), (2, 1, 64, 90, 65)])
+                                                    (3, 2, 96, 721, 200), (3, 1, 96, 64, 70), (2, 1, 64, 90, 65),
+                                                    # 5 .. 8 antennas: 2 .. 4 operand groups per tile, fp64 operands from L2
+                                                    (8, 2, 1024, 3600, 150), (8, 3, 512, 1000, 70), (7, 2, 280, 721, 130), (5, 1, 160, 200, 40),
+                                                    (6, 2, 384, 500, 200), (5, 4, 320, 360, 100), (5, 2, 320, 64, 65)])
 def test_coarse_gated_scan_equals_the_full_scan(m, n, nsamples, res, batch, snr, incoherent, gpu_device, monkeypatch):
     table, items = _scene(m, n, nsamples, res, batch, snr, 9000 + int(snr) + 13 * m + n, incoherent)
     (a1, l1, r1), (a0, l0, r0) = _both(monkeypatch, m, n, nsamples, res, table, items, gpu_device)
@@ -123,9 +126,10 @@ def test_gated_scan_with_an_arbitrary_table(gpu_device, monkeypatch):
 
 
 @pytest.mark.parametrize("snr", [0.0, 20.0, 60.0])
-@pytest.mark.parametrize("m,n,nsamples,res", [(4, 2, 1024, 3600), (4, 3, 256, 1000), (3, 1, 96, 721), (2, 1, 64, 90)])
+@pytest.mark.parametrize("m,n,nsamples,res", [(4, 2, 1024, 3600), (4, 3, 256, 1000), (3, 1, 96, 721), (2, 1, 64, 90),
+                                              (8, 2, 1024, 3600), (7, 3, 448, 1000), (6, 2, 384, 721), (5, 1, 320, 360)])
 def test_coarse_error_bound_holds_with_room_to_spare(m, n, nsamples, res, snr, gpu_device):
-    """|coarse / SC - exact| <= 2^-16 (S + |exact|) is what makes skipping a tile safe.  The debug tap evaluates both forms
+    """|coarse / SC - exact| <= NG 2^-16 (S + |exact|), NG = ceil(m^2 / 16), is what makes skipping a tile safe.  The debug tap evaluates both forms
     on EVERY (item, bin) of the batch and returns the worst error / allowance: < 1 is sound; the derivation leaves a factor
     > 2, the f16 matrix core accumulates more accurately than the worst case assumed, so < 0.5 is asserted."""
     import torch
@@ -162,3 +166,32 @@ def test_the_gate_actually_skips_work(gpu_device, monkeypatch):
             t, k = ctx.stage_ms(_capi().STAGE_SCAN)
             ms[coarse] = t / k
     assert ms["1"] < 0.8 * ms["0"], ms
+
+
+def test_the_gate_skips_work_at_eight_antennas(gpu_device, monkeypatch):
+    """BASELINE configs[2]'s shape (m8, N4096, res36000) in the helper's default wiring: the gated scan against the full one."""
+    import torch
+    from gr_baz_amd import synth
+    m, N, res, B = 8, 4096, 36000, 4096
+    arr = mo.array_geometry(m)
+    table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
+    x = synth.synth_stream(torch, gpu_device, B, m, N, arr, mo.FREQUENCY, mo.SPACING, seed=1003)
+    out, ms = {}, {}
+    for coarse in ("1", "0"):
+        monkeypatch.setenv("BAZ_MUSIC_COARSE", coarse)
+        ang = torch.zeros(B, 2, dtype=torch.float32, device=gpu_device)
+        lvl = torch.zeros_like(ang)
+        with _capi().Context(m, 2, N, res, table) as ctx:
+            ctx.reserve(B)
+            for _ in range(3):
+                ctx.process_device(x.data_ptr(), B, ang.data_ptr(), lvl.data_ptr(), None)
+            ctx.sync()
+            ctx.profile(1)
+            for _ in range(5):
+                ctx.process_device(x.data_ptr(), B, ang.data_ptr(), lvl.data_ptr(), None)
+            ctx.sync()
+            t, k = ctx.stage_ms(_capi().STAGE_SCAN)
+            ms[coarse] = t / k
+        out[coarse] = (ang.cpu().numpy(), lvl.cpu().numpy())
+    assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1].view(np.uint32), out["0"][1].view(np.uint32))
+    assert ms["1"] < 0.6 * ms["0"], ms
