@@ -1,6 +1,6 @@
 // scan_coarse_kernels.hip.h -- the pseudo-spectrum scan when ONLY the n strongest bins are wanted
 // (lib/baz_music_doa.cc:97-99,120-121: the spectrum port is not wired -- music_doa_helper's default
-// output_spectrum=False, python/music_doa_helper.py:49,61-64), m <= 4.  gfx950 only.
+// output_spectrum=False, python/music_doa_helper.py:49,61-64), m <= 8.  gfx950 only.
 //
 // The reference evaluates 1/||G^H a||^2 for every bin (.cc:103-121) and keeps the n largest (.cc:129-141).  Without the
 // spectrum port the only observable is that top-n list, i.e. the n SMALLEST d(bin) = a^H Q a.  scan_mfma_kernel

@@ -134,13 +134,13 @@ BAZ_MUSIC_API int baz_music_debug_evd(baz_music_ctx* ctx, const void* d_R, uint3
 /*   q   : d_in -> d_Q      the two stages back to back, exactly as process_device() runs them for this
  *                          configuration; projector coefficients as for `evd` */
 BAZ_MUSIC_API int baz_music_debug_q(baz_music_ctx* ctx, const void* d_in, uint32_t batch, void* d_Q);
-/*   coarse margin : the scan that runs when port 2 is NOT wired and m <= 4 (lib/baz_music_doa.cc:97-99: only the top-n list
+/*   coarse margin : the scan that runs when port 2 is NOT wired and m <= 8 (lib/baz_music_doa.cc:97-99: only the top-n list
  *                          is observable then) evaluates every 16-item x 16-bin tile in a coarse f16-matrix-core form first and
  *                          the exact fp64 form only where a tile can still hold a top-n member; ang / lvl are bit-identical to
- *                          the full scan as long as |coarse - exact| <= 2^-16 (S + |exact|) (gr_baz_amd/csrc/
+ *                          the full scan as long as |coarse - exact| <= NG 2^-16 (S + |exact|), NG = 1 (m <= 4) or ceil(m^2 / 32) (gr_baz_amd/csrc/
  *                          scan_coarse_kernels.hip.h).  This tap runs covariance + EVD of the batch and then BOTH forms on every
  *                          (item, bin); *worst = the largest observed error / allowance (sound below 1; derived with a factor
- *                          > 2 to spare).  BAZ_MUSIC_E_UNSUPPORTED for m > 4 or a table whose scale does not fit. */
+ *                          > 2 to spare).  BAZ_MUSIC_E_UNSUPPORTED for m > 8 or a table whose scale does not fit. */
 BAZ_MUSIC_API int baz_music_debug_coarse_margin(baz_music_ctx* ctx, const void* d_in, uint32_t batch, float* worst);
 /*   lab statistic: exact (16-item row group x 16-bin tile) evaluations of the coarse-gated scan's launches since the last
  *                          read (the counter resets); -1 unless the context was created under BAZ_MUSIC_COARSE_STATS=1. */
