@@ -9,7 +9,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbaz_agc_hip.so")
 
-SYMBOLS = ["baz_agc_create", "baz_agc_destroy", "baz_agc_process", "baz_agc_process_device", "baz_agc_process_device_interleaved", "baz_agc_reset",
+SYMBOLS = ["baz_agc_create", "baz_agc_destroy", "baz_agc_process", "baz_agc_process_device", "baz_agc_process_device_interleaved", "baz_agc_reset", "baz_agc_debug_selfcheck",
            "baz_agc_set_stream", "baz_agc_sync", "baz_agc_count", "baz_agc_strerror"]
 
 _vp = ctypes.c_void_p
@@ -50,6 +50,8 @@ def lib():
     L.baz_agc_sync.argtypes = [_vp]
     L.baz_agc_count.restype = _u64
     L.baz_agc_count.argtypes = [_vp]
+    L.baz_agc_debug_selfcheck.restype = ctypes.c_int
+    L.baz_agc_debug_selfcheck.argtypes = [_vp, _vp, _vp, _u64, ctypes.POINTER(_u64)]
     L.baz_agc_strerror.restype = ctypes.c_char_p
     L.baz_agc_strerror.argtypes = [ctypes.c_int]
     _lib = L
@@ -121,6 +123,15 @@ class Agc:
 
     def reset(self):
         lib().baz_agc_reset(self._h)
+
+    def debug_selfcheck(self, d_a, d_b, n):
+        """(differing square roots, differing quotients) of the fast path's sqrt / division against the rounded ones over n
+        device-resident doubles a[i] and pairs a[i] / b[i] (baz_agc_debug_selfcheck)."""
+        bad = (_u64 * 2)()
+        r = lib().baz_agc_debug_selfcheck(self._h, _vp(d_a), _vp(d_b), int(n), bad)
+        if r:
+            raise AgcError(r, "baz_agc_debug_selfcheck")
+        return int(bad[0]), int(bad[1])
 
     @property
     def count(self):

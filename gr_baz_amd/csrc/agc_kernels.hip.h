@@ -26,6 +26,10 @@ struct AgcParams {
     double a;          // 1.0 - (double)rate
     double b;          // (double)rate
     double reference;
+    // the fast path of full tiles (see agc_tile_kernel); pw == nullptr switches it off
+    double c1, c2, c4, c8;     // (a^IE)^1, ^2, ^4, ^8
+    double a_tile;             // a^(64 IE): the A of a full tile's map
+    const double* pw;          // [64][4]: (a^IE)^((l & 15) + 1), (a^IE)^((l & 31) + 1), (a^IE)^l, unused
 };
 
 // The reference's per-sample expressions (.cc:74-100), operation for operation: every product and sum is rounded
@@ -133,6 +137,65 @@ constexpr int AGC_IE = 4;                  // consecutive samples per lane
 constexpr int AGC_IT = 64 * AGC_IE;        // 256 samples per stream per workgroup
 constexpr int AGC_IMAX = 16;               // streams per context in this form
 
+// ---- the fast path of a FULL tile whose values are in the ordinary range (round 3) ---------------------------------------
+// What the tile kernels spend is instruction issue, not bytes: fp64 sqrt and division come with scaling and
+// special-case handling around their Newton cores, the wave scan moved (A, S) pairs through ds_bpermute with a select per
+// step, and every sample carried its "j < cnt" predicate.  For a tile of 256 valid samples whose |x|^2 and carry-in lie in
+// [2^-400, 2^400] (every non-zero finite float input does) none of that is needed:
+//   sqrt, division : the same rsq / rcp + fma refinement the compiler's expansion runs between its scaling steps -- the
+//                    scaling is the identity in this range, so the results are the same bits (checked against __dsqrt_rn /
+//                    __ddiv_rn on the GPU: tests/test_agc.py::test_fast_sqrt_and_division_are_the_rounded_ones);
+//   scan           : A of a full lane is the constant a^4, so only S is scanned:  S_i = sum_{j<=i} (a^4)^(i-j) S_j  by
+//                    DPP row shifts (1, 2, 4, 8 with the constants a^4, a^8, a^16, a^32) and the two row broadcasts
+//                    (per-lane constants (a^4)^((lane & 15) + 1), (a^4)^((lane & 31) + 1)): 3 instructions per step.
+// The constants come from the host (long double powers, rounded once): AgcParams::pw = [64][4] doubles
+// {(a^4)^((l&15)+1), (a^4)^((l&31)+1), (a^4)^l, -}.  Tiles that do not qualify (stream tail, zeros, inf / NaN, denormal
+// products) take the general path below, as before.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double agc_dpp(const double v)     // lanes without a source (or outside ROW_MASK) read 0.0
+{
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+// 2^-400 <= v <= 2^400 (false for 0, denormals, inf, NaN, negative): one subtract and one compare on the high word
+__device__ __forceinline__ bool agc_ordinary(const double v)
+{
+    const uint32_t hi = (uint32_t)(__builtin_bit_cast(uint64_t, v) >> 32);
+    return (hi - 0x26F00000u) < (0x58F00000u - 0x26F00000u);
+}
+__device__ __forceinline__ double agc_mag2(const float2 x)
+{
+#pragma clang fp contract(off)
+    const double d0 = x.x, d1 = x.y;
+    const double p0 = d0 * d0, p1 = d1 * d1;
+    return p0 + p1;                                                            // .cc:74-76
+}
+__device__ __forceinline__ double agc_sqrt_ordinary(const double x)            // == __dsqrt_rn(x) for agc_ordinary(x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+__device__ __forceinline__ double agc_div_ordinary(const double n, const double d)   // == __ddiv_rn(n, d), both ordinary
+{
+    double y = __builtin_amdgcn_rcp(d);
+    double t = fma(-d, y, 1.0);
+    y = fma(t, y, y);
+    t = fma(-d, y, 1.0);
+    y = fma(t, y, y);
+    const double q = n * y;
+    const double r = fma(-d, q, n);
+    return fma(r, y, q);
+}
+
 // MODE 0: tile maps; MODE 1: apply + interleave (workgroup = the S streams of one tile); MODE 2: apply, planar output
 // with the optional env / gain ports (waves are dealt over (stream, tile) pairs, consecutive waves = consecutive tiles
 // of one stream).  PLANAR_GRID selects the MODE-2 wave -> (stream, tile) mapping for MODE 0 as well.
@@ -147,6 +210,7 @@ __global__ __launch_bounds__(1024) void agc_tile_kernel(const float2* __restrict
     extern __shared__ float2 tile[];       // MODE 1: [nstreams][AGC_IT + 1]
     const int lane = threadIdx.x & 63;
     uint32_t stream, t;
+    bool live = true;
     if constexpr (PLANAR_GRID) {
         const uint64_t gw = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         if (gw >= (uint64_t)ntiles * nstreams) return;
@@ -156,6 +220,7 @@ __global__ __launch_bounds__(1024) void agc_tile_kernel(const float2* __restrict
         stream = threadIdx.x >> 6;
         t = blockIdx.x;
     }
+    (void)live;
     const uint64_t base = (uint64_t)t * AGC_IT;
     const uint32_t valid = (uint32_t)((n - base < (uint64_t)AGC_IT) ? (n - base) : AGC_IT);
     const int i0 = lane * AGC_IE;
@@ -174,40 +239,91 @@ __global__ __launch_bounds__(1024) void agc_tile_kernel(const float2* __restrict
 #pragma unroll
         for (int j = 0; j < AGC_IE; ++j) x[j] = (j < cnt) ? xin[j] : make_float2(0.f, 0.f);
     }
-    double A = 1.0, S = 0.0;
-#pragma unroll
-    for (int j = 0; j < AGC_IE; ++j) {
-        mag[j] = agc_mag(x[j]);                              // .cc:74-77
-        if (j < cnt) { S = fma(P.a, S, P.b * mag[j]); A *= P.a; }
+    // the fast path's per-lane constants and the tile's carry-in are requested before the input is needed
+    double pw15 = 0.0, pw31 = 0.0, pwl = 0.0, carry = 0.0;
+    const bool try_fast = P.pw != nullptr && valid == (uint32_t)AGC_IT;                // wave-uniform
+    if (try_fast) {
+        const double2 c01 = *reinterpret_cast<const double2*>(P.pw + 4 * lane);
+        pw15 = c01.x; pw31 = c01.y;
+        pwl = P.pw[4 * lane + 2];
     }
-    double Ai = A, Si = S;                                   // inclusive wave scan of the lane maps
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double Ap = __shfl_up(Ai, d, 64), Sp = __shfl_up(Si, d, 64);
-        if (lane >= d) compose(Ai, Si, Ap, Sp);
-    }
-    if (MODE == 0) {
-        if (lane == 63) chunk_pair[(size_t)stream * ntiles + t] = make_double2(Ai, Si);
-        return;
-    }
-    double Ae = __shfl_up(Ai, 1, 64), Se = __shfl_up(Si, 1, 64);
-    if (lane == 0) { Ae = 1.0; Se = 0.0; }
-    double e = fma(Ae, carry_in[(size_t)stream * ntiles + t], Se);   // state entering this lane's run
-    if constexpr (MODE == 2) {     // planar: the lane's AGC_IE outputs are 32 contiguous bytes of its stream
-        float2 y[AGC_IE];
-        float ev[AGC_IE], gv[AGC_IE];
+    if constexpr (MODE != 0) carry = carry_in[(size_t)stream * ntiles + t];
+    bool fast = false;
+    if (try_fast) {
+        bool ok = (MODE == 0) || agc_ordinary(carry);
 #pragma unroll
         for (int j = 0; j < AGC_IE; ++j) {
-            y[j] = make_float2(0.f, 0.f); ev[j] = 0.f; gv[j] = 0.f;
-            if (j < cnt) {
+            mag[j] = agc_mag2(x[j]);                             // (|x|^2 for now)
+            ok = ok && agc_ordinary(mag[j]);
+        }
+        fast = __all(ok);
+    }
+    float2 y[AGC_IE];
+    [[maybe_unused]] float ev[AGC_IE], gv[AGC_IE];
+    double e = 0.0;
+    if (fast) {
+        double S = 0.0;
+#pragma unroll
+        for (int j = 0; j < AGC_IE; ++j) {
+            mag[j] = agc_sqrt_ordinary(mag[j]);                  // .cc:77
+            S = fma(P.a, S, P.b * mag[j]);
+        }
+        S = fma(P.c1, agc_dpp<0x111, 0xF>(S), S);                // row_shr:1
+        S = fma(P.c2, agc_dpp<0x112, 0xF>(S), S);                // row_shr:2
+        S = fma(P.c4, agc_dpp<0x114, 0xF>(S), S);                // row_shr:4
+        S = fma(P.c8, agc_dpp<0x118, 0xF>(S), S);                // row_shr:8
+        S = fma(pw15, agc_dpp<0x142, 0xA>(S), S);                // row_bcast:15 into rows 1 and 3
+        S = fma(pw31, agc_dpp<0x143, 0xC>(S), S);                // row_bcast:31 into rows 2 and 3
+        if constexpr (MODE == 0) {
+            if (lane == 63) chunk_pair[(size_t)stream * ntiles + t] = make_double2(P.a_tile, S);
+            return;
+        } else {
+            e = fma(pwl, carry, agc_dpp<0x138, 0xF>(S));         // wave_shr:1: the inclusive value of the lane before
+#pragma unroll
+            for (int j = 0; j < AGC_IE; ++j) {
                 e = agc_env_step(e, mag[j], P.a, P.b);            // .cc:82
-                const double gain = __ddiv_rn(P.reference, e);    // .cc:89
+                const double gain = agc_div_ordinary(P.reference, e);   // .cc:89
                 y[j] = agc_apply(x[j], gain);                     // .cc:97-100
-                ev[j] = (float)e;                                 // .cc:85
-                gv[j] = (float)gain;                              // .cc:92
+                if constexpr (MODE == 2) { ev[j] = (float)e; gv[j] = (float)gain; }   // .cc:85, 92
             }
         }
+    } else {
+        double A = 1.0, S = 0.0;
+#pragma unroll
+        for (int j = 0; j < AGC_IE; ++j) {
+            mag[j] = agc_mag(x[j]);                              // .cc:74-77
+            if (j < cnt) { S = fma(P.a, S, P.b * mag[j]); A *= P.a; }
+        }
+        double Ai = A, Si = S;                                   // inclusive wave scan of the lane maps
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double Ap = __shfl_up(Ai, d, 64), Sp = __shfl_up(Si, d, 64);
+            if (lane >= d) compose(Ai, Si, Ap, Sp);
+        }
+        if constexpr (MODE == 0) {
+            if (lane == 63) chunk_pair[(size_t)stream * ntiles + t] = make_double2(Ai, Si);
+            return;
+        } else {
+            double Ae = __shfl_up(Ai, 1, 64), Se = __shfl_up(Si, 1, 64);
+            if (lane == 0) { Ae = 1.0; Se = 0.0; }
+            e = fma(Ae, carry, Se);                               // state entering this lane's run
+#pragma unroll
+            for (int j = 0; j < AGC_IE; ++j) {
+                y[j] = make_float2(0.f, 0.f);
+                if constexpr (MODE == 2) { ev[j] = 0.f; gv[j] = 0.f; }
+                if (j < cnt) {
+                    e = agc_env_step(e, mag[j], P.a, P.b);            // .cc:82
+                    const double gain = __ddiv_rn(P.reference, e);    // .cc:89
+                    y[j] = agc_apply(x[j], gain);                     // .cc:97-100
+                    if constexpr (MODE == 2) { ev[j] = (float)e; gv[j] = (float)gain; }   // .cc:85, 92
+                }
+            }
+        }
+    }
+    if constexpr (MODE != 0) {
         if (env_state && base + i0 + cnt == n && cnt > 0) env_state[stream] = e;
+    }
+    if constexpr (MODE == 2) {     // planar: the lane's AGC_IE outputs are 32 contiguous bytes of its stream
         const size_t o = (size_t)stream * stride + base + i0;
         float2* __restrict__ yo = out + o;
         if (cnt == AGC_IE && (reinterpret_cast<uintptr_t>(yo) & 15u) == 0) {
@@ -233,34 +349,44 @@ __global__ __launch_bounds__(1024) void agc_tile_kernel(const float2* __restrict
                 for (int j = 0; j < AGC_IE; ++j) if (j < cnt) mo[j] = gv[j];
             }
         }
-        return;
     }
-    float2* __restrict__ row = tile + (size_t)stream * (AGC_IT + 1);
+    if constexpr (MODE == 1) {
+        float2* __restrict__ row = tile + (size_t)stream * (AGC_IT + 1);
 #pragma unroll
-    for (int j = 0; j < AGC_IE; ++j) {
-        if (j < cnt) {
-            e = agc_env_step(e, mag[j], P.a, P.b);            // .cc:82
-            const double gain = __ddiv_rn(P.reference, e);    // .cc:89
-            row[i0 + j] = agc_apply(x[j], gain);              // .cc:97-100
+        for (int j = 0; j < AGC_IE; ++j)
+            if (j < cnt) row[i0 + j] = y[j];
+        __syncthreads();
+        // contiguous write-out: element p of the tile block is (time p / S, stream p % S)
+        float2* __restrict__ ob = out + (size_t)base * nstreams;
+        const uint32_t total = valid * nstreams;
+        if ((nstreams & 1u) == 0 && (reinterpret_cast<uintptr_t>(ob) & 15u) == 0) {
+            for (uint32_t p = threadIdx.x * 2; p < total; p += blockDim.x * 2) {     // two streams of one time step
+                const uint32_t tt = p / nstreams, ss = p - tt * nstreams;
+                const float2 a = tile[(size_t)ss * (AGC_IT + 1) + tt], b = tile[(size_t)(ss + 1) * (AGC_IT + 1) + tt];
+                *reinterpret_cast<float4*>(ob + p) = make_float4(a.x, a.y, b.x, b.y);
+            }
+        } else {
+            for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) {
+                const uint32_t tt = p / nstreams, ss = p - tt * nstreams;
+                ob[p] = tile[(size_t)ss * (AGC_IT + 1) + tt];
+            }
         }
     }
-    if (env_state && base + i0 + cnt == n && cnt > 0) env_state[stream] = e;
-    __syncthreads();
-    // contiguous write-out: element p of the tile block is (time p / S, stream p % S)
-    float2* __restrict__ ob = out + (size_t)base * nstreams;
-    const uint32_t total = valid * nstreams;
-    if ((nstreams & 1u) == 0 && (reinterpret_cast<uintptr_t>(ob) & 15u) == 0) {
-        for (uint32_t p = threadIdx.x * 2; p < total; p += blockDim.x * 2) {     // two streams of one time step
-            const uint32_t tt = p / nstreams, ss = p - tt * nstreams;
-            const float2 a = tile[(size_t)ss * (AGC_IT + 1) + tt], b = tile[(size_t)(ss + 1) * (AGC_IT + 1) + tt];
-            *reinterpret_cast<float4*>(ob + p) = make_float4(a.x, a.y, b.x, b.y);
-        }
-    } else {
-        for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) {
-            const uint32_t tt = p / nstreams, ss = p - tt * nstreams;
-            ob[p] = tile[(size_t)ss * (AGC_IT + 1) + tt];
-        }
-    }
+}
+
+// lab / test: the fast path's square root and division against the rounded library ones, bit for bit
+__global__ void agc_selfcheck_kernel(const double* __restrict__ v, const double* __restrict__ w, uint64_t n,
+                                     unsigned long long* __restrict__ bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = v[i], b = w[i];
+    unsigned int k = 0;
+    if (agc_ordinary(a) && __builtin_bit_cast(uint64_t, agc_sqrt_ordinary(a)) != __builtin_bit_cast(uint64_t, __dsqrt_rn(a))) k |= 1u;
+    if (agc_ordinary(a) && agc_ordinary(b) &&
+        __builtin_bit_cast(uint64_t, agc_div_ordinary(a, b)) != __builtin_bit_cast(uint64_t, __ddiv_rn(a, b))) k |= 2u;
+    if (k & 1u) atomicAdd(bad, 1ull);
+    if (k & 2u) atomicAdd(bad + 1, 1ull);
 }
 
 }  // namespace bazagc

@@ -4,7 +4,9 @@
 #include "../../include/baz_agc_hip.h"
 #include "agc_kernels.hip.h"
 
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -18,6 +20,7 @@ struct baz_agc_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     uint64_t count = 0;            // _count (identical for every stream of the context)
     double* d_env = nullptr;       // _env per stream
+    double* d_pw = nullptr;        // per-lane powers of a^IE for the fast path (AgcParams::pw)
     double2* d_pair = nullptr;     // per-chunk maps
     double* d_carry = nullptr;     // per-chunk carry-in
     size_t chunk_cap = 0;          // chunks per stream the workspace holds
@@ -142,6 +145,32 @@ int baz_agc_create(baz_agc_ctx** out, uint32_t nstreams, float rate, float refer
         return BAZ_AGC_E_HIP;
     }
     c->stream = c->own_stream;
+    // The fast path of full tiles (agc_kernels.hip.h): powers of a^IE, computed in long double and rounded once.  Only for
+    // an ordinary smoothing rate and reference (0 < a < 1 and the quotient reference / envelope far from the range's ends);
+    // BAZ_AGC_FAST=0 keeps the general path (lab / A-B tests).
+    c->P.pw = nullptr;
+    const char* fenv = getenv("BAZ_AGC_FAST");
+    const double ar = std::fabs(c->P.reference);
+    if (!(fenv && atoi(fenv) == 0) && c->P.a > 0.0 && c->P.a < 1.0 && c->P.b > 0.0 && ar >= 0x1p-100 && ar <= 0x1p100) {
+        const long double a4 = powl((long double)c->P.a, (long double)AGC_IE);
+        c->P.c1 = (double)a4;
+        c->P.c2 = (double)powl(a4, 2.0L);
+        c->P.c4 = (double)powl(a4, 4.0L);
+        c->P.c8 = (double)powl(a4, 8.0L);
+        c->P.a_tile = (double)powl(a4, 64.0L);
+        double h[64 * 4];
+        for (int l = 0; l < 64; ++l) {
+            h[4 * l + 0] = (double)powl(a4, (long double)((l & 15) + 1));
+            h[4 * l + 1] = (double)powl(a4, (long double)((l & 31) + 1));
+            h[4 * l + 2] = (double)powl(a4, (long double)l);
+            h[4 * l + 3] = 0.0;
+        }
+        if (hipMalloc((void**)&c->d_pw, sizeof(h)) != hipSuccess || hipMemcpy(c->d_pw, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) {
+            baz_agc_destroy(c);
+            return BAZ_AGC_E_HIP;
+        }
+        c->P.pw = c->d_pw;
+    }
     *out = c;
     return BAZ_AGC_OK;
 }
@@ -153,6 +182,7 @@ void baz_agc_destroy(baz_agc_ctx* c)
         DeviceGuard guard(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         if (c->d_env) (void)hipFree(c->d_env);
+        if (c->d_pw) (void)hipFree(c->d_pw);
         if (c->d_pair) (void)hipFree(c->d_pair);
         if (c->d_carry) (void)hipFree(c->d_carry);
         if (c->s_in) (void)hipFree(c->s_in);
@@ -245,6 +275,29 @@ int baz_agc_sync(baz_agc_ctx* c)
 }
 
 uint64_t baz_agc_count(const baz_agc_ctx* c) { return c ? c->count : 0; }
+
+int baz_agc_debug_selfcheck(baz_agc_ctx* c, const void* d_a, const void* d_b, uint64_t n, uint64_t mismatches[2])
+{
+    if (!c || !d_a || !d_b || !mismatches || n == 0 || n > 0x7FFFFFFFull * 256ull) return BAZ_AGC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    DeviceGuard guard(c->device);
+    unsigned long long* d_bad = nullptr;
+    AGC_TRY(hipMalloc((void**)&d_bad, 2 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_bad, 0, 2 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(agc_selfcheck_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream,
+                           static_cast<const double*>(d_a), static_cast<const double*>(d_b), n, d_bad);
+        e = hipGetLastError();
+    }
+    unsigned long long h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d_bad, sizeof(h), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) return BAZ_AGC_E_HIP;
+    mismatches[0] = h[0];
+    mismatches[1] = h[1];
+    return BAZ_AGC_OK;
+}
 
 const char* baz_agc_strerror(int code)
 {

@@ -58,6 +58,11 @@ BAZ_AGC_API int baz_agc_sync(baz_agc_ctx* ctx);
 /* Number of samples consumed per stream so far (the reference's _count). */
 BAZ_AGC_API uint64_t baz_agc_count(const baz_agc_ctx* ctx);
 BAZ_AGC_API const char* baz_agc_strerror(int code);
+/* Test tap: full tiles of ordinary values run a lean square root and division (the rsq / rcp + fma cores of the rounded
+ * ones, without their scaling: gr_baz_amd/csrc/agc_kernels.hip.h).  This compares them with the rounded library functions
+ * on n device-resident doubles a[i] (sqrt(a[i])) and pairs (a[i] / b[i]), bit for bit, wherever the fast path would take
+ * them (2^-400 <= v <= 2^400); mismatches[0] = differing square roots, mismatches[1] = differing quotients. */
+BAZ_AGC_API int baz_agc_debug_selfcheck(baz_agc_ctx* ctx, const void* d_a, const void* d_b, uint64_t n, uint64_t mismatches[2]);
 
 #ifdef __cplusplus
 }

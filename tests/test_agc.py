@@ -163,3 +163,65 @@ def test_agc_zero_first_sample_and_reset(gpu_device):
         assert blk.count == 0
         o3, e3, m3 = blk.work(x[5:])
     assert close(e3, ar.Agc(0.1, 1.0).work(x[5:])[1])
+
+
+@pytest.mark.gpu
+def test_fast_sqrt_and_division_are_the_rounded_ones(gpu_device):
+    """Full tiles of ordinary values run lean sqrt / division sequences (agc_kernels.hip.h): the Newton cores of the rounded
+    library functions without their range scaling.  Bit for bit the same as __dsqrt_rn / __ddiv_rn on |x|^2 of random float
+    samples, on envelope-like divisors, and log-uniformly over the whole range the fast path accepts."""
+    import torch
+    from gr_baz_amd import agc
+    rng = np.random.default_rng(11)
+    n = 1 << 22
+    xs = (rng.standard_normal((n, 2)) * 10.0 ** rng.uniform(-18, 18, size=(n, 1))).astype(np.float32).astype(np.float64)
+    a1 = xs[:, 0] * xs[:, 0] + xs[:, 1] * xs[:, 1]                                  # |x|^2 as the kernel forms it
+    b1 = np.sqrt(a1) * rng.uniform(0.5, 2.0, size=n)                                 # envelope-like
+    a2 = np.ldexp(rng.uniform(1.0, 2.0, size=n), rng.integers(-399, 399, size=n))    # the whole accepted range
+    b2 = np.ldexp(rng.uniform(1.0, 2.0, size=n), rng.integers(-399, 399, size=n))
+    a3 = np.full(n, 1.0); b3 = np.ldexp(rng.uniform(1.0, 2.0, size=n), rng.integers(-60, 60, size=n))   # reference / env
+    a4 = np.nextafter(np.ldexp(1.0, rng.integers(-300, 300, size=n)), rng.choice([0.0, np.inf], size=n))  # around powers of two
+    with agc.Agc(1e-4, 1.0) as blk:
+        for a, b in ((a1, b1), (a2, b2), (a3, b3), (a4, b2), (a2, a4)):
+            da = torch.from_numpy(np.ascontiguousarray(a)).to(gpu_device)
+            db = torch.from_numpy(np.ascontiguousarray(b)).to(gpu_device)
+            torch.cuda.synchronize()
+            assert blk.debug_selfcheck(da.data_ptr(), db.data_ptr(), n) == (0, 0)
+
+
+@pytest.mark.gpu
+def test_fast_and_general_tile_paths_agree(gpu_device, monkeypatch):
+    """BAZ_AGC_FAST=0 keeps every tile on the general path.  The two builds differ only in how a tile's ENTRY state is
+    re-associated (DPP scan with host-computed powers against the (A, S) pair scan): float32 outputs identical except a
+    1-ulp flip in < 1e-5 of the samples, like either against the sequential loop; zeros in the stream (general path for
+    those tiles) and a ragged tail included."""
+    import torch
+    from gr_baz_amd import agc
+    S, n = 3, 256 * 40 + 77
+    rng = np.random.default_rng(3)
+    x = ((rng.standard_normal((S, n)) + 1j * rng.standard_normal((S, n))) * np.linspace(0.1, 5.0, n)).astype(np.complex64)
+    x[1, 1000:1300] = 0                                   # a zero run: |x|^2 = 0 is not "ordinary"
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BAZ_AGC_FAST", mode)
+        with agc.Agc(1e-3, 2.0, nstreams=S) as blk:
+            d_in = torch.from_numpy(x.view(np.float32)).to(gpu_device)
+            d_out = torch.zeros_like(d_in)
+            d_env = torch.zeros(S, n, dtype=torch.float32, device=gpu_device)
+            d_mul = torch.zeros_like(d_env)
+            d_items = torch.zeros(n, S, 2, dtype=torch.float32, device=gpu_device)
+            torch.cuda.synchronize()
+            blk.process_device(d_in.data_ptr(), n, n, d_out.data_ptr(), d_env.data_ptr(), d_mul.data_ptr())
+            blk.sync()
+            blk.reset()
+            blk.process_device_interleaved(d_in.data_ptr(), n, n, d_items.data_ptr())
+            blk.sync()
+            outs[mode] = [t.cpu().numpy() for t in (d_out, d_env, d_mul, d_items)]
+    for got, ref in zip(outs["1"], outs["0"]):
+        fin = np.isfinite(ref)
+        u = np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))[fin]
+        assert u.max() <= 1 and np.count_nonzero(u) <= max(1, 1e-5 * u.size)
+    assert np.array_equal(outs["1"][3].reshape(n, S, 2).transpose(1, 0, 2).reshape(S, -1), outs["1"][0].reshape(S, -1))   # both output forms agree
+    for s in range(S):
+        o, e, m = ar.Agc(1e-3, 2.0).work(x[s])
+        assert close(outs["1"][1][s], e) and close(outs["1"][0][s].view(np.complex64), o)
