@@ -143,6 +143,45 @@ __global__ __launch_bounds__(256) void write_rows_class(char* __restrict__ base,
     }
 }
 
+// the row-class pattern with the stores of W consecutive steps gathered (in the scan: a 4 x 4 exchange between lane rows and
+// registers, v_permlane16/32_swap): one store instruction = 1 KiB of 4 / W rows, W x 256 B contiguous per row, instead of
+// 256 B of each of 4 rows.  Same bytes, same number of instructions; does the memory system prefer the longer runs?
+template <int POLICY, int W>
+__global__ __launch_bounds__(256) void write_rows_gather(char* __restrict__ base, uint32_t rows, uint32_t nsplit, uint32_t spin)
+{
+    const uint32_t res = 3600, nclass = 4, pitch = 14400;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t rpc = rows / nclass;
+    const uint32_t split = blockIdx.x % nsplit, grp = blockIdx.x / nsplit;
+    const uint32_t p0 = (grp * 4 + wave) * 16;
+    const uint32_t cls = p0 / rpc, j0 = p0 - cls * rpc;
+    const uint32_t sh = (res * cls) & 63u;
+    const uint32_t nsteps = (res + sh + 63) >> 6;
+    const uint32_t ngr = (nsteps + W - 1) / W;
+    const uint32_t g0 = (uint32_t)(((uint64_t)ngr * split) / nsplit), g1 = (uint32_t)(((uint64_t)ngr * (split + 1)) / nsplit);
+    const uint32_t item0 = nclass * j0 + cls;
+    v4f v = {1.0f, 2.0f, 3.0f, (float)lane};
+    char* wbase = base + (size_t)item0 * pitch - 4 * sh;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wbase, 0, 0x7FFFFFFF, 0x00020000);
+    constexpr int LPR = 16 * W;                 // lanes per row in one instruction
+    const uint32_t sub = (uint32_t)lane / LPR, lo = (uint32_t)lane % LPR;
+    for (uint32_t gq = g0; gq < g1; ++gq) {
+        for (uint32_t k = 0; k < spin * W; ++k) v[0] = __builtin_fmaf(v[0], 1.0000001f, 0.5f);
+        const uint32_t bin = gq * (64 * W) + 4 * lo - sh;
+#pragma unroll
+        for (int i = 0; i < 4 * W; ++i) {
+            const uint32_t row = (uint32_t)i * (4 / W) + sub;
+            const uint32_t off = row * nclass * pitch + 16u * lo;
+            if (bin < res) {
+                if constexpr (POLICY == 2)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rs, (int)off, (int)(gq * 256u * W), 1 | 2 | 16);
+                else if constexpr (POLICY == 1) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(wbase + off + gq * 256u * W));
+                else *reinterpret_cast<v4f*>(wbase + off + gq * 256u * W) = v;
+            }
+        }
+    }
+}
+
 template <int POLICY>
 __global__ __launch_bounds__(256) void mixed(const v4f* __restrict__ src, size_t nr16, v4f* __restrict__ dst, size_t nw16, float* sink)
 {
@@ -243,6 +282,22 @@ int main()
         timeit(nm, (double)rows * pitchA, [&] { hipLaunchKernelGGL((write_rows_class<0, false, 1>), dim3(blocks), dim3(256), 0, 0, dst, rows, 2, spin); });
         snprintf(nm, sizeof nm, "write_rows_class plain global_store, XCD owns runs of 32 groups    spin %u", spin);
         timeit(nm, (double)rows * pitchA, [&] { hipLaunchKernelGGL((write_rows_class<0, false, 2>), dim3(blocks), dim3(256), 0, 0, dst, rows, 2, spin); });
+    }
+    for (uint32_t spin : {0u, 64u}) {
+        const uint32_t blocks = (rows / 64) * 2;
+        char nm[160];
+        snprintf(nm, sizeof nm, "write_rows_gather W=1 (= the scan pattern) sc0 sc1 nt  spin %u", spin);
+        timeit(nm, (double)rows * pitchA, [&] { hipLaunchKernelGGL((write_rows_gather<2, 1>), dim3(blocks), dim3(256), 0, 0, dst, rows, 2, spin); });
+        snprintf(nm, sizeof nm, "write_rows_gather W=2 (512 B per row and instruction) sc0 sc1 nt  spin %u", spin);
+        timeit(nm, (double)rows * pitchA, [&] { hipLaunchKernelGGL((write_rows_gather<2, 2>), dim3(blocks), dim3(256), 0, 0, dst, rows, 2, spin); });
+        snprintf(nm, sizeof nm, "write_rows_gather W=4 (1 KiB of one row per instruction) sc0 sc1 nt  spin %u", spin);
+        timeit(nm, (double)rows * pitchA, [&] { hipLaunchKernelGGL((write_rows_gather<2, 4>), dim3(blocks), dim3(256), 0, 0, dst, rows, 2, spin); });
+        snprintf(nm, sizeof nm, "write_rows_gather W=2 nt  spin %u", spin);
+        timeit(nm, (double)rows * pitchA, [&] { hipLaunchKernelGGL((write_rows_gather<1, 2>), dim3(blocks), dim3(256), 0, 0, dst, rows, 2, spin); });
+        snprintf(nm, sizeof nm, "write_rows_gather W=4 nt  spin %u", spin);
+        timeit(nm, (double)rows * pitchA, [&] { hipLaunchKernelGGL((write_rows_gather<1, 4>), dim3(blocks), dim3(256), 0, 0, dst, rows, 2, spin); });
+        snprintf(nm, sizeof nm, "write_rows_gather W=4 plain  spin %u", spin);
+        timeit(nm, (double)rows * pitchA, [&] { hipLaunchKernelGGL((write_rows_gather<0, 4>), dim3(blocks), dim3(256), 0, 0, dst, rows, 2, spin); });
     }
     for (int gsz : {4096, 16384}) {
         char nm[128];
