@@ -39,13 +39,6 @@ struct baz_music_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;      // the stream process_device() launches on (own or caller's)
-    // Default wiring, large calls (BAZ_MUSIC_OVERLAP=k sub-batches): the gated scan of sub-batch i on a second stream beside
-    // covariance + EVD of sub-batch i + 1 (process_overlapped); views into the shared workspace for the scan / merge launches
-    int overlap = 0;
-    hipStream_t s_aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sub[8] = {};
-    double* cand_view = nullptr;       // candidates of the sub-batch being launched (nullptr: dCand)
-    size_t view_off = 0;               // its first item: offset into dQ / dG
     // steering table as the real bilinear-form table F[bin][m*m] (fp64) in MFMA B-operand order:
     // FB[step][chunk][lane] (double2), see build_FB; one padded step in front of step 0 and one behind the last
     // (the scan's row classes read shifted windows), dFB points at the allocation, step 0 is dFB + fb_step_elems
@@ -582,19 +575,18 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
                   float* d_lvl, float* d_spec)
 {
     if constexpr (M <= 8 && NMAX <= 4) {
-        if (!d_spec && coarse_applies(c) && dQ == c->dQ + c->view_off) {
+        if (!d_spec && coarse_applies(c) && dQ == c->dQ) {
             const CoarseGeom CG = coarse_geometry(c, batch);
-            if ((size_t)batch * CG.nsplit * NMAX + (c->cand_view ? (size_t)(c->cand_view - c->dCand) : 0) > c->cand_cap) return BAZ_MUSIC_E_INVALID;
+            if ((size_t)batch * CG.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;
             ScanRefine rf;
-            rf.Gs = c->refine_off ? nullptr : c->dG + c->view_off;
+            rf.Gs = c->refine_off ? nullptr : c->dG;
             rf.TB = c->dTB + c->tb_step_elems;
             rf.below = c->refine_below;
             rf.count = c->dRefined + c->stat_parity;
             rf.A2 = nullptr;
-            double* const cand_base = c->cand_view ? c->cand_view : c->dCand;
             unsigned long long* stats = c->coarse_stats ? c->dMargin : nullptr;     // lab: exact tile evaluations, summed over launches
 #define BAZ_COARSE_ARGS dim3(CG.groups * CG.nsplit), dim3(256), 0, c->stream, dQ, c->dCS, c->dCS + (size_t)(c->cs_tiles + 1) * cs_c_units(M), \
-                        cand_base, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, stats, nullptr
+                        c->dCand, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, stats, nullptr
             if constexpr (M > 4) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, coarse_rg_wide(M, NMAX), 4>), BAZ_COARSE_ARGS);
             else if (CG.tpp == 4) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 2, 4>), BAZ_COARSE_ARGS);
             else if (c->coarse_lab == 1) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8, false, 1>), BAZ_COARSE_ARGS);
@@ -672,8 +664,8 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
 template <int NMAX>
 int launch_merge_t(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl, float* d_spec)
 {
-    hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream,
-                       c->cand_view ? c->cand_view : c->dCand, d_spec, d_ang, d_lvl, batch, c->res, c->n, c->last_nsplit, c->keep_mask, c->dRefined + (c->stat_parity ^ 1));
+    hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream, c->dCand,
+                       d_spec, d_ang, d_lvl, batch, c->res, c->n, c->last_nsplit, c->keep_mask, c->dRefined + (c->stat_parity ^ 1));
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
 }
@@ -1204,54 +1196,6 @@ int begin_statistic(baz_music_ctx* c)
     return BAZ_MUSIC_OK;
 }
 
-// Default wiring (no spectrum port), m <= 4, a large device-resident call: covariance + EVD are bound by the HBM read
-// stream, the gated scan by the f16 matrix core and LDS.  The call is cut into k sub-batches; sub-batch i's scan + merge run
-// on a second stream while sub-batch i + 1's covariance + EVD run on the context's (fork / join by events, no host
-// synchronisation; the outputs are the serial form's bit for bit: the same launches on the same data).
-int process_overlapped(baz_music_ctx* c, const float* d_in, uint32_t batch, float* d_ang, float* d_lvl, uint32_t qstride)
-{
-    const uint32_t k = (uint32_t)std::min(c->overlap, 8);
-    const uint32_t sub = round_up((batch + k - 1) / k, 256);
-    if (!c->s_aux) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->s_aux, hipStreamNonBlocking));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-        for (auto& e : c->ev_sub) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    size_t cand_total = 0;                                     // every sub-batch its own candidate region
-    for (uint32_t off = 0; off < batch; off += sub)
-        cand_total += (size_t)std::min(sub, batch - off) * coarse_geometry(c, std::min(sub, batch - off)).nsplit * topn_list_len(c->n);
-    int r = ensure_candidates(c, cand_total);
-    if (r) return r;
-    hipStream_t const main_stream = c->stream;
-    HIP_TRY(c, hipEventRecord(c->ev_fork, main_stream));      // the second stream starts behind whatever the caller queued
-    HIP_TRY(c, hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
-    size_t cand_off = 0;
-    uint32_t i = 0;
-    for (uint32_t off = 0; off < batch; off += sub, ++i) {
-        const uint32_t nb = std::min(sub, batch - off);
-        r = launch_covevd(c, d_in + (size_t)off * c->nsamples * 2, nb, c->dQ + off, qstride, c->dG + off);
-        if (r) break;
-        HIP_TRY(c, hipEventRecord(c->ev_sub[i], main_stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->s_aux, c->ev_sub[i], 0));
-        c->stream = c->s_aux;                                   // (the launch helpers use the context's stream)
-        c->view_off = off;
-        c->cand_view = c->dCand + cand_off;
-        r = launch_scan(c, c->dQ + off, qstride, nb, d_ang + (size_t)off * c->n, d_lvl ? d_lvl + (size_t)off * c->n : nullptr, nullptr);
-        if (!r) r = launch_merge(c, nb, d_ang + (size_t)off * c->n, d_lvl ? d_lvl + (size_t)off * c->n : nullptr, nullptr);
-        cand_off += (size_t)nb * c->last_nsplit * topn_list_len(c->n);
-        c->stream = main_stream;
-        c->view_off = 0;
-        c->cand_view = nullptr;
-        if (r) break;
-    }
-    HIP_TRY(c, hipEventRecord(c->ev_join, c->s_aux));         // join (also after a failed launch: nothing may be left behind)
-    HIP_TRY(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
-    if (r) return r;
-    c->stat_next_clean = true;
-    return BAZ_MUSIC_OK;
-}
-
 int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void* d_ang, void* d_lvl,
                           void* d_spec)
 {
@@ -1265,9 +1209,6 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
     r = reserve_candidates(c, batch);
     if (r) return r;
     const uint32_t qstride = baz_music_q_stride(batch);
-    if (c->overlap > 1 && !d_spec && !c->peak_mode && !c->profiling && c->fused_covevd && coarse_applies(c) &&
-        batch >= (uint32_t)c->overlap * 16384u)
-        return process_overlapped(c, static_cast<const float*>(d_in), batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), qstride);
     if (c->fused_covevd) {
         r = launch_covevd(c, static_cast<const float*>(d_in), batch, c->dQ, qstride, c->dG);
         if (r) return r;
@@ -1414,7 +1355,6 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (const char* v = getenv("BAZ_MUSIC_COARSE_RG")) c->coarse_rg = atoi(v);                // lab
         if (const char* v = getenv("BAZ_MUSIC_COARSE_LAB")) c->coarse_lab = atoi(v);              // lab
         if (const char* v = getenv("BAZ_MUSIC_COARSE_STATS")) c->coarse_stats = atoi(v);          // lab
-        if (const char* v = getenv("BAZ_MUSIC_OVERLAP")) c->overlap = std::max(0, std::min(8, atoi(v)));
         if (m <= 8) {
             c->cs_tiles = round_up((resolution + 15) / 16, 8);
             if (hipMalloc((void**)&c->dCS, ((size_t)(c->cs_tiles + 1) * cs_c_units((int)m) + (size_t)c->cs_tiles * CS_X_UNITS * cs_groups((int)m)) * 16) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
@@ -1471,10 +1411,6 @@ void baz_music_destroy(baz_music_ctx* c)
             for (auto e : p.ev) (void)hipEventDestroy(e);
         if (c->dFB) (void)hipFree(c->dFB);
         if (c->dCand) (void)hipFree(c->dCand);
-        if (c->s_aux) (void)hipStreamDestroy(c->s_aux);
-        if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-        if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-        for (auto& e : c->ev_sub) if (e) (void)hipEventDestroy(e);
         if (c->dR) (void)hipFree(c->dR);
         if (c->dQ) (void)hipFree(c->dQ);
         if (c->dG) (void)hipFree(c->dG);
