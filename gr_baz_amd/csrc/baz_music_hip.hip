@@ -39,11 +39,6 @@ struct baz_music_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;      // the stream process_device() launches on (own or caller's)
-    // Default wiring, large calls at m = 4 (process_roles): sub-batches of ROLES_SUB items, covariance + EVD of sub-batch i + 1
-    // and the gated scan of sub-batch i as the two roles of one launch; views into the shared workspace for scan / merge
-    int roles = 1;                     // BAZ_MUSIC_ROLES=0: the serial launch sequence (A/B, tests)
-    double* cand_view = nullptr;       // candidates of the sub-batch being launched (nullptr: dCand)
-    size_t view_off = 0;               // its first item: offset into dQ / dG
     // steering table as the real bilinear-form table F[bin][m*m] (fp64) in MFMA B-operand order:
     // FB[step][chunk][lane] (double2), see build_FB; one padded step in front of step 0 and one behind the last
     // (the scan's row classes read shifted windows), dFB points at the allocation, step 0 is dFB + fb_step_elems
@@ -580,19 +575,18 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
                   float* d_lvl, float* d_spec)
 {
     if constexpr (M <= 8 && NMAX <= 4) {
-        if (!d_spec && coarse_applies(c) && dQ == c->dQ + c->view_off) {
+        if (!d_spec && coarse_applies(c) && dQ == c->dQ) {
             const CoarseGeom CG = coarse_geometry(c, batch);
-            if ((size_t)batch * CG.nsplit * NMAX + (c->cand_view ? (size_t)(c->cand_view - c->dCand) : 0) > c->cand_cap) return BAZ_MUSIC_E_INVALID;
+            if ((size_t)batch * CG.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;
             ScanRefine rf;
-            rf.Gs = c->refine_off ? nullptr : c->dG + c->view_off;
+            rf.Gs = c->refine_off ? nullptr : c->dG;
             rf.TB = c->dTB + c->tb_step_elems;
             rf.below = c->refine_below;
             rf.count = c->dRefined + c->stat_parity;
             rf.A2 = nullptr;
-            double* const cand_base = c->cand_view ? c->cand_view : c->dCand;
             unsigned long long* stats = c->coarse_stats ? c->dMargin : nullptr;     // lab: exact tile evaluations, summed over launches
 #define BAZ_COARSE_ARGS dim3(CG.groups * CG.nsplit), dim3(256), 0, c->stream, dQ, c->dCS, c->dCS + (size_t)(c->cs_tiles + 1) * cs_c_units(M), \
-                        cand_base, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, stats, nullptr
+                        c->dCand, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, stats, nullptr
             if constexpr (M > 4) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, coarse_rg_wide(M, NMAX), 4>), BAZ_COARSE_ARGS);
             else if (CG.tpp == 4) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 2, 4>), BAZ_COARSE_ARGS);
             else if (c->coarse_lab == 1) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8, false, 1>), BAZ_COARSE_ARGS);
@@ -670,8 +664,8 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
 template <int NMAX>
 int launch_merge_t(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl, float* d_spec)
 {
-    hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream,
-                       c->cand_view ? c->cand_view : c->dCand, d_spec, d_ang, d_lvl, batch, c->res, c->n, c->last_nsplit, c->keep_mask, c->dRefined + (c->stat_parity ^ 1));
+    hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream, c->dCand,
+                       d_spec, d_ang, d_lvl, batch, c->res, c->n, c->last_nsplit, c->keep_mask, c->dRefined + (c->stat_parity ^ 1));
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
 }
@@ -1202,71 +1196,6 @@ int begin_statistic(baz_music_ctx* c)
     return BAZ_MUSIC_OK;
 }
 
-// Default wiring (no spectrum port), m = 4, n <= 2, a large device-resident call: sub-batches of ROLES_SUB items (one
-// 64-item task per wave of the persistent covariance grid); launch j runs covariance + EVD of sub-batch j and the gated scan
-// of sub-batch j - 1 as the two roles of covevd_scan_roles_kernel, the tiny merge behind it.  Same kernels' bodies on the same
-// data as the serial sequence: bit-identical outputs.  The first sub-batch's covariance and the last one's scan run alone.
-constexpr uint32_t ROLES_SUB = 65536;
-bool roles_apply(const baz_music_ctx* c, uint32_t batch, const void* d_spec)
-{
-    return c->roles && !d_spec && !c->peak_mode && !c->profiling && c->m == 4 && c->n <= 2 && c->fused_covevd && coarse_applies(c) &&
-           c->coarse_rg != 2 && !c->coarse_lab && !c->coarse_stats && c->force_nsplit <= 0 && batch >= 2 * ROLES_SUB;
-}
-int process_roles(baz_music_ctx* c, const float* d_in, uint32_t batch, float* d_ang, float* d_lvl, uint32_t qstride)
-{
-    size_t cand_total = 0;                                     // every sub-batch its own candidate region
-    for (uint32_t off = 0; off < batch; off += ROLES_SUB)
-        cand_total += (size_t)std::min(ROLES_SUB, batch - off) * coarse_geometry(c, std::min(ROLES_SUB, batch - off)).nsplit * 2u;
-    int r = ensure_candidates(c, cand_total);
-    if (r) return r;
-    r = launch_covevd(c, d_in, std::min(ROLES_SUB, batch), c->dQ, qstride, c->dG);       // sub-batch 0: alone
-    if (r) return r;
-    size_t cand_off = 0;
-    for (uint32_t off = 0; off < batch; off += ROLES_SUB) {
-        const uint32_t nb = std::min(ROLES_SUB, batch - off);
-        float* const ang = d_ang + (size_t)off * c->n;
-        float* const lvl = d_lvl ? d_lvl + (size_t)off * c->n : nullptr;
-        c->view_off = off;
-        c->cand_view = c->dCand + cand_off;
-        const uint32_t noff = off + ROLES_SUB;
-        if (noff < batch) {                                    // this sub-batch's scan beside the next one's covariance + EVD
-            const uint32_t nnb = std::min(ROLES_SUB, batch - noff);
-            const CoarseGeom CG = coarse_geometry(c, nb);
-            RolesCovArgs ca{d_in + (size_t)noff * c->nsamples * 2, c->dQ + noff, c->dG + noff, nnb, c->K, c->n, qstride};
-            RolesScanArgs sa;
-            sa.Qs = c->dQ + off; sa.imgC = c->dCS; sa.imgX = c->dCS + (size_t)(c->cs_tiles + 1) * cs_c_units(4); sa.cand = c->cand_view;
-            sa.batch = nb; sa.res = c->res; sa.qstride = qstride; sa.nphases = CG.nphases; sa.nsplit = CG.nsplit;
-            sa.keep_mask = c->keep_mask; sa.n = c->n; sa.units = CG.groups * CG.nsplit;
-            sa.rf.Gs = c->refine_off ? nullptr : c->dG + off;
-            sa.rf.TB = c->dTB + c->tb_step_elems;
-            sa.rf.below = c->refine_below;
-            sa.rf.count = c->dRefined + c->stat_parity;
-            sa.rf.A2 = nullptr;
-            sa.cp = c->cs;
-            static const int roles_mode = getenv("BAZ_MUSIC_ROLES_MODE") ? atoi(getenv("BAZ_MUSIC_ROLES_MODE")) : 0;     // lab
-            uint32_t nprod = std::min<uint32_t>(((nnb + 63) / 64 + 3) / 4, c->covevd_blocks);
-            uint32_t ncons = std::min<uint32_t>(sa.units, c->covevd_blocks);          // one more workgroup per CU
-            if (roles_mode) { nprod = round_up(c->covevd_blocks, 8); ncons = nprod; }
-            hipLaunchKernelGGL((covevd_scan_roles_kernel<2, 4, 8>), dim3(nprod + ncons), dim3(256), 0, c->stream, ca, sa, nprod,
-                               (uint32_t)(roles_mode ? 1 : 0));
-            {
-                const hipError_t e = hipGetLastError();
-                r = (e == hipSuccess) ? BAZ_MUSIC_OK : hip_fail(c, e, "covevd_scan_roles_kernel");
-            }
-            c->last_nsplit = CG.nsplit;
-        } else {
-            r = launch_scan(c, c->dQ + off, qstride, nb, ang, lvl, nullptr);
-        }
-        if (!r) r = launch_merge(c, nb, ang, lvl, nullptr);
-        cand_off += (size_t)nb * c->last_nsplit * 2u;
-        c->view_off = 0;
-        c->cand_view = nullptr;
-        if (r) return r;
-    }
-    c->stat_next_clean = true;
-    return BAZ_MUSIC_OK;
-}
-
 int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void* d_ang, void* d_lvl,
                           void* d_spec)
 {
@@ -1280,8 +1209,6 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
     r = reserve_candidates(c, batch);
     if (r) return r;
     const uint32_t qstride = baz_music_q_stride(batch);
-    if (roles_apply(c, batch, d_spec))
-        return process_roles(c, static_cast<const float*>(d_in), batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), qstride);
     if (c->fused_covevd) {
         r = launch_covevd(c, static_cast<const float*>(d_in), batch, c->dQ, qstride, c->dG);
         if (r) return r;
@@ -1428,7 +1355,6 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (const char* v = getenv("BAZ_MUSIC_COARSE_RG")) c->coarse_rg = atoi(v);                // lab
         if (const char* v = getenv("BAZ_MUSIC_COARSE_LAB")) c->coarse_lab = atoi(v);              // lab
         if (const char* v = getenv("BAZ_MUSIC_COARSE_STATS")) c->coarse_stats = atoi(v);          // lab
-        if (const char* v = getenv("BAZ_MUSIC_ROLES")) c->roles = atoi(v);                        // A/B, tests
         if (m <= 8) {
             c->cs_tiles = round_up((resolution + 15) / 16, 8);
             if (hipMalloc((void**)&c->dCS, ((size_t)(c->cs_tiles + 1) * cs_c_units((int)m) + (size_t)c->cs_tiles * CS_X_UNITS * cs_groups((int)m)) * 16) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }

@@ -582,20 +582,15 @@ __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict_
 //     A streaming wave runs at s_setprio 3, an EVD phase at 0 (worth 0.04 ms against equal priorities once the waves
 //     drift apart).
 // -------------------------------------------------------------------------------------
-// The kernel's body over the LDS block `smem` (COV4_EVD_LDS_BYTES), as workgroup `bid` of `nblk`: shared by cov4_evd_kernel and
-// by the producer role of covevd_scan_roles_kernel (scan_coarse_kernels.hip.h).
-constexpr int COV4_EVD_RSD = 34;                                  // see cov4_x4_kernel
-constexpr int COV4_EVD_LDS_BYTES = (4 * 2 * 8 * COV4_EVD_RSD + 4 * 2 * 64 + 4 * 16 * 64) * 8;      // 54,272
-__device__ __forceinline__ void cov4_evd_body(double* __restrict__ smem, const uint32_t bid, const uint32_t nblk,
-                                              const float* __restrict__ in, double* __restrict__ Qs,
-                                              double* __restrict__ Gs, double2* __restrict__ Rdbg,
-                                              uint32_t batch, uint32_t K, uint32_t n, uint32_t qstride)
+__global__ __launch_bounds__(256) void cov4_evd_kernel(const float* __restrict__ in, double* __restrict__ Qs,
+                                                       double* __restrict__ Gs, double2* __restrict__ Rdbg,
+                                                       uint32_t batch, uint32_t K, uint32_t n, uint32_t qstride)
 {
-    constexpr int RSD = COV4_EVD_RSD;
+    constexpr int RSD = 34;                       // see cov4_x4_kernel
     constexpr int RING = 8;                       // chunk loads in flight per wave (8 KiB)
-    double(*const stage)[2][8 * RSD] = reinterpret_cast<double(*)[2][8 * RSD]>(smem);                         // per wave, double-buffered
-    double(*const gram)[2][64] = reinterpret_cast<double(*)[2][64]>(smem + 4 * 2 * 8 * RSD);                // per wave: D1, D2
-    double(*const rtab)[16][64] = reinterpret_cast<double(*)[16][64]>(smem + 4 * 2 * 8 * RSD + 4 * 2 * 64); // per wave: R of 64 items, [slot][item]: 4 diagonals, 6 x (re, im)
+    __shared__ double stage[4][2][8 * RSD];       // per wave, double-buffered
+    __shared__ double gram[4][2][64];             // per wave: D1, D2
+    __shared__ double rtab[4][16][64];            // per wave: R of 64 items, [slot][item]: 4 diagonals, 6 x (re, im)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t chunks = K >> 5;               // 1-KiB chunks per item (multiple of 8)
@@ -608,13 +603,13 @@ __device__ __forceinline__ void cov4_evd_body(double* __restrict__ smem, const u
     double(*const rt)[64] = rtab[wave];
     const double dK = (double)K;
     const uint32_t ntasks = (batch + 63) >> 6;
-    const uint32_t tstride = nblk * 4;
+    const uint32_t tstride = gridDim.x * 4;
     // slot of the upper-triangle entry this lane (< 16: a = lane>>2, b = lane&3) produces: diagonal a -> a;
     // pair (a < b) -> 4 + 2p (re), 5 + 2p (im), p = index of (a, b) in (0,1)(0,2)(0,3)(1,2)(1,3)(2,3)
     const int ea = (lane >> 2) & 3, eb = lane & 3;
     const int pidx = (ea == 0) ? eb - 1 : (ea == 1 ? eb + 1 : 5);
 
-    for (uint32_t task = bid * 4 + wave; task < ntasks; task += tstride) {
+    for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += tstride) {
         __builtin_amdgcn_s_setprio(3);
         const uint32_t item0 = task * 64;
         const uint32_t nit = (batch - item0 < 64u) ? batch - item0 : 64u;
@@ -690,15 +685,6 @@ __device__ __forceinline__ void cov4_evd_body(double* __restrict__ smem, const u
         }
         wave_lds_fence();
     }
-    __builtin_amdgcn_s_setprio(0);
-}
-
-__global__ __launch_bounds__(256) void cov4_evd_kernel(const float* __restrict__ in, double* __restrict__ Qs,
-                                                       double* __restrict__ Gs, double2* __restrict__ Rdbg,
-                                                       uint32_t batch, uint32_t K, uint32_t n, uint32_t qstride)
-{
-    __shared__ __attribute__((aligned(16))) double smem[COV4_EVD_LDS_BYTES / 8];
-    cov4_evd_body(smem, blockIdx.x, gridDim.x, in, Qs, Gs, Rdbg, batch, K, n, qstride);
 }
 
 // -------------------------------------------------------------------------------------

@@ -152,22 +152,16 @@ __device__ __forceinline__ float row_kth_smallest(float v, const uint32_t k)
 // single exact tile has run.  Without it the thresholds only tighten as the walk happens to pass the minima: on a
 // descending slope of the spectrum EVERY tile beats the list and fires (measured: 0.28 ms per 262,144 coherent cfg2 items,
 // and 0.93 ms -- slower than the full scan -- when every item of a wave has its own scene).  PASS 2: the gated walk.
-// LDS of one workgroup, in 16-B units
-template <int M, int RG, int TPP>
-constexpr int coarse_lds_units()
-{
-    return 2 * ((TPP + 1) * cs_c_units(M) + (cs_groups(M) == 1 ? TPP * CS_X_UNITS : 0));
-}
-
-// The kernel's body as workgroup `bid` of the launch geometry (nsplit ranges per group of 4 waves x RG x 16 items), over the
-// LDS block `smem`: shared by scan_coarse_kernel and by the consumer role of covevd_scan_roles_kernel.
 template <int M, int NMAX, int RG, int TPP, bool VAL = false, int LAB = 0>
-__device__ __forceinline__ void scan_coarse_body(uint4* __restrict__ smem, const uint32_t bid, const double* __restrict__ Qs,
-                                                 const uint4* __restrict__ imgC, const uint4* __restrict__ imgX,
-                                                 double* __restrict__ cand, uint32_t batch, uint32_t res, uint32_t qstride,
-                                                 uint32_t nphases, uint32_t nsplit, uint32_t keep_mask, uint32_t n,
-                                                 ScanRefine rf, CoarseParams cp, unsigned long long* __restrict__ margin,
-                                                 float* __restrict__ val_dump)
+__global__ __launch_bounds__(256, (RG <= 2 && M <= 4) ? 3 : 2) void scan_coarse_kernel(const double* __restrict__ Qs,
+                                                                             const uint4* __restrict__ imgC,
+                                                                             const uint4* __restrict__ imgX,
+                                                                             double* __restrict__ cand, uint32_t batch,
+                                                                             uint32_t res, uint32_t qstride, uint32_t nphases,
+                                                                             uint32_t nsplit, uint32_t keep_mask, uint32_t n,
+                                                                             ScanRefine rf, CoarseParams cp,
+                                                                             unsigned long long* __restrict__ margin,
+                                                                             float* __restrict__ val_dump = nullptr)
 {
     constexpr int MM = M * M;
     constexpr int NGC = cs_groups(M);                  // groups of 16 terms (4 fp64 k-steps each)
@@ -183,15 +177,14 @@ __device__ __forceinline__ void scan_coarse_body(uint4* __restrict__ smem, const
     // across the phase boundary) -- and the X operands of TPP tiles
     constexpr int C_UNITS = (TPP + 1) * TC_UNITS, X_UNITS = XLDS ? TPP * TX_UNITS : 0;
     constexpr int C_CHUNKS = C_UNITS / 64, X_CHUNKS = X_UNITS / 64;         // 1-KiB wave loads per phase
-    static_assert(2 * (C_UNITS + X_UNITS) == coarse_lds_units<M, RG, TPP>(), "LDS size");
-    auto& stage = *reinterpret_cast<uint4(*)[2][C_UNITS + X_UNITS]>(smem);   // per buffer: [Fh | Fl of TPP + 1 tiles][X of TPP tiles]
+    __shared__ uint4 stage[2][C_UNITS + X_UNITS];                            // per buffer: [Fh | Fl of TPP + 1 tiles][X of TPP tiles]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, g = lane >> 4;
 
-    const uint32_t split = bid % nsplit;
-    const uint32_t item0 = ((bid / nsplit) * 4 + wave) * (16 * RG);             // first item of the wave
+    const uint32_t split = blockIdx.x % nsplit;
+    const uint32_t item0 = ((blockIdx.x / nsplit) * 4 + wave) * (16 * RG);      // first item of the wave
     const uint32_t ph_begin = (uint32_t)(((uint64_t)nphases * split) / nsplit);
     const uint32_t ph_end = (uint32_t)(((uint64_t)nphases * (split + 1)) / nsplit);
 
@@ -565,64 +558,6 @@ __device__ __forceinline__ void scan_coarse_body(uint4* __restrict__ smem, const
                     for (int i = 0; i < NMAX; ++i) cand[((size_t)it * nsplit + split) * NMAX + i] = key[q][r][i];
                 }
             }
-    }
-}
-
-template <int M, int NMAX, int RG, int TPP, bool VAL = false, int LAB = 0>
-__global__ __launch_bounds__(256, (RG <= 2 && M <= 4) ? 3 : 2) void scan_coarse_kernel(const double* __restrict__ Qs,
-                                                                             const uint4* __restrict__ imgC,
-                                                                             const uint4* __restrict__ imgX,
-                                                                             double* __restrict__ cand, uint32_t batch,
-                                                                             uint32_t res, uint32_t qstride, uint32_t nphases,
-                                                                             uint32_t nsplit, uint32_t keep_mask, uint32_t n,
-                                                                             ScanRefine rf, CoarseParams cp,
-                                                                             unsigned long long* __restrict__ margin,
-                                                                             float* __restrict__ val_dump = nullptr)
-{
-    __shared__ uint4 smem[coarse_lds_units<M, RG, TPP>()];
-    scan_coarse_body<M, NMAX, RG, TPP, VAL, LAB>(smem, blockIdx.x, Qs, imgC, imgX, cand, batch, res, qstride, nphases, nsplit,
-                                                  keep_mask, n, rf, cp, margin, val_dump);
-}
-
-// -------------------------------------------------------------------------------------------------------------------------
-// Covariance + EVD of one sub-batch AND the gated scan of the previous one in ONE launch (m = 4, K % 256 == 0, n <= 2,
-// spectrum port not wired; review r2, item 2).  The two kernels want different things -- the HBM read stream against
-// the f16 matrix core and LDS -- and run one after the other only because a launch of either fills the chip.  Two streams
-// do not fix that (measured three times: the dispatcher runs the launches back to back, and event-chained sub-batches add
-// ~50 us each, profiles/r03_negative_*.txt).  Here the workgroups of one grid take ROLES: the first `nprod` (one per CU,
-// the persistent grid of cov4_evd_kernel) stream sub-batch i + 1, the others walk the scan's work units of sub-batch i (whose
-// q the previous launch wrote).  No flags, no spinning: the dependency is between launches.  Both bodies are the stand-alone
-// kernels' (same instructions on the same data: bit-identical outputs); the LDS block is shared between the roles.
-// -------------------------------------------------------------------------------------------------------------------------
-struct RolesCovArgs {
-    const float* in; double* Qs; double* Gs; uint32_t batch, K, n, qstride;
-};
-struct RolesScanArgs {
-    const double* Qs; const uint4* imgC; const uint4* imgX; double* cand;
-    uint32_t batch, res, qstride, nphases, nsplit, keep_mask, n, units;
-    ScanRefine rf; CoarseParams cp;
-};
-template <int NMAX, int RG, int TPP>
-constexpr int roles_lds_units()
-{
-    return coarse_lds_units<4, RG, TPP>() > COV4_EVD_LDS_BYTES / 16 ? coarse_lds_units<4, RG, TPP>() : COV4_EVD_LDS_BYTES / 16;
-}
-template <int NMAX, int RG, int TPP>
-__global__ __launch_bounds__(256, 2) void covevd_scan_roles_kernel(RolesCovArgs ca, RolesScanArgs sa, uint32_t nprod, uint32_t mode)
-{
-    __shared__ uint4 smem[roles_lds_units<NMAX, RG, TPP>()];
-    // which workgroups produce: mode 0 the first nprod; mode 1 every other one of an XCD's sequence (workgroup b goes to XCD
-    // b % 8; its neighbours there are b +- 8), gridDim.x = 2 nprod
-    const uint32_t b = blockIdx.x;
-    const bool producer = mode ? (((b >> 3) & 1u) == 0) : (b < nprod);
-    const uint32_t rid = mode ? (((b >> 4) << 3) | (b & 7u)) : (producer ? b : b - nprod);
-    if (producer) {
-        cov4_evd_body(reinterpret_cast<double*>(smem), rid, nprod, ca.in, ca.Qs, ca.Gs, nullptr, ca.batch, ca.K, ca.n, ca.qstride);
-    } else {
-        const uint32_t ncons = gridDim.x - nprod;
-        for (uint32_t u = rid; u < sa.units; u += ncons)
-            scan_coarse_body<4, NMAX, RG, TPP>(smem, u, sa.Qs, sa.imgC, sa.imgX, sa.cand, sa.batch, sa.res, sa.qstride, sa.nphases,
-                                                sa.nsplit, sa.keep_mask, sa.n, sa.rf, sa.cp, nullptr, nullptr);
     }
 }
 
