@@ -72,9 +72,6 @@ struct baz_music_ctx {
     std::mutex mtx;   // serialises set_table against process*, like d_mutex (.cc:67,101)
     int profiling = 0;      // 0 off, 1 every stage, 2 only the dominant (scan) stage
     int lab_variant = 0;
-    int res_scan = 1;              // m = 4, spectrum port wired, large batches: scan_res_kernel (table resident in LDS; BAZ_MUSIC_RES_SCAN=0: lab / A-B)
-    uint32_t cus = 256;            // compute units of the device (the resident scan launches one workgroup per CU)
-    bool scan_res_last = false;    // the last full scan launch was scan_res_kernel (baz_music_stage_name)
     // literal-form refinement of near-null tiles (literal_tile() inside the scan)
     double* dG = nullptr;          // noise eigenvectors, item-minor like dQ (cap * m*m * 2 doubles)
     double2* dTB = nullptr;        // raw steering table as fp64 MFMA B-operand image (build_TB), padded like dFB
@@ -532,35 +529,6 @@ ScanGeom scan_geometry(uint32_t batch, uint32_t nsteps, uint32_t nclass, int for
     return G;
 }
 
-// Launch geometry of the table-resident scan (scan_res_kernel): the fewest bin ranges whose longest range -- plus the step
-// in front of it (shifted row classes) and the extra step a shifted class may end on -- fits the LDS budget, one
-// 16-wave workgroup per CU, ranges dealt b % nsplit.  Applies to m = 4, n <= 2 with the spectrum port wired when every
-// wave gets at least RES_MIN_TASKS row groups (below that the staged kernel's finer tasks balance better).
-constexpr uint32_t RES_LDS_STEPS_MAX = 19u;     // x 8 KiB = 152 KiB of the CU's 160 KiB
-constexpr uint32_t RES_MIN_TASKS = 4u;
-struct ResGeom {
-    bool ok;
-    uint32_t nsplit, blocks, lds_steps, rows_per_class;
-};
-
-ResGeom res_geometry(const baz_music_ctx* c, uint32_t batch)
-{
-    ResGeom R = {false, 1, 0, 0, 0};
-    if (!c->res_scan || c->m != 4 || c->n > 2 || c->lab_variant || c->fb_steps == 0) return R;
-    const uint32_t nsteps0 = c->fb_steps;
-    R.nsplit = (nsteps0 + (RES_LDS_STEPS_MAX - 2u) - 1u) / (RES_LDS_STEPS_MAX - 2u);
-    if (c->force_nsplit > 0) R.nsplit = std::max<uint32_t>(R.nsplit, (uint32_t)c->force_nsplit);   // tests: more ranges than needed
-    if (R.nsplit > 8u || R.nsplit > nsteps0) return R;
-    R.lds_steps = (nsteps0 + R.nsplit - 1u) / R.nsplit + 2u;
-    const uint32_t bps = c->cus / R.nsplit;
-    if (bps == 0) return R;
-    R.blocks = bps * R.nsplit;
-    R.rows_per_class = round_up((batch + c->nclass - 1) / c->nclass, 64);
-    const uint32_t live_groups = (batch + 15u) / 16u;
-    R.ok = c->res_scan >= 2 || live_groups >= bps * 16u * RES_MIN_TASKS;   // (2: tests force it for small batches)
-    return R;
-}
-
 int ensure_candidates(baz_music_ctx* c, size_t entries)
 {
     if (entries <= c->cand_cap) return BAZ_MUSIC_OK;
@@ -671,23 +639,6 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
 #define BAZ_SCAN_LAUNCH(SPEC, VEC4, ABLV, AUXV)                                                                    \
     hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4, ABLV, AUXV>), dim3(G.blocks), dim3(256), 0, c->stream, \
                        BAZ_SCAN_ARGS)
-    if constexpr (M == 4 && NMAX == 2) {
-        if (const ResGeom R = res_geometry(c, batch); spec && R.ok) {   // large batches: the table-resident form (same bits)
-            if ((size_t)batch * R.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;
-            const size_t lds = (size_t)R.lds_steps * c->fb_step_elems * sizeof(double2);
-#define BAZ_RES_LAUNCH(VEC4)                                                                                              \
-    hipLaunchKernelGGL((scan_res_kernel<NMAX, VEC4>), dim3(R.blocks), dim3(1024), lds, c->stream, dQ, fb0, d_spec, cand, batch, \
-                       c->res, qstride, R.nsplit, c->nclass, R.rows_per_class, c->keep_mask, c->n, R.lds_steps, rf, (uint32_t)(getenv("BAZ_MUSIC_RES_LAB") ? atoi(getenv("BAZ_MUSIC_RES_LAB")) : 0))
-            if (vec4) BAZ_RES_LAUNCH(true);
-            else BAZ_RES_LAUNCH(false);
-#undef BAZ_RES_LAUNCH
-            HIP_TRY(c, hipGetLastError());
-            c->last_nsplit = R.nsplit;
-            c->scan_res_last = true;
-            return BAZ_MUSIC_OK;
-        }
-    }
-    c->scan_res_last = false;
     if constexpr (M == 4 && NMAX == 2) {   // lab switches for the A/Bs in profiles/HISTORY_r01_r02.md 5.3 (BAZ_MUSIC_SCAN_VARIANT)
         if (spec && vec4 && c->lab_variant) {
             switch (c->lab_variant) {
@@ -695,9 +646,10 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
                 case 3: BAZ_SCAN_LAUNCH(true, true, 0, 0); break;               // plain cached spectrum stores
                 case 4: BAZ_SCAN_LAUNCH(true, true, 0, 2); break;               // nt
                 case 5: BAZ_SCAN_LAUNCH(true, true, 0, (1 | 16)); break;        // sc0 sc1
-                case 6: BAZ_SCAN_LAUNCH(true, true, 1, (1 | 2 | 16)); break;    // lab: everything but the spectrum stores
-                case 7: BAZ_SCAN_LAUNCH(true, true, (8 | 2 | 4), (1 | 2 | 16)); break;   // lab: stores + staging + barriers only
-                case 8: BAZ_SCAN_LAUNCH(true, true, (1 | 2), (1 | 2 | 16)); break;       // lab: MFMA + conversions, no top-n, no stores
+                // (6-8: timing only, wrong results -- tests/lab/scan_ablate.py, profiles/r03_scan_ablation_real_inputs.txt)
+                case 6: BAZ_SCAN_LAUNCH(true, true, 1, (1 | 2 | 16)); break;              // everything but the spectrum stores
+                case 7: BAZ_SCAN_LAUNCH(true, true, (8 | 2 | 4), (1 | 2 | 16)); break;    // stores + staging + barriers only
+                case 8: BAZ_SCAN_LAUNCH(true, true, (1 | 2), (1 | 2 | 16)); break;        // MFMA + conversions, no top-n, no stores
                 default: BAZ_SCAN_LAUNCH(true, true, 0, (1 | 2 | 16)); break;
             }
             HIP_TRY(c, hipGetLastError());
@@ -742,7 +694,6 @@ size_t cand_entries(const baz_music_ctx* c, uint32_t nb)
 {
     size_t per_item = scan_geometry(nb, c->fb_steps, c->nclass, c->force_nsplit).nsplit;
     if (c->m <= 8 && c->dCS) per_item = std::max<size_t>(per_item, coarse_geometry(c, nb).nsplit);
-    if (const ResGeom R = res_geometry(c, nb); R.ok) per_item = std::max<size_t>(per_item, R.nsplit);
     return (size_t)nb * per_item * topn_list_len(c->n);
 }
 
@@ -758,8 +709,7 @@ size_t cand_entries_upto(const baz_music_ctx* c, uint32_t batch)
     const size_t forced = c->force_nsplit > 0 ? (size_t)batch * std::min<size_t>((size_t)c->force_nsplit, cap_split) : 0;
     // the coarse-gated scan: nsplit = ceil(COARSE_WANT_BLOCKS / ceil(nb / 128)) <= 16  ->  nb * nsplit <= 128 * WANT + nb
     const size_t coarse = (c->m <= 8) ? std::min<size_t>((size_t)batch * 16u, 128u * COARSE_WANT_BLOCKS + (size_t)batch) : 0;
-    const size_t resident = (c->m == 4) ? (size_t)batch * 8u : 0;                    // res_geometry(): nsplit <= 8
-    return std::max(std::max(std::max(std::max(worst, forced), coarse), resident), (size_t)batch) * topn_list_len(c->n);
+    return std::max(std::max(std::max(worst, forced), coarse), (size_t)batch) * topn_list_len(c->n);
 }
 
 int reserve_candidates(baz_music_ctx* c, uint32_t batch)
@@ -1324,7 +1274,6 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     c->m = m; c->n = n; c->nsamples = nsamples; c->res = resolution; c->K = nsamples / m;
     c->device = dev;
     if (const char* v = getenv("BAZ_MUSIC_SCAN_VARIANT")) c->lab_variant = atoi(v);
-    if (const char* v = getenv("BAZ_MUSIC_RES_SCAN")) c->res_scan = std::max(0, std::min(2, atoi(v)));   // lab / A-B / tests
     if (const char* v = getenv("BAZ_MUSIC_CHUNK_MIB")) c->chunk_bytes = (size_t)std::max(1, std::min(1024, atoi(v))) << 20;
     if (const char* v = getenv("BAZ_MUSIC_PIN_LIMIT_MIB")) c->pin_limit = (uint64_t)std::max(0, atoi(v)) << 20;
     if (const char* v = getenv("BAZ_MUSIC_ZERO_COPY")) c->zero_copy = atoi(v) != 0;
@@ -1424,13 +1373,6 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
             c->cov4_resident_blocks = (uint32_t)std::max(1, prop.multiProcessorCount);
             if (const char* v = getenv("BAZ_MUSIC_COV_BLOCKS_PER_CU"))    // lab: grid of the covariance kernel
                 if (atoi(v) > 0) c->cov4_resident_blocks = (uint32_t)atoi(v) * (uint32_t)std::max(1, prop.multiProcessorCount);
-        }
-        c->cus = (uint32_t)std::max(1, prop.multiProcessorCount);
-        if (m == 4) {   // scan_res_kernel keeps up to 19 table steps (152 KiB) in LDS: beyond 64 KiB the function needs the attribute
-            const int lds = (int)(RES_LDS_STEPS_MAX * c->fb_step_elems * sizeof(double2));
-            const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(scan_res_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
-                            hipFuncSetAttribute(reinterpret_cast<const void*>(scan_res_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
-            if (!ok) c->res_scan = 0;   // (the staged kernel then serves every call)
         }
         if (hipMalloc((void**)&c->dRefined, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         if (hipMemset(c->dRefined, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
@@ -1785,7 +1727,6 @@ int baz_music_stage_ms(baz_music_ctx* c, int stage, double* total_ms, uint64_t* 
 const char* baz_music_stage_name(baz_music_ctx* c, int stage)
 {
     if (!c || stage < 0 || stage >= BAZ_MUSIC_NUM_STAGES) return "";
-    if (stage == BAZ_MUSIC_STAGE_SCAN && c->scan_res_last) return "bazmusic::scan_res_kernel<2,";
     return c->stage_name[stage].c_str();
 }
 

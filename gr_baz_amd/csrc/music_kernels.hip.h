@@ -1809,231 +1809,6 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
 #undef BAZ_FB_LD
 #undef BAZ_STAGE_STORE
 
-// =====================================================================================
-// 4b. The scan with the table RESIDENT in LDS (round 3; m = 4, spectrum port wired, large batches).
-//
-//    scan_mfma_kernel's waves spend most of a step waiting: its step costs ~1,300 issue cycles, yet a wave completes one
-//    every ~7,500.  Two couplings do that.  (1) The next step's table slice arrives by global loads, and on this ISA the
-//    wait for a load is also a wait for every OLDER store of the wave (one counter, vmcnt): a wave never has more than one
-//    step of spectrum stores in flight.  (2) The four waves of a workgroup share the staged slice, so one wave held at a
-//    full store queue holds three others at the barrier.  Here a workgroup of 16 waves keeps its range of table steps in
-//    LDS for the whole launch (cfg2: 57 steps in 4 ranges, <= 17 steps x 8 KiB = 136 of the CU's 160 KiB; one workgroup
-//    per CU) and every wave walks 16-row groups on its own: no loads, no waits and no barriers inside the step loop.
-//    Operands, MFMA order, gate, literal refinement, keys and stores are scan_mfma_kernel's, instruction for instruction,
-//    so every d, key and spectrum float has the same bits; only the candidate lists are cut at other step boundaries,
-//    which the merge does not see.
-//
-//    Geometry: block b -> range split = b % nsplit (XCD b % 8 therefore serves range b % nsplit when nsplit divides 8),
-//    wave slot ws = (b / nsplit) * 16 + wave takes the 16-row groups ws, ws + stride, ...  Ranges are cut on the step
-//    count of class 0 (nsteps0 = ceil(res / 64)); the last range also takes the one extra step a shifted class may have.
-// =====================================================================================
-template <int NMAX, bool VEC4, int AUX = (1 | 2 | 16)>
-__global__ __launch_bounds__(1024, 1) void scan_res_kernel(const double* __restrict__ Qs, const double2* __restrict__ FB,
-                                                            float* __restrict__ spec, double* __restrict__ cand,
-                                                            uint32_t batch, uint32_t res, uint32_t qstride, uint32_t nsplit,
-                                                            uint32_t nclass, uint32_t rows_per_class, uint32_t keep_mask,
-                                                            uint32_t n, uint32_t lds_steps, ScanRefine rf, uint32_t lab_drain)
-{
-    constexpr int M = 4, MM = 16, KS = 4;
-    constexpr int STEP_ELEMS = 2 * KS * 64;            // v2f64 elements of one 64-bin step of FB (8 KiB)
-    extern __shared__ v2f64 restab[];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    // block -> (range, slot).  Workgroups go to the 8 XCDs round-robin (XCD = blockIdx % 8).  xmap 1 puts the nsplit ranges of
-    // one slot on the SAME XCD (they then write the same rows at the same time and share its address-translation cache);
-    // xmap 0 is the plain order (range = blockIdx % nsplit: an XCD serves one range)
-    uint32_t split = blockIdx.x % nsplit, slot = blockIdx.x / nsplit;
-    if (lab_drain >= 100u && (gridDim.x % (8u * nsplit)) == 0) {
-        split = (blockIdx.x >> 3) % nsplit;
-        slot = (blockIdx.x & 7u) + 8u * (blockIdx.x / (8u * nsplit));
-    }
-    if (lab_drain >= 100u) lab_drain = 0;
-    const uint32_t nsteps0 = (res + 63u) >> 6;
-    const uint32_t st_begin = (uint32_t)(((uint64_t)nsteps0 * split) / nsplit);
-    const uint32_t st_end0 = (uint32_t)(((uint64_t)nsteps0 * (split + 1)) / nsplit);
-    const bool last_range = (split + 1 == nsplit);
-
-    // this range's slice of the table: steps st_begin - 1 (the shifted classes reach one step back) .. st_begin - 1 + lds_steps
-    {
-        const v2f64* __restrict__ src = reinterpret_cast<const v2f64*>(FB) + ((ptrdiff_t)st_begin - 1) * STEP_ELEMS;
-        const uint32_t have = (nsteps0 + 2u) - st_begin;            // FB holds steps -1 .. nsteps0
-        const uint32_t cnt = (lds_steps < have ? lds_steps : have) * (uint32_t)STEP_ELEMS;
-        for (uint32_t i = threadIdx.x; i < cnt; i += 1024u) restab[i] = src[i];
-    }
-    __syncthreads();
-
-    const uint32_t ngroups = nclass * (rows_per_class >> 4);
-    const uint32_t stride = (gridDim.x / nsplit) * 16u;
-    v4f32 sv[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // spectrum values of item row r (see scan_mfma_kernel)
-    const bool refine_on = rf.Gs != nullptr;                         // wave-uniform
-    const float below_f = refine_on ? (float)rf.below : -1.0f;
-    const double below_d = refine_on ? rf.below : -1.0;
-
-    // A operand of the NEXT group, fetched one group ahead: its latency (and the store drain the wait implies) is over
-    // long before the group starts
-    double qn[KS];
-    {
-        const uint32_t t0 = slot * 16u + (uint32_t)wave;
-        const uint32_t pp = t0 * 16u, cl = pp / rows_per_class;
-        const uint32_t itn = nclass * (pp - cl * rows_per_class) + cl + nclass * (uint32_t)(lane & 15);
-        const uint32_t itc0 = (itn < batch) ? itn : (batch - 1);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) qn[s] = Qs[(size_t)(4 * s + (lane >> 4)) * qstride + itc0];
-    }
-    for (uint32_t task = slot * 16u + (uint32_t)wave; task < ngroups; task += stride) {
-        // lane coordinates re-derived per group behind an opaque copy: whatever depends on them is then recomputed (a few
-        // VALU instructions) instead of being hoisted out of this loop and spilled -- a reload is a load, and every wait for
-        // one is a serial round trip through a memory system that is busy with the spectrum
-        int lane_t = lane;
-        asm volatile("" : "+v"(lane_t));
-        const int c = lane_t & 15, g = lane_t >> 4;
-        const uint32_t p0 = task * 16u;                                  // first row of the group in class-major order
-        const uint32_t cls = __builtin_amdgcn_readfirstlane(p0 / rows_per_class);
-        const uint32_t j0 = p0 - cls * rows_per_class;
-        const uint32_t item0 = nclass * j0 + cls;                        // row x of the group is item item0 + nclass*x
-        double qa[KS];
-        const uint32_t it_c = item0 + nclass * (uint32_t)c;
-        const uint32_t itc = (it_c < batch) ? it_c : (batch - 1);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) qa[s] = qn[s];
-        {
-            const uint32_t tn = task + stride;
-            const uint32_t pp = (tn < ngroups ? tn : task) * 16u, cl = pp / rows_per_class;
-            const uint32_t itn = nclass * (pp - cl * rows_per_class) + cl + nclass * (uint32_t)c;
-            const uint32_t itcn = (itn < batch) ? itn : (batch - 1);
-#pragma unroll
-            for (int s = 0; s < KS; ++s) qn[s] = Qs[(size_t)(4 * s + g) * qstride + itcn];
-        }
-        if (item0 >= batch) continue;                                    // a padding group: nothing to write
-        const uint32_t sh = ((res & 63u) * cls) & 63u;
-        const int shc = (int)(sh >> 2);
-        const uint32_t nsteps = (res + sh + 63u) >> 6;
-        const uint32_t st_end = last_range ? nsteps : st_end0;
-
-        double key[4][NMAX];
-        float gate_f[4];
-        double gate_d[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int i = 0; i < NMAX; ++i) key[r][i] = key_empty();
-            gate_f[r] = __builtin_inff();
-            gate_d[r] = __builtin_bit_cast(double, (uint64_t)BAZ_KEY_EMPTY_BITS | 0xFFFFFull);
-        }
-
-        // this lane's element of a step's chunks: column c - shc of the step, or column c - shc + 16 of the step before
-        const int cc = c - shc;
-        const v2f64* __restrict__ tl = restab + (g * 16 + (cc < 0 ? cc + 16 : cc)) + (cc < 0 ? 0 : STEP_ELEMS);   // step st_begin
-
-        float* __restrict__ spec_base = spec + (size_t)item0 * res - sh;
-        __amdgpu_buffer_rsrc_t spec_rsrc = __builtin_amdgcn_make_buffer_rsrc(spec_base, 0, 0x7FFFFFFF, 0x00020000);
-        uint32_t soff[4];
-        bool row_ok[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            soff[r] = ((uint32_t)(g + 4 * r) * nclass * res + 4u * (uint32_t)c) * 4u;
-            row_ok[r] = (item0 + nclass * (uint32_t)(g + 4 * r)) < batch;
-        }
-
-        for (uint32_t st = st_begin; st < st_end; ++st) {
-            v4f64 acc[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0, 0, 0, 0};
-            const uint32_t bin = st * 64 + 4 * c - sh;
-            const v2f64* __restrict__ tp = tl + (size_t)(st - st_begin) * STEP_ELEMS;
-            if (lab_drain && ((st - st_begin) % lab_drain) == lab_drain - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // lab
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const v2f64 f01 = tp[(2 * s) * 64];
-                const v2f64 f23 = tp[(2 * s + 1) * 64];
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f01.x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f01.y, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f23.x, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f23.y, acc[3], 0, 0, 0);
-            }
-            // the previous step's store data stay allocated until here (scan_mfma_kernel, step 3)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(sv[r]));
-            bool hit = false, low = false;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float fd[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) fd[t] = (float)acc[t][r];
-                float mn;
-                asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(mn) : "v"(fd[0]), "v"(fd[1]), "v"(fd[2]));
-                asm("v_min_f32 %0, %1, |%2|" : "=v"(mn) : "v"(mn), "v"(fd[3]));
-                hit |= (mn <= gate_f[r]);
-                low |= (mn <= below_f);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) sv[r][t] = __builtin_amdgcn_rcpf(fabsf(fd[t]));
-            }
-            if (__any(hit)) {
-                if (refine_on && __any(low)) {
-                    const v2f64* __restrict__ tbl = reinterpret_cast<const v2f64*>(rf.TB) +
-                        (g * 16 + (cc < 0 ? cc + 16 : cc)) - (cc < 0 ? ((2 * M + 3) / 4) * 2 * 64 : 0);
-                    uint32_t cnt = literal_tile<M>(acc, rf, tbl, st, itc, g, qstride, (int)M - (int)n, bin, res, row_ok);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) sv[r][t] = strength_f32(fabs(acc[t][r]));
-                    if (rf.count) {
-#pragma unroll
-                        for (int msk = 1; msk < 64; msk <<= 1) cnt += __shfl_xor(cnt, msk, 64);
-                        if (lane == 0 && cnt) atomicAdd(rf.count, (unsigned long long)cnt);
-                    }
-                }
-                const uint32_t nobin = ~keep_mask;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        key_insert_new<NMAX>(key[r], make_key(acc[t][r], (bin + t < res) ? bin + t : nobin, keep_mask));
-                    const uint64_t kb = __builtin_bit_cast(uint64_t, key[r][NMAX - 1]) | (uint64_t)(~keep_mask);
-                    gate_d[r] = fmax(__builtin_bit_cast(double, kb), below_d);
-                    gate_f[r] = (float)gate_d[r];
-                }
-            }
-            const int step_off = (int)(st * 256u);
-            if constexpr (VEC4) {
-                if ((st > 0 || sh == 0) && st * 64 + 64 - sh <= res) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (row_ok[r]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, AUX);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (row_ok[r] && bin < res) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, AUX);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const v4u32 u = __builtin_bit_cast(v4u32, sv[r]);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (row_ok[r] && bin + t < res)
-                            __builtin_amdgcn_raw_buffer_store_b32(u[t], spec_rsrc, (int)(soff[r] + 4u * t), step_off, AUX);
-                }
-            }
-        }
-
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            key_merge_xor<NMAX>(key[r], 1);
-            key_merge_xor<NMAX>(key[r], 2);
-            key_merge_xor<NMAX>(key[r], 4);
-            key_merge_xor<NMAX>(key[r], 8);
-            const uint32_t it = item0 + nclass * (uint32_t)(g + 4 * r);
-            if (c == 0 && it < batch) {
-#pragma unroll
-                for (int i = 0; i < NMAX; ++i) cand[((size_t)it * nsplit + split) * NMAX + i] = key[r][i];
-            }
-        }
-    }
-}
-
 // Final top-n over the per-range candidate keys (one thread per item), ang / lvl outputs
 // (lib/baz_music_doa.cc:129-155).  lvl[i] is read back from the spectrum this launch sequence just
 // wrote when port 2 is wired, so that lvl[i] == spectrum[bin_i] holds bit for bit as in the reference.
