@@ -126,16 +126,6 @@ struct baz_music_ctx {
     uint64_t pin_limit = 4096ull << 20;                  // BAZ_MUSIC_PIN_LIMIT_MIB
     int auto_pin = 0;                                    // baz_music_set_host_pinning
     int zero_copy = 1;                                   // small calls on page-locked memory: no copies (BAZ_MUSIC_ZERO_COPY=0: lab)
-    // zero-copy calls with the spectrum port wired, in both directions of the link at once (process_zero_copy_duplex)
-    int duplex = 1;                                      // BAZ_MUSIC_DUPLEX=0: one launch sequence per call (A/B, tests)
-    uint32_t duplex_min_items = 192;                     // sub-batches are at least this long (BAZ_MUSIC_DUPLEX_MIN)
-    hipStream_t stream2 = nullptr;                       // the odd sub-batches' stream
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cov[2] = {nullptr, nullptr};
-    hipEvent_t cov_wait_ev = nullptr, cov_done_ev = nullptr;   // process_device_locked: wait before / record after covariance + EVD
-    struct Workspace {                                   // what one launch sequence owns (ensure_workspace, reserve_candidates)
-        double2* dR = nullptr; double* dQ = nullptr; double* dG = nullptr; uint8_t* dRedo = nullptr; double* dSs = nullptr;
-        uint32_t cap = 0; double* dCand = nullptr; size_t cand_cap = 0;
-    } ws2;                                               // the odd sub-batches' workspace (swapped in while they are queued)
     int single_limit_mib = 64;                           // page-locked calls below this much traffic run as ONE chunk (BAZ_MUSIC_SINGLE_MIB)
     StageProf prof[BAZ_MUSIC_NUM_STAGES];
     std::string stage_name[BAZ_MUSIC_NUM_STAGES];
@@ -1223,7 +1213,6 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
     r = reserve_candidates(c, batch);
     if (r) return r;
     const uint32_t qstride = baz_music_q_stride(batch);
-    if (c->cov_wait_ev) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->cov_wait_ev, 0));
     if (c->fused_covevd) {
         r = launch_covevd(c, static_cast<const float*>(d_in), batch, c->dQ, qstride, c->dG);
         if (r) return r;
@@ -1233,7 +1222,6 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
         r = launch_evd(c, c->dR, batch, c->dQ, qstride, c->dG);
         if (r) return r;
     }
-    if (c->cov_done_ev) HIP_TRY(c, hipEventRecord(c->cov_done_ev, c->stream));
     float* spec = static_cast<float*>(d_spec);
     if (c->peak_mode && !spec) {   // the peak picker reads the spectrum: keep a private one when port 2 is not wired
         const size_t need = (size_t)batch * c->res;
@@ -1253,65 +1241,6 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
     c->stat_next_clean = true;     // the merge cleared the next call's statistic counter
     if (c->peak_mode) return launch_peaks(c, batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), spec);
     return BAZ_MUSIC_OK;
-}
-
-void workspace_swap(baz_music_ctx* c)
-{
-    std::swap(c->dR, c->ws2.dR); std::swap(c->dQ, c->ws2.dQ); std::swap(c->dG, c->ws2.dG);
-    std::swap(c->dRedo, c->ws2.dRedo); std::swap(c->dSs, c->ws2.dSs); std::swap(c->cap, c->ws2.cap);
-    std::swap(c->dCand, c->ws2.dCand); std::swap(c->cand_cap, c->ws2.cand_cap);
-}
-
-// A zero-copy call with the spectrum port wired moves its input over the link in one direction (the covariance kernel
-// reads the caller's items) and ~1.8x as much in the other (the scan stores the caller's spectrum), one after the other:
-// a 1,024-item config-2 call spends 0.2 ms reading and 0.26 ms writing on a link that could do both at once.  Here the
-// call is cut into up to four sub-batches, even ones on the context's stream, odd ones on a second stream with a second
-// workspace; sub-batch i+1's covariance waits for sub-batch i's (the reads stay one stream of requests), so that it
-// runs beside sub-batch i's scan: reads and stores overlap, the stores stay back to back.  Same kernels on the same
-// items: bit-identical outputs.  Returns BAZ_MUSIC_OK with *ran = false when the call is too small to cut.
-int process_zero_copy_duplex(baz_music_ctx* c, const float* z_in, uint32_t batch, float* z_ang, float* z_lvl, float* z_spec, bool* ran)
-{
-    *ran = false;
-    const uint32_t nsub = std::min<uint32_t>(4u, batch / std::max<uint32_t>(16u, c->duplex_min_items));
-    if (!c->duplex || c->wide || c->peak_mode || !z_spec || nsub < 2) return BAZ_MUSIC_OK;
-    if (!c->stream2) HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    for (hipEvent_t* e : {&c->ev_fork, &c->ev_join, &c->ev_cov[0], &c->ev_cov[1]})
-        if (!*e) HIP_TRY(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
-    const uint32_t per = ((batch + nsub - 1) / nsub + 15u) & ~15u;        // items per sub-batch (a multiple of 16 rows)
-    // both workspaces sized before anything is queued (a re-allocation would synchronise in the middle)
-    int r = ensure_workspace(c, per);
-    if (!r) r = reserve_candidates(c, per);
-    workspace_swap(c);
-    if (!r) r = ensure_workspace(c, per);
-    if (!r) r = reserve_candidates(c, per);
-    workspace_swap(c);
-    if (r) return r;
-    r = begin_statistic(c);
-    if (r) return r;
-    *ran = true;
-    hipStream_t s0 = c->stream;
-    HIP_TRY(c, hipEventRecord(c->ev_fork, s0));                             // whatever the context's stream still holds comes first
-    HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    uint32_t k = 0;
-    for (uint32_t done = 0; done < batch && r == BAZ_MUSIC_OK; done += per, ++k) {
-        const uint32_t nb = std::min(per, batch - done);
-        const bool odd = (k & 1u) != 0;
-        if (odd) { workspace_swap(c); c->stream = c->stream2; }
-        c->cov_wait_ev = k ? c->ev_cov[(k - 1) & 1u] : nullptr;
-        c->cov_done_ev = c->ev_cov[k & 1u];
-        r = process_device_locked(c, z_in + (size_t)done * c->nsamples * 2, nb, z_ang + (size_t)done * c->n,
-                                  z_lvl + (size_t)done * c->n, z_spec + (size_t)done * c->res);
-        c->cov_wait_ev = c->cov_done_ev = nullptr;
-        if (odd) { workspace_swap(c); c->stream = s0; }
-    }
-    // join: the context's stream ends after both (the caller synchronises it); also after a failed launch
-    const hipError_t ej = hipEventRecord(c->ev_join, c->stream2);
-    const hipError_t ew = (ej == hipSuccess) ? hipStreamWaitEvent(s0, c->ev_join, 0) : ej;
-    if (ew != hipSuccess) {
-        (void)hipStreamSynchronize(c->stream2);
-        if (r == BAZ_MUSIC_OK) r = hip_fail(c, ew, "duplex join");
-    }
-    return r;
 }
 
 }  // namespace
@@ -1348,8 +1277,6 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     if (const char* v = getenv("BAZ_MUSIC_CHUNK_MIB")) c->chunk_bytes = (size_t)std::max(1, std::min(1024, atoi(v))) << 20;
     if (const char* v = getenv("BAZ_MUSIC_PIN_LIMIT_MIB")) c->pin_limit = (uint64_t)std::max(0, atoi(v)) << 20;
     if (const char* v = getenv("BAZ_MUSIC_ZERO_COPY")) c->zero_copy = atoi(v) != 0;
-    if (const char* v = getenv("BAZ_MUSIC_DUPLEX")) c->duplex = atoi(v) != 0;                        // A/B, tests
-    if (const char* v = getenv("BAZ_MUSIC_DUPLEX_MIN")) c->duplex_min_items = (uint32_t)std::max(16, atoi(v));
     if (const char* v = getenv("BAZ_MUSIC_SINGLE_MIB")) c->single_limit_mib = std::max(1, std::min(1024, atoi(v)));
     DeviceGuard guard(dev);
     int r = BAZ_MUSIC_OK;
@@ -1486,11 +1413,6 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         for (auto& p : c->prof)
             for (auto e : p.ev) (void)hipEventDestroy(e);
-        if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
-        for (hipEvent_t e : {c->ev_fork, c->ev_join, c->ev_cov[0], c->ev_cov[1]})
-            if (e) (void)hipEventDestroy(e);
-        for (void* q : {(void*)c->ws2.dR, (void*)c->ws2.dQ, (void*)c->ws2.dG, (void*)c->ws2.dRedo, (void*)c->ws2.dSs, (void*)c->ws2.dCand})
-            if (q) (void)hipFree(q);
         if (c->dFB) (void)hipFree(c->dFB);
         if (c->dCand) (void)hipFree(c->dCand);
         if (c->dR) (void)hipFree(c->dR);
@@ -1664,15 +1586,9 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
             (void)hipGetLastError();           // not addressable from the device after all: the copy path below
         } else {
             float* z_ang = static_cast<float*>(z_al);
-            bool cut = false;
-            int zr = process_zero_copy_duplex(c, static_cast<const float*>(z_in), batch, z_ang, z_ang + (size_t)batch * c->n,
-                                              want_spec ? static_cast<float*>(z_spec) : nullptr, &cut);
-            if (!cut && zr == BAZ_MUSIC_OK) {
-                zr = begin_statistic(c);
-                if (zr == BAZ_MUSIC_OK)
-                    zr = process_device_locked(c, z_in, batch, z_ang, z_ang + (size_t)batch * c->n, want_spec ? z_spec : nullptr);
-            }
-            if (cut && c->stream2) (void)hipStreamSynchronize(c->stream2);   // (also after a failed launch)
+            int zr = begin_statistic(c);
+            if (zr == BAZ_MUSIC_OK)
+                zr = process_device_locked(c, z_in, batch, z_ang, z_ang + (size_t)batch * c->n, want_spec ? z_spec : nullptr);
             const hipError_t es = hipStreamSynchronize(c->stream);   // also after a failed launch
             if (zr == BAZ_MUSIC_OK && es != hipSuccess) zr = hip_fail(c, es, "hipStreamSynchronize");
             if (zr != BAZ_MUSIC_OK) return zr;

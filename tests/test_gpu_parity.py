@@ -810,41 +810,6 @@ def test_partly_page_locked_ranges_take_the_copy_path(gpu_device):
         A.host_unregister_all()
 
 
-@pytest.mark.parametrize("nitems", [1024, 777, 401, 384])
-def test_zero_copy_calls_cut_for_both_link_directions(nitems, gpu_device, monkeypatch):
-    """Page-locked calls with the spectrum port wired run as up to four sub-batches on two streams (the covariance of one
-    reads the caller's items while the scan of the previous one stores the caller's spectrum: process_zero_copy_duplex).
-    Same kernels on the same items: outputs bit-identical to the one-sequence call (BAZ_MUSIC_DUPLEX=0), ragged item counts
-    and the statistic of the literal form included; a table swap between calls is ordered before both streams."""
-    c = mo.make_config("cfg2", 128, seed=37, snr_db=70.0)
-    items = np.ascontiguousarray(np.tile(c["items"], ((nitems + 127) // 128, 1))[:nitems])
-    table2 = np.ascontiguousarray(np.roll(c["table"], 5, axis=0))
-    res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("BAZ_MUSIC_DUPLEX", mode)
-        with _capi().Context(c["m"], c["n"], c["nsamples"], c["res"], c["table"]) as ctx:
-            out = (np.zeros((nitems, c["n"]), np.float32), np.zeros((nitems, c["n"]), np.float32),
-                   np.zeros((nitems, c["res"]), np.float32))
-            assert ctx.host_register(items) == 0 and ctx.host_register(out[2]) == 0
-            ctx.process(items, out=out)
-            first = [x.copy() for x in out] + [ctx.refined_values()]
-            ctx.set_table(table2)
-            ctx.process(items, out=out)
-            second = [x.copy() for x in out] + [ctx.refined_values()]
-            ctx.host_unregister_all()
-            res[mode] = (first, second)
-    for k in (0, 1):
-        a0, l0, s0, r0 = res["0"][k]
-        a1, l1, s1, r1 = res["1"][k]
-        assert np.array_equal(s1.view(np.uint32), s0.view(np.uint32))
-        assert np.array_equal(a1, a0) and np.array_equal(l1.view(np.uint32), l0.view(np.uint32))
-        assert r1 == r0
-    assert res["1"][0][3] > 0                                   # 70 dB: some values took the literal form
-    assert not np.array_equal(res["1"][0][2], res["1"][1][2])   # the second call saw the new table
-    ao, lo, so, st = mo.music_doa_work_batch(c["items"], c["table"], c["m"], c["n"])
-    assert_spectrum_close(res["1"][0][2][:128], so)
-
-
 def test_registrations_are_shared_between_contexts(gpu_device):
     """two blocks reading ONE stream buffer share its registration, and it survives until the last of
     them lets go -- the first block's stop() must not unmap memory the second one still addresses over PCIe."""
