@@ -19,12 +19,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
     ctx.profile(1)
     for _ in range(10): step()
     ctx.sync(); st = [ctx.stage_ms(s)[0] / max(ctx.stage_ms(s)[1], 1) for s in range(4)]
-    print("variant %s: cov+evd %.3f scan %.3f merge %.3f ms" % (os.environ.get("BAZ_MUSIC_SCAN_VARIANT", "0"), st[0] + st[1], st[2], st[3]), flush=True)
+    fp = [int(t.view(torch.int32).to(torch.int64).sum()) & (2**64 - 1) for t in (spec, ang, lvl)]
+    print("variant %s: cov+evd %.3f scan %.3f merge %.3f ms | fingerprint of spectrum / ang / lvl bits %x %x %x"
+          % (os.environ.get("BAZ_MUSIC_SCAN_VARIANT", "0"), st[0] + st[1], st[2], st[3], fp[0], fp[1], fp[2]), flush=True)
     ctx.close()
 else:
     names = {"1": "shipped (staged)", "2": "ungated top-n network", "6": "everything but the spectrum stores", "7": "stores + staging + barriers only",
              "8": "MFMA + float conversions only (no top-n, no stores)"}
-    for v in ("1", "6", "8", "7", "2", "1"):
+    for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("1", "6", "8", "7", "2", "1")):
         env = dict(os.environ, BAZ_MUSIC_SCAN_VARIANT=v, BAZ_MUSIC_RES_SCAN="0")
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "one"], env=env, capture_output=True, text=True)
         print(names[v].ljust(52), (r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1], flush=True)
