@@ -511,7 +511,7 @@ struct ScanGeom {
     uint32_t groups, nsplit, blocks, rows_per_class;
 };
 
-ScanGeom scan_geometry(uint32_t batch, uint32_t nsteps, uint32_t nclass, int force_nsplit)
+ScanGeom scan_geometry(uint32_t batch, uint32_t nsteps, uint32_t nclass, int force_nsplit, uint32_t m)
 {
     ScanGeom G;
     G.rows_per_class = round_up((batch + nclass - 1) / nclass, 64);
@@ -521,7 +521,11 @@ ScanGeom scan_geometry(uint32_t batch, uint32_t nsteps, uint32_t nclass, int for
     // and no more -- every extra range restarts the top-n lists (the gate fires until they fill), writes another
     // candidate list per item and multiplies the row streams written at once: 262,144 cfg2 items ran the scan in 0.716 /
     // 0.758 / 0.826 ms at 1 / 2 / 4 ranges (round 1 asked for 8 waves/SIMD worth = 32,768 tasks, i.e. 2 ranges there).
-    const uint32_t want_tasks = 256u * 4u * 4u * 2u;
+    // From 9 antennas on the kernel holds 2 waves per SIMD (256 registers) and a task costs more to set up (the short form's
+    // 32 coefficient registers): ONE round of the 2,048 wave slots is best there -- 16 antennas, 3,600 bins: 16,384 items ran
+    // the scan in 0.358 / 0.278 / 0.294 / 0.321 ms at 1 / 2 / 4 / 8 ranges, 4,096 items in 0.093 / 0.088 / 0.095 / 0.107 ms at
+    // 4 / 8 / 16 / 32 (profiles/r03_bin_ranges_by_shape.txt; 5..8 antennas do not care between 2 and 8).
+    const uint32_t want_tasks = (m >= 9) ? 256u * 4u * 2u : 256u * 4u * 4u * 2u;
     uint32_t ns = (want_tasks + live_groups - 1) / live_groups;
     G.nsplit = std::max<uint32_t>(1u, std::min<uint32_t>(ns, std::min<uint32_t>(nsteps, 64u)));
     if (force_nsplit > 0) G.nsplit = std::min<uint32_t>((uint32_t)force_nsplit, std::min<uint32_t>(nsteps, 64u));   // tests / lab
@@ -598,7 +602,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             return BAZ_MUSIC_OK;
         }
     }
-    const ScanGeom G = scan_geometry(batch, c->fb_steps, c->nclass, c->force_nsplit);
+    const ScanGeom G = scan_geometry(batch, c->fb_steps, c->nclass, c->force_nsplit, c->m);
     c->last_nsplit = G.nsplit;
     double* cand = c->dCand;
     if ((size_t)batch * G.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;   // reserve_candidates() sized it
@@ -692,7 +696,7 @@ uint32_t topn_list_len(uint32_t n) { return n <= 2 ? 2u : (n <= 4 ? 4u : (n <= 8
 // candidate keys one scan launch over `nb` items produces (mirrors launch_scan_t's geometry)
 size_t cand_entries(const baz_music_ctx* c, uint32_t nb)
 {
-    size_t per_item = scan_geometry(nb, c->fb_steps, c->nclass, c->force_nsplit).nsplit;
+    size_t per_item = scan_geometry(nb, c->fb_steps, c->nclass, c->force_nsplit, c->m).nsplit;
     if (c->m <= 8 && c->dCS) per_item = std::max<size_t>(per_item, coarse_geometry(c, nb).nsplit);
     return (size_t)nb * per_item * topn_list_len(c->n);
 }
