@@ -92,8 +92,8 @@ struct baz_music_ctx {
     double* dA2 = nullptr;         // ||a||^2 per bin
     int wide_literal_only = 0;     // lab (BAZ_MUSIC_WIDE_LITERAL=1): no short form in scan_wide_kernel
     uint32_t wide_cov_blocks = 512;
-    int wide_cov_mfma = 0;         // 17 <= m <= 32: cov_wide_mfma_kernel (BAZ_MUSIC_WIDE_COV_MFMA=0: lab)
-    int wide_mfma = 0;             // 17 <= m <= 32, n <= 2: the scan on the fp64 matrix core (scan_wide_mfma_kernel; BAZ_MUSIC_WIDE_MFMA=0: lab)
+    int wide_cov_mfma = 0;         // 17 <= m <= 32: cov_wide_mfma_kernel, 33 <= m <= 64: cov_wide_pairs_kernel (BAZ_MUSIC_WIDE_COV_MFMA=0: lab)
+    int wide_mfma = 0;             // 17 <= m <= 64, n <= 2: the scan on the fp64 matrix core (scan_wide_mfma_kernel; BAZ_MUSIC_WIDE_MFMA=0: lab)
     uint32_t wide_cap = 0;         // items the three buffers above (and dR) hold
     double* dSs = nullptr;         // short_form_applies(): coefficient vectors of the scan's short form, [2n * 2m][q_stride]
     double* dA2p = nullptr;        // ... and ||a||^2 per bin, padded like dFB (fb_steps + 2 steps of 64)
@@ -804,6 +804,15 @@ int ensure_wide_workspace(baz_music_ctx* c, uint32_t items)
 int launch_cov_wide(baz_music_ctx* c, const float* d_in, uint32_t nb, double2* dR)
 {
     ProfScope ps(c, BAZ_MUSIC_STAGE_COV);
+    if (c->wide_cov_mfma && c->m > 32) {   // 33 <= m <= 64: one wave per (item, pair of 16-antenna blocks)
+        const uint32_t nblk = (c->m + 15u) / 16u, npairs = nblk * (nblk + 1u) / 2u;
+        const uint64_t tasks = (uint64_t)nb * npairs;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((tasks + 3) / 4, 8u * (uint64_t)c->wide_cov_blocks);
+        hipLaunchKernelGGL(bazwide::cov_wide_pairs_kernel, dim3(blocks), dim3(256), 0, c->stream,
+                           reinterpret_cast<const float2*>(d_in), dR, nb, c->m, c->K, npairs);
+        HIP_TRY(c, hipGetLastError());
+        return BAZ_MUSIC_OK;
+    }
     if (c->wide_cov_mfma) {         // 17 <= m <= 32: one wave per item on the fp64 matrix core, 2 workgroups per CU at most
         const uint32_t blocks = std::min<uint32_t>((nb + 3) / 4, c->wide_cov_blocks);
         hipLaunchKernelGGL(bazwide::cov_wide_mfma_kernel, dim3(blocks), dim3(256), 0, c->stream,
@@ -848,7 +857,7 @@ int process_wide_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void
             HIP_TRY(c, hipGetLastError());
         }
         if (c->wide_mfma && !c->wide_literal_only) {
-            // 17 <= m <= 32, n <= 2: the short form on the fp64 matrix core, candidates per bin range, bazmusic's merge
+            // 17 <= m <= 64, n <= 2: the short form on the fp64 matrix core, candidates per bin range, bazmusic's merge
             const uint32_t groups = (nb + 15) / 16;                                     // workgroups of 4 waves x 4 items
             const uint32_t nsplit = std::max(1u, std::min((1024u + groups - 1) / groups, std::min(c->fb_steps, 16u)));
             r = ensure_candidates(c, (size_t)nb * nsplit * 2);
@@ -859,9 +868,15 @@ int process_wide_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void
                 const bool vec4 = sp && (c->res % 4u) == 0 && (reinterpret_cast<uintptr_t>(sp) % 16u) == 0;
 #define BAZ_WIDE_ARGS dim3(groups * nsplit), dim3(256), 0, c->stream, c->dSw, c->dGw, c->dTB + c->tb_step_elems, c->dA2p + 64, c->dTA, sp, \
                       c->dCand, nb, c->m, c->n, c->res, nsplit, c->keep_mask, c->refine_below, c->dRefined + c->stat_parity
-                if (sp && vec4) hipLaunchKernelGGL((bazwide::scan_wide_mfma_kernel<true, true>), BAZ_WIDE_ARGS);
-                else if (sp) hipLaunchKernelGGL((bazwide::scan_wide_mfma_kernel<true, false>), BAZ_WIDE_ARGS);
-                else hipLaunchKernelGGL((bazwide::scan_wide_mfma_kernel<false, false>), BAZ_WIDE_ARGS);
+                if (c->m <= 32) {
+                    if (sp && vec4) hipLaunchKernelGGL((bazwide::scan_wide_mfma_kernel<true, true>), BAZ_WIDE_ARGS);
+                    else if (sp) hipLaunchKernelGGL((bazwide::scan_wide_mfma_kernel<true, false>), BAZ_WIDE_ARGS);
+                    else hipLaunchKernelGGL((bazwide::scan_wide_mfma_kernel<false, false>), BAZ_WIDE_ARGS);
+                } else {              // 33 .. 64 antennas: four staged phases per step, 32 coefficient registers
+                    if (sp && vec4) hipLaunchKernelGGL((bazwide::scan_wide_mfma_kernel<true, true, 4>), BAZ_WIDE_ARGS);
+                    else if (sp) hipLaunchKernelGGL((bazwide::scan_wide_mfma_kernel<true, false, 4>), BAZ_WIDE_ARGS);
+                    else hipLaunchKernelGGL((bazwide::scan_wide_mfma_kernel<false, false, 4>), BAZ_WIDE_ARGS);
+                }
 #undef BAZ_WIDE_ARGS
                 HIP_TRY(c, hipGetLastError());
             }
@@ -1313,10 +1328,10 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
             if (const char* v = getenv("BAZ_MUSIC_WIDE_LITERAL")) c->wide_literal_only = atoi(v);   // lab / tests
             if (hipMalloc((void**)&c->dRefined, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMemset(c->dRefined, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
-            c->wide_cov_mfma = (m <= 32) ? 1 : 0;
+            c->wide_cov_mfma = 1;
             c->wide_cov_blocks = 2u * (uint32_t)std::max(1, prop.multiProcessorCount);
             if (const char* v = getenv("BAZ_MUSIC_WIDE_COV_MFMA")) c->wide_cov_mfma = (c->wide_cov_mfma && atoi(v)) ? 1 : 0;   // lab / tests
-            c->wide_mfma = (m <= 32 && n <= 2) ? 1 : 0;
+            c->wide_mfma = (n <= 2) ? 1 : 0;
             if (const char* v = getenv("BAZ_MUSIC_WIDE_MFMA")) c->wide_mfma = (c->wide_mfma && atoi(v)) ? 1 : 0;   // lab / tests
             if (c->wide_mfma) {
                 c->fb_steps = (resolution + 63) / 64;
@@ -1387,7 +1402,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         return r;
     }
     if (wide) {
-        c->stage_name[BAZ_MUSIC_STAGE_COV] = c->wide_cov_mfma ? "bazwide::cov_wide_mfma_kernel" : "bazwide::cov_wide_kernel";
+        c->stage_name[BAZ_MUSIC_STAGE_COV] = !c->wide_cov_mfma ? "bazwide::cov_wide_kernel" : (m > 32 ? "bazwide::cov_wide_pairs_kernel" : "bazwide::cov_wide_mfma_kernel");
         c->stage_name[BAZ_MUSIC_STAGE_EVD] = "bazwide::evd_wide_kernel";
         c->stage_name[BAZ_MUSIC_STAGE_SCAN] = c->wide_mfma ? "bazwide::scan_wide_mfma_kernel" : "bazwide::scan_wide_kernel";
         c->stage_name[BAZ_MUSIC_STAGE_MERGE] = c->wide_mfma ? "bazmusic::topn_merge_kernel<2>" : "bazwide::topn_wide_kernel";

@@ -183,6 +183,76 @@ __global__ __launch_bounds__(256, 2) void cov_wide_mfma_kernel(const float2* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 1c. The covariance on the fp64 matrix core for 33 <= m <= 64 (round 3).  The antennas form NB = ceil(m / 16) blocks of 16;
+//     a wave task = (item, block pair (A, B), A >= B): the 16 x 16 block R[16 A .. +16][16 B .. +16] from four real Grams,
+//         R[a][b] K = (Re_A Re_B^T + Im_A Im_B^T) + i (Im_A Re_B^T - Re_A Im_B^T)
+//     -- four v_mfma_f64_16x16x4 per k-step of 4 time columns from two 8-B loads per lane (antenna 16 A + i and 16 B + i of
+//     column 4 t + kk), the four terms of an entry in the same lane and register of four accumulators.  A diagonal pair
+//     (A = B) spends the fourth product on what is the transpose of the third; its lower triangle is stored and mirrored as
+//     the bitwise conjugate, like cov_wide_mfma_kernel, and an off-diagonal pair writes its block and the conjugate transpose.
+//     An item is read NB + 1 times (10 pairs touch 20 blocks of 4 at m = 64), out of L2 after the first.  Rows of antennas
+//     >= m re-read antenna m - 1 and are not stored.  fp32 x fp32 products are exact in fp64, the sums are fp64 (.cc:77-85).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cov_wide_pairs_kernel(const float2* __restrict__ in, double2* __restrict__ R,
+                                                             uint32_t batch, uint32_t m, uint32_t K, uint32_t npairs)
+{
+    using bazmusic::v4f64;
+    constexpr int CH = 8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, kk = lane >> 4;
+    const uint32_t mm = m * m;
+    const uint32_t steps = (K + 3) >> 2;
+    const uint32_t full = K >> 2;                      // k-steps whose four columns all exist
+    const double dK = (double)K;
+    const uint32_t ntasks = batch * npairs;
+    for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+        const uint32_t item = task / npairs, pr = task - item * npairs;
+        uint32_t A = 0;                                 // pair index -> (A, B), A >= B: pr = A (A + 1) / 2 + B   (wave-uniform)
+        while ((A + 1) * (A + 2) / 2 <= pr) ++A;
+        const uint32_t B = pr - A * (A + 1) / 2;
+        const uint32_t aA = (16u * A + (uint32_t)i < m) ? 16u * A + (uint32_t)i : m - 1;
+        const uint32_t aB = (16u * B + (uint32_t)i < m) ? 16u * B + (uint32_t)i : m - 1;
+        const float2* __restrict__ src = in + (size_t)item * K * m + (size_t)kk * m;
+        const size_t step_elems = (size_t)4 * m;
+        v4f64 err = {0, 0, 0, 0}, eii = err, eir = err, eri = err;
+        auto kstep = [&](const float2 pa, const float2 pb) {
+            const double ra = (double)pa.x, ia = (double)pa.y, rb = (double)pb.x, ib = (double)pb.y;   // exact (.cc:77)
+            err = __builtin_amdgcn_mfma_f64_16x16x4f64(ra, rb, err, 0, 0, 0);
+            eii = __builtin_amdgcn_mfma_f64_16x16x4f64(ia, ib, eii, 0, 0, 0);
+            eir = __builtin_amdgcn_mfma_f64_16x16x4f64(ia, rb, eir, 0, 0, 0);
+            eri = __builtin_amdgcn_mfma_f64_16x16x4f64(ra, ib, eri, 0, 0, 0);
+        };
+        uint32_t t = 0;
+        for (; t + CH <= full; t += CH) {
+            float2 pa[CH], pb[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                pa[u] = src[(size_t)(t + u) * step_elems + aA];
+                pb[u] = src[(size_t)(t + u) * step_elems + aB];
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) kstep(pa[u], pb[u]);
+        }
+        for (; t < steps; ++t) {                        // the last k-steps one by one; columns >= K are zero
+            const bool ok = 4 * t + (uint32_t)kk < K;
+            const float2 z = make_float2(0.0f, 0.0f);
+            kstep(ok ? src[(size_t)t * step_elems + aA] : z, ok ? src[(size_t)t * step_elems + aB] : z);
+        }
+        double2* __restrict__ Ri = R + (size_t)item * mm;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                   // D layout: row = kk + 4 r (block A), col = i (block B)
+            const uint32_t a = 16u * A + (uint32_t)(kk + 4 * r), b = 16u * B + (uint32_t)i;
+            if (a < m && b < m && (A != B || a >= b)) {
+                const double re = (err[r] + eii[r]) / dK, im = (eir[r] - eri[r]) / dK;               // .cc:85
+                Ri[(size_t)a * m + b] = make_double2(re, im);
+                if (a != b) Ri[(size_t)b * m + a] = make_double2(re, -im);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // 2. EVD.  One workgroup per item; A and V (complex128, row stride m + 1) in LDS.  A sweep = ME - 1 rounds of the circle
 //    method (ME = m rounded up to even): the pairs of a round are disjoint, so all their rotations are computed at once
 //    (one thread per pair), applied to the columns of A and V (A J, V J), then to the rows of A (J^H (A J)).
@@ -622,7 +692,7 @@ __global__ __launch_bounds__(WB) void scan_wide_kernel(const double2* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// 3b. The scan on the fp64 matrix core for 17 <= m <= 32, n <= 2 (round 3; scan_wide_kernel above stays for everything
+// 3b. The scan on the fp64 matrix core for 17 <= m <= 64, n <= 2 (round 3; scan_wide_kernel above stays for everything
 //     else).  Short form  d = ||a||^2 - sum_c |s_c^H a|^2  (music_kernels.hip.h, SIG): per (item, bin) 2n real inner products
 //     of length 2m -- Re and Im of s_c^H a against the table's real coordinates (re a_0, im a_0, re a_1, ...) -- as a
 //     GEMM [4 items x 4 outputs] x [2m] . [2m x 64 bins] on v_mfma_f64_16x16x4: tile row = item + 4 output, so that the
@@ -630,12 +700,14 @@ __global__ __launch_bounds__(WB) void scan_wide_kernel(const double2* __restrict
 //     4 reg) and d is formed in place.  B = the raw-table image TB (bazmusic's build_TB: columns permuted so that a lane
 //     holds 4 consecutive bins of a 64-bin step -> one 16-B spectrum store, 256 B contiguous per item row); the 4 waves
 //     of a workgroup take 4 x 4 items and share every slice of TB through a double-buffered LDS stage (phases of <= 8
-//     k-steps, KS = ceil(2m / 4) <= 16).  Where the difference is at or below `below` (near a null: it loses ~m eps ||a||^2
+//     k-steps, KS = ceil(2m / 4) <= 32).  Where the difference is at or below `below` (near a null: it loses ~m eps ||a||^2
 //     absolutely) the reference's literal form sum_k |g_k^H a|^2 (.cc:110-119) runs for that value on the vector unit, from
 //     G as sub_wide / evd_wide wrote it.  Top-n: bazmusic's packed keys; candidates per bin range -> topn_merge_kernel.
 //     With one emitter two of the four outputs are zero rows (half the matrix work is idle; n = 1 is rare at these widths).
 // ---------------------------------------------------------------------------------------------------------------
-template <bool SPEC, bool VEC4>
+//     PMAX = staged phases per 64-bin step the instantiation can hold: 2 covers m <= 32 (KS <= 16, 16 coefficient registers), 4
+//     covers 33 <= m <= 64 (KS <= 32: 32 coefficient registers; the same code, two more phases per step).
+template <bool SPEC, bool VEC4, int PMAX = 2>
 __global__ __launch_bounds__(256) void scan_wide_mfma_kernel(const double2* __restrict__ Ssig, const double2* __restrict__ G,
                                                              const double2* __restrict__ TB, const double* __restrict__ A2p,
                                                              const float2* __restrict__ TA, float* __restrict__ spec,
@@ -649,8 +721,8 @@ __global__ __launch_bounds__(256) void scan_wide_mfma_kernel(const double2* __re
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, g = lane >> 4;
-    const uint32_t KS = (2 * m + 3) >> 2;          // 9 .. 16
-    const uint32_t pps = (KS + SCH - 1) / SCH;     // phases per step (2)
+    const uint32_t KS = (2 * m + 3) >> 2;          // 9 .. 16 (PMAX = 2), 17 .. 32 (PMAX = 4)
+    const uint32_t pps = (KS + SCH - 1) / SCH;     // phases per step (2 .. PMAX)
     const uint32_t split = blockIdx.x % nsplit;
     const uint32_t item0 = ((blockIdx.x / nsplit) * 4 + wave) * 4;          // this wave's 4 items
     const uint32_t nsteps = (res + 63u) >> 6;
@@ -659,13 +731,13 @@ __global__ __launch_bounds__(256) void scan_wide_mfma_kernel(const double2* __re
 
     // A operand: tile row c = (item c & 3, output c >> 2); output o = 2 cI + part: Re (part 0) / Im (part 1) of s_cI^H a,
     // as coefficients of the real coordinate e = 4 s + g = (antenna e >> 1, re / im)
-    double sa[16];
+    double sa[SCH * PMAX];
     {
         const uint32_t it_r = item0 + (uint32_t)(c & 3);
         const uint32_t itr = (it_r < batch) ? it_r : (batch - 1);
         const int o = c >> 2, cI = o >> 1, part = o & 1;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < SCH * PMAX; ++s) {
             const uint32_t e = 4u * (uint32_t)s + (uint32_t)g, j = e >> 1;
             double v = 0.0;
             if ((uint32_t)s < KS && j < m && (uint32_t)cI < n) {
@@ -713,12 +785,15 @@ __global__ __launch_bounds__(256) void scan_wide_mfma_kernel(const double2* __re
         v4f64 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0, 0, 0, 0};
-        for (uint32_t p = 0; p < pps; ++p) {
+#pragma unroll
+        for (int pc = 0; pc < PMAX; ++pc) {                                // (compile-time phase index: sa[] stays in registers)
+            const uint32_t p = (uint32_t)pc;
+            if (p >= pps) break;                                           // wave-uniform
             const bool last_p = p + 1 == pps;
             const bool more = !last_p || (st + 1 < st_end);
             if (more) stage_load(last_p ? st + 1 : st, last_p ? 0u : p + 1);
             const uint32_t nks = phase_chunks(p) >> 1;                     // k-steps of this phase (wave-uniform)
-            if (p == 0) {
+            if (pc == 0) {
 #pragma unroll
                 for (int sl = 0; sl < SCH; ++sl) {
                     const v2f64 f01 = stage[buf][(2 * sl) * 64 + lane], f23 = stage[buf][(2 * sl + 1) * 64 + lane];
@@ -732,10 +807,10 @@ __global__ __launch_bounds__(256) void scan_wide_mfma_kernel(const double2* __re
                 for (int sl = 0; sl < SCH; ++sl) {
                     if ((uint32_t)sl < nks) {
                         const v2f64 f01 = stage[buf][(2 * sl) * 64 + lane], f23 = stage[buf][(2 * sl + 1) * 64 + lane];
-                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[SCH + sl], f01.x, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[SCH + sl], f01.y, acc[1], 0, 0, 0);
-                        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[SCH + sl], f23.x, acc[2], 0, 0, 0);
-                        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[SCH + sl], f23.y, acc[3], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[pc * SCH + sl], f01.x, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[pc * SCH + sl], f01.y, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[pc * SCH + sl], f23.x, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[pc * SCH + sl], f23.y, acc[3], 0, 0, 0);
                     }
                 }
             }

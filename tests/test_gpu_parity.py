@@ -144,6 +144,8 @@ def test_hip_matches_oracle_on_odd_shapes(m, n, N, res, batch, gpu_device):
     (32, 2, 32 * 128, 3600, 6),
     (48, 7, 48 * 96, 500, 3),
     (64, 2, 64 * 64, 720, 3),       # BAZ_MUSIC_MAX_M: 137 KB of LDS per item
+    (37, 2, 37 * 50, 360, 5),       # 33 .. 64 antennas: covariance by pairs of 16-antenna blocks (3 blocks, the last one 5 wide; K % 4 != 0)
+    (49, 3, 49 * 33, 200, 3),       # 4 blocks, the last one a single antenna; K = 32 + 1
 ])
 def test_wide_arrays_match_the_oracle(m, n, N, res, batch, gpu_device):
     """17..64 antennas (music_wide_kernels.hip.h): device path, host path and stage tap against the oracle."""
@@ -162,7 +164,7 @@ def test_wide_arrays_match_the_oracle(m, n, N, res, batch, gpu_device):
         R = torch.zeros(batch, m * m, 2, dtype=torch.float64, device=gpu_device)
         ctx.debug_cov(x.data_ptr(), batch, R.data_ptr())
         ctx.sync()
-        assert ctx.refined_values() >= 0          # (counted by the matrix-core scan only: m <= 32, n <= 2)
+        assert ctx.refined_values() >= 0          # (counted by the matrix-core scan only: n <= 2)
     assert_spectrum_close(spec, so)
     assert_doa_match(ang, lvl, ao, lo, res, st)
     assert np.array_equal(a1, ang)
@@ -237,9 +239,13 @@ def test_wide_arrays_short_form_and_literal_form_agree(m, n, K, res, snr, gpu_de
     (32, 2, 64, 3600, 70, 20.0),      # the headline wide shape; 70 items: a ragged last workgroup and wave
     (29, 2, 50, 1000, 1200, 10.0),    # enough items that the bins of an item are NOT split over workgroups; K = 32 + 18
     (32, 2, 48, 640, 5, 80.0),        # sharp nulls: the literal form runs inside the kernel
+    (33, 1, 20, 360, 9, 20.0),        # 33 .. 64 antennas: four staged phases per step (17 k-steps: the third phase holds one)
+    (48, 2, 24, 724, 40, 20.0),       # 24 k-steps = three full phases
+    (64, 2, 32, 3600, 70, 20.0),      # the widest array the kernels take: 32 k-steps
+    (64, 2, 16, 640, 5, 80.0),        # ... with sharp nulls
 ])
 def test_wide_arrays_matrix_core_scan(m, n, K, res, batch, snr, gpu_device, monkeypatch):
-    """scan_wide_mfma_kernel (17 <= m <= 32, n <= 2) against scan_wide_kernel + topn_wide_kernel (BAZ_MUSIC_WIDE_MFMA=0) and
+    """scan_wide_mfma_kernel (17 <= m <= 64, n <= 2) against scan_wide_kernel + topn_wide_kernel (BAZ_MUSIC_WIDE_MFMA=0) and
     the oracle; an item's bits do not depend on the batch around it (hence not on how its bins were split)"""
     N = m * K
     arr = mo.array_geometry(m)
