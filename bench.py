@@ -544,6 +544,9 @@ def main():
                                                  bound="fp64 matrix (covariance and scan on v_mfma_f64_16x16x4; EVD: signal subspace by orthogonal iteration)",
                                                  workload="32 antennas (run-time-m kernels; the reference has no antenna limit), n=2, "
                                                           "nsamples=4096 (K=128), resolution=3600, spectrum wired, 4,096 items")),
+                    ("wide_m64_n2", lambda: dict(extra_music(torch, np, capi, synth, dev, stream, 64, 4096, 3600, 2048, True, 0.3),
+                                                 bound="fp64 matrix (covariance by pairs of 16-antenna blocks, scan with four staged phases per step) + EVD",
+                                                 workload="64 antennas (BAZ_MUSIC_MAX_M), n=2, nsamples=4096 (K=64), resolution=3600, spectrum wired, 2,048 items")),
                     ("cfg5_chain", lambda: dict(extra_cfg5(torch, np, capi, synth, dev, stream, 16384, 0.5),
                                                 workload="BASELINE configs[4] on one GPU: 16 antennas, fractional_resampler_cc "
                                                          "(ratio 1.25) -> agc_cc -> music_doa (m16 n2 N4096 res3600), one stream"))):
