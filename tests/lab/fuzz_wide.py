@@ -1,5 +1,5 @@
-"""Randomised differential run of the matrix-core kernels for wide arrays (17 <= m <= 32: cov_wide_mfma_kernel; n <= 2:
-scan_wide_mfma_kernel) against the C oracle AND against the vector-unit kernels they replace (BAZ_MUSIC_WIDE_MFMA=0
+"""Randomised differential run of the matrix-core kernels for wide arrays (17 <= m <= 32: cov_wide_mfma_kernel, 33 <= m <= 64:
+cov_wide_pairs_kernel; n <= 2: scan_wide_mfma_kernel) against the C oracle AND against the vector-unit kernels they replace (BAZ_MUSIC_WIDE_MFMA=0
 BAZ_MUSIC_WIDE_COV_MFMA=0).  argv: number of cases [seed].  Prints every failure; exit code 1 if any."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -35,12 +35,12 @@ def run(m, n, N, res, table, items, mfma):
 
 
 for case in range(ncases):
-    m = int(rng.integers(17, 33))
+    m = int(rng.integers(17, 33)) if rng.random() < 0.4 else int(rng.integers(33, 65))
     n = int(rng.choice([1, 2, 2, 2, 3, 4]))
     K = int(rng.choice([m, m + 1, 33, 40, 47, 64, 96, 100, 128, 131]))
     K = max(K, m)
     res = int(rng.choice([1, 3, 5, 63, 64, 65, 90, 127, 128, 129, 360, 361, 1000, 1440, 3600]))
-    batch = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 31, 33, 63, 64, 65, 100]))
+    batch = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 31, 33, 63, 64, 65, 100] if m <= 32 else [1, 2, 3, 5, 15, 16, 17, 33]))
     snr = float(rng.choice([0.0, 10.0, 20.0, 40.0, 70.0]))
     N = m * K
     arr = mo.array_geometry(m) if rng.random() < 0.5 else (rng.random((m, 2)) * 4.0).tolist()
@@ -52,7 +52,7 @@ for case in range(ncases):
         ao, lo, so = mr.work_batch(items, table, m, n)
         a1, l1, s1, a1n, names1 = run(m, n, N, res, table, items, "1")
         a0, l0, s0, a0n, names0 = run(m, n, N, res, table, items, "0")
-        assert names1[0].endswith("cov_wide_mfma_kernel") and names0[0].endswith("cov_wide_kernel"), (names1, names0)
+        assert names1[0].endswith("cov_wide_mfma_kernel" if m <= 32 else "cov_wide_pairs_kernel") and names0[0].endswith("cov_wide_kernel"), (names1, names0)
         assert names1[1].endswith("scan_wide_mfma_kernel") == (n <= 2), names1
         if not (n > nem and snr > 40.0):
             worst = max(worst, assert_spectrum_close(s1, so))
