@@ -692,7 +692,7 @@ __global__ __launch_bounds__(WB) void scan_wide_kernel(const double2* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// 3b. The scan on the fp64 matrix core for 17 <= m <= 64, n <= 2 (round 3; scan_wide_kernel above stays for everything
+// 3b. The scan on the fp64 matrix core for 17 <= m <= 64, n <= 4 (round 3; scan_wide_kernel above stays for everything
 //     else).  Short form  d = ||a||^2 - sum_c |s_c^H a|^2  (music_kernels.hip.h, SIG): per (item, bin) 2n real inner products
 //     of length 2m -- Re and Im of s_c^H a against the table's real coordinates (re a_0, im a_0, re a_1, ...) -- as a
 //     GEMM [4 items x 4 outputs] x [2m] . [2m x 64 bins] on v_mfma_f64_16x16x4: tile row = item + 4 output, so that the
@@ -707,7 +707,11 @@ __global__ __launch_bounds__(WB) void scan_wide_kernel(const double2* __restrict
 // ---------------------------------------------------------------------------------------------------------------
 //     PMAX = staged phases per 64-bin step the instantiation can hold: 2 covers m <= 32 (KS <= 16, 16 coefficient registers), 4
 //     covers 33 <= m <= 64 (KS <= 32: 32 coefficient registers; the same code, two more phases per step).
-template <bool SPEC, bool VEC4, int PMAX = 2>
+//     NOUT = real outputs per item: 4 for n <= 2 (a tile = 4 items x 4 outputs, the four of an (item, bin) in the four accumulator
+//     registers of one lane), 8 for n = 3, 4 (a tile = 2 items x 8 outputs, tile row = item + 2 output: an item's eight outputs
+//     sit in lane groups g and g ^ 2, whose partial sums of squares meet through one cross-lane add; lane groups 2, 3 then only
+//     mirror 0, 1).  The list length follows (2 / 4 keys).
+template <bool SPEC, bool VEC4, int PMAX = 2, int NOUT = 4>
 __global__ __launch_bounds__(256) void scan_wide_mfma_kernel(const double2* __restrict__ Ssig, const double2* __restrict__ G,
                                                              const double2* __restrict__ TB, const double* __restrict__ A2p,
                                                              const float2* __restrict__ TA, float* __restrict__ spec,
@@ -724,18 +728,20 @@ __global__ __launch_bounds__(256) void scan_wide_mfma_kernel(const double2* __re
     const uint32_t KS = (2 * m + 3) >> 2;          // 9 .. 16 (PMAX = 2), 17 .. 32 (PMAX = 4)
     const uint32_t pps = (KS + SCH - 1) / SCH;     // phases per step (2 .. PMAX)
     const uint32_t split = blockIdx.x % nsplit;
-    const uint32_t item0 = ((blockIdx.x / nsplit) * 4 + wave) * 4;          // this wave's 4 items
+    constexpr int IPT = 16 / NOUT;                 // items per tile: 4 or 2
+    constexpr int NK = NOUT / 2;                   // list length: 2 or 4
+    const uint32_t item0 = ((blockIdx.x / nsplit) * 4 + wave) * IPT;        // this wave's items
     const uint32_t nsteps = (res + 63u) >> 6;
     const uint32_t st_begin = (uint32_t)(((uint64_t)nsteps * split) / nsplit);
     const uint32_t st_end = (uint32_t)(((uint64_t)nsteps * (split + 1)) / nsplit);
 
-    // A operand: tile row c = (item c & 3, output c >> 2); output o = 2 cI + part: Re (part 0) / Im (part 1) of s_cI^H a,
+    // A operand: tile row c = (item c % IPT, output c / IPT); output o = 2 cI + part: Re (part 0) / Im (part 1) of s_cI^H a,
     // as coefficients of the real coordinate e = 4 s + g = (antenna e >> 1, re / im)
     double sa[SCH * PMAX];
     {
-        const uint32_t it_r = item0 + (uint32_t)(c & 3);
+        const uint32_t it_r = item0 + (uint32_t)(c & (IPT - 1));
         const uint32_t itr = (it_r < batch) ? it_r : (batch - 1);
-        const int o = c >> 2, cI = o >> 1, part = o & 1;
+        const int o = c / IPT, cI = o >> 1, part = o & 1;
 #pragma unroll
         for (int s = 0; s < SCH * PMAX; ++s) {
             const uint32_t e = 4u * (uint32_t)s + (uint32_t)g, j = e >> 1;
@@ -747,10 +753,12 @@ __global__ __launch_bounds__(256) void scan_wide_mfma_kernel(const double2* __re
             sa[s] = v;
         }
     }
-    const uint32_t it_g = item0 + (uint32_t)g;                              // the item whose d this lane holds
-    const bool row_ok = it_g < batch;
-    const uint32_t itg = row_ok ? it_g : (batch - 1);
-    double key[2] = {key_empty(), key_empty()};
+    const uint32_t it_g = item0 + (uint32_t)(g & (IPT - 1));                // the item whose d this lane holds
+    const bool row_ok = it_g < batch && g < IPT;                            // (NOUT = 8: lane groups 2, 3 mirror 0, 1 and write nothing)
+    const uint32_t itg = (it_g < batch) ? it_g : (batch - 1);
+    double key[NK];
+#pragma unroll
+    for (int i = 0; i < NK; ++i) key[i] = key_empty();
     const uint32_t nobin = ~keep_mask;
     uint32_t refined = 0;
 
@@ -825,7 +833,9 @@ __global__ __launch_bounds__(256) void scan_wide_mfma_kernel(const double2* __re
         bool low = false;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            d[t] = a2v[t] - ((acc[t][0] * acc[t][0] + acc[t][1] * acc[t][1]) + (acc[t][2] * acc[t][2] + acc[t][3] * acc[t][3]));
+            double ssq = (acc[t][0] * acc[t][0] + acc[t][1] * acc[t][1]) + (acc[t][2] * acc[t][2] + acc[t][3] * acc[t][3]);
+            if constexpr (NOUT == 8) ssq += __shfl_xor(ssq, 32, 64);       // the other four outputs of the item (lane group g ^ 2)
+            d[t] = a2v[t] - ssq;
             low |= !(d[t] > below) && (bin + t < res);        // (also a negative or NaN difference, like scan_wide_kernel)
         }
         if (__any(low)) {                      // near a null: the reference's literal form for those values (.cc:110-119)
@@ -854,7 +864,7 @@ __global__ __launch_bounds__(256) void scan_wide_mfma_kernel(const double2* __re
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             sv[t] = strength_f32(fabs(d[t]));
-            key_insert_new<2>(key, make_key(d[t], (bin + t < res) ? bin + t : nobin, keep_mask));
+            key_insert_new<NK>(key, make_key(d[t], (bin + t < res) ? bin + t : nobin, keep_mask));
         }
         if constexpr (SPEC) {
             if (row_ok) {
@@ -873,13 +883,13 @@ __global__ __launch_bounds__(256) void scan_wide_mfma_kernel(const double2* __re
         for (int msk = 1; msk < 64; msk <<= 1) refined += __shfl_xor(refined, msk, 64);
         if (lane == 0 && refined) atomicAdd(count, (unsigned long long)refined);
     }
-    key_merge_xor<2>(key, 1);
-    key_merge_xor<2>(key, 2);
-    key_merge_xor<2>(key, 4);
-    key_merge_xor<2>(key, 8);
+    key_merge_xor<NK>(key, 1);
+    key_merge_xor<NK>(key, 2);
+    key_merge_xor<NK>(key, 4);
+    key_merge_xor<NK>(key, 8);
     if (c == 0 && row_ok) {
-        cand[((size_t)it_g * nsplit + split) * 2 + 0] = key[0];
-        cand[((size_t)it_g * nsplit + split) * 2 + 1] = key[1];
+#pragma unroll
+        for (int i = 0; i < NK; ++i) cand[((size_t)it_g * nsplit + split) * NK + i] = key[i];
     }
 }
 

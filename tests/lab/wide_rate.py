@@ -5,11 +5,12 @@ import numpy as np, torch
 from gr_baz_amd import capi
 from oracle import music_oracle as mo
 dev = torch.device("cuda:0")
-for m, n, K, res, B in ((17, 2, 256, 3600, 4096), (24, 2, 128, 3600, 4096), (32, 1, 128, 3600, 4096), (32, 2, 128, 3600, 4096), (32, 4, 128, 3600, 4096), (32, 2, 128, 3600, 16384), (64, 2, 64, 3600, 2048), (64, 8, 256, 720, 2048)):
+for m, n, K, res, B in ((17, 2, 256, 3600, 4096), (24, 2, 128, 3600, 4096), (32, 1, 128, 3600, 4096), (32, 2, 128, 3600, 4096), (32, 4, 128, 3600, 4096), (32, 2, 128, 3600, 16384), (48, 3, 64, 3600, 2048), (64, 2, 64, 3600, 2048), (64, 4, 64, 3600, 2048), (64, 8, 256, 720, 2048)):
     N = m * K
     arr = mo.array_geometry(m)
     table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
-    items = mo.synth_items(64, m, N, arr, mo.FREQUENCY, mo.SPACING, snr_db=20.0, seed=5)
+    angles = (40.3, 121.7) if n == 2 else tuple(np.linspace(40.3, 300.0, n))          # as many emitters as the block is told to expect
+    items = mo.synth_items(64, m, N, arr, mo.FREQUENCY, mo.SPACING, angles_deg=angles, snr_db=20.0, seed=5)
     x = torch.from_numpy(np.ascontiguousarray(items).view(np.float32)).to(dev).repeat(B // 64, 1)
     ang = torch.zeros(B, n, device=dev); lvl = torch.zeros(B, n, device=dev); spec = torch.zeros(B, res, device=dev)
     with capi.Context(m, n, N, res, table) as ctx:
