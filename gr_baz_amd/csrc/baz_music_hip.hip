@@ -99,7 +99,7 @@ struct baz_music_ctx {
     double* dA2p = nullptr;        // ... and ||a||^2 per bin, padded like dFB (fb_steps + 2 steps of 64)
     int sig_scan = 1;              // lab / tests: BAZ_MUSIC_SIG_SCAN=0 keeps the projector GEMM
     uint8_t* dRedo = nullptr;      // [cap] items evd_sub_kernel hands back to the Jacobi
-    int sub_evd = 1;               // signal subspace by orthogonal iteration where n <= 4 (lab: BAZ_MUSIC_SUB_EVD=0)
+    int sub_evd = 1;               // signal subspace by orthogonal iteration where n <= 4 (run-time-m kernels: n <= 8) (lab: BAZ_MUSIC_SUB_EVD=0)
     int fused_covevd = 0;          // m = 4, K % 256 == 0: covariance + EVD in one kernel (BAZ_MUSIC_FUSE=0: lab, two kernels)
     uint32_t covevd_blocks = 512u; // grid of cov4_evd_kernel: the workgroups resident at once (2 per CU)
     uint32_t cov4_resident_blocks = 256u;        // grid of cov4_x4_kernel (persistent waves): one workgroup per CU
@@ -843,12 +843,16 @@ int process_wide_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void
         {
             ProfScope ps(c, BAZ_MUSIC_STAGE_EVD);
             const uint8_t* only = nullptr;
-            if (c->sub_evd && c->n <= 4) {     // few emitters: signal subspace by orthogonal iteration, Jacobi for what it hands back
+            if (c->sub_evd && c->n <= 8) {     // few emitters: signal subspace by orthogonal iteration, Jacobi for what it hands back
                 const size_t lds = ((size_t)c->m * (c->m + 1) + (size_t)c->n * 64) * sizeof(double2);
                 if (c->n == 1) hipLaunchKernelGGL(bazwide::sub_wide_kernel<1>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
                 else if (c->n == 2) hipLaunchKernelGGL(bazwide::sub_wide_kernel<2>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
                 else if (c->n == 3) hipLaunchKernelGGL(bazwide::sub_wide_kernel<3>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
-                else hipLaunchKernelGGL(bazwide::sub_wide_kernel<4>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
+                else if (c->n == 4) hipLaunchKernelGGL(bazwide::sub_wide_kernel<4>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
+                else if (c->n == 5) hipLaunchKernelGGL(bazwide::sub_wide_kernel<5>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
+                else if (c->n == 6) hipLaunchKernelGGL(bazwide::sub_wide_kernel<6>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
+                else if (c->n == 7) hipLaunchKernelGGL(bazwide::sub_wide_kernel<7>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
+                else hipLaunchKernelGGL(bazwide::sub_wide_kernel<8>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
                 HIP_TRY(c, hipGetLastError());
                 only = c->dRedo;
             }
@@ -1318,16 +1322,20 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
                 // so it is always set for the largest m, never for this context's
                 constexpr uint32_t MX = BAZ_MUSIC_MAX_M;
                 const int evd_lds = (int)wide_evd_lds(MX), scan_lds = (int)((size_t)MX * MX * sizeof(double2));
-                const int sub_lds = (int)(((size_t)MX * (MX + 1) + 4u * 64u) * sizeof(double2));
-                const void* fn[6] = {reinterpret_cast<const void*>(bazwide::evd_wide_kernel),
-                                     reinterpret_cast<const void*>(bazwide::scan_wide_kernel),
-                                     reinterpret_cast<const void*>(bazwide::sub_wide_kernel<1>),
-                                     reinterpret_cast<const void*>(bazwide::sub_wide_kernel<2>),
-                                     reinterpret_cast<const void*>(bazwide::sub_wide_kernel<3>),
-                                     reinterpret_cast<const void*>(bazwide::sub_wide_kernel<4>)};
-                const int sz[6] = {evd_lds, scan_lds, sub_lds, sub_lds, sub_lds, sub_lds};
+                const int sub_lds = (int)(((size_t)MX * (MX + 1) + 8u * 64u) * sizeof(double2));
+                const void* fn[10] = {reinterpret_cast<const void*>(bazwide::evd_wide_kernel),
+                                      reinterpret_cast<const void*>(bazwide::scan_wide_kernel),
+                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<1>),
+                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<2>),
+                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<3>),
+                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<4>),
+                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<5>),
+                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<6>),
+                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<7>),
+                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<8>)};
+                const int sz[10] = {evd_lds, scan_lds, sub_lds, sub_lds, sub_lds, sub_lds, sub_lds, sub_lds, sub_lds, sub_lds};
                 bool ok = true;
-                for (int k = 0; k < 6; ++k)
+                for (int k = 0; k < 10; ++k)
                     ok = ok && hipFuncSetAttribute(fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, sz[k]) == hipSuccess;
                 if (!ok) { r = BAZ_MUSIC_E_HIP; break; }
             }

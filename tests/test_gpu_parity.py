@@ -177,7 +177,8 @@ def test_wide_arrays_match_the_oracle(m, n, N, res, batch, gpu_device):
     assert np.array_equal(Rg, Rg.conj().transpose(0, 2, 1))          # exactly Hermitian
 
 
-@pytest.mark.parametrize("m,n,K,res", [(24, 2, 40, 180), (40, 3, 48, 120), (64, 1, 64, 90), (32, 4, 64, 180)])
+@pytest.mark.parametrize("m,n,K,res", [(24, 2, 40, 180), (40, 3, 48, 120), (64, 1, 64, 90), (32, 4, 64, 180),
+                                       (20, 5, 64, 90), (48, 7, 64, 120), (64, 8, 96, 90)])      # five to eight emitters: the same iteration
 def test_wide_arrays_subspace_iteration_and_hand_back(m, n, K, res, gpu_device, monkeypatch):
     """the wide path's sub_wide_kernel against its Jacobi (BAZ_MUSIC_SUB_EVD=0) on a batch that mixes easy, slow and
     rank-deficient items; bits independent of the batch around an item"""
