@@ -212,7 +212,7 @@ class Context:
     def refined_values(self):
         """(item, bin) VALUES of the last process call that were recomputed in the reference's literal form (near-null
         bins, extreme SNR) -- not items: one item can contribute up to `resolution` of them.  On the wide path counted by the
-        matrix-core scan only (17 <= m <= 64, n <= 4), else 0."""
+        matrix-core scan only (17 <= m <= 64, n <= 8), else 0."""
         return int(lib().baz_music_refined_values(self._h))
 
     refined_items = refined_values      # the round-1 name of the same statistic (kept for callers; the unit is values)

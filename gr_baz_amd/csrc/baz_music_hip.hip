@@ -93,7 +93,7 @@ struct baz_music_ctx {
     int wide_literal_only = 0;     // lab (BAZ_MUSIC_WIDE_LITERAL=1): no short form in scan_wide_kernel
     uint32_t wide_cov_blocks = 512;
     int wide_cov_mfma = 0;         // 17 <= m <= 32: cov_wide_mfma_kernel, 33 <= m <= 64: cov_wide_pairs_kernel (BAZ_MUSIC_WIDE_COV_MFMA=0: lab)
-    int wide_mfma = 0;             // 17 <= m <= 64, n <= 4: the scan on the fp64 matrix core (scan_wide_mfma_kernel; BAZ_MUSIC_WIDE_MFMA=0: lab)
+    int wide_mfma = 0;             // 17 <= m <= 64, n <= 8: the scan on the fp64 matrix core (scan_wide_mfma_kernel; BAZ_MUSIC_WIDE_MFMA=0: lab)
     uint32_t wide_cap = 0;         // items the three buffers above (and dR) hold
     double* dSs = nullptr;         // short_form_applies(): coefficient vectors of the scan's short form, [2n * 2m][q_stride]
     double* dA2p = nullptr;        // ... and ||a||^2 per bin, padded like dFB (fb_steps + 2 steps of 64)
@@ -861,9 +861,9 @@ int process_wide_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void
             HIP_TRY(c, hipGetLastError());
         }
         if (c->wide_mfma && !c->wide_literal_only) {
-            // 17 <= m <= 64, n <= 4: the short form on the fp64 matrix core, candidates per bin range, bazmusic's merge
-            const uint32_t ipw = (c->n <= 2) ? 4u : 2u;                                 // items per wave (tile = ipw items x 16 / ipw outputs)
-            const uint32_t nk = (c->n <= 2) ? 2u : 4u;                                  // list length
+            // 17 <= m <= 64, n <= 8: the short form on the fp64 matrix core, candidates per bin range, bazmusic's merge
+            const uint32_t ipw = (c->n <= 2) ? 4u : (c->n <= 4 ? 2u : 1u);              // items per wave (tile = ipw items x 16 / ipw outputs)
+            const uint32_t nk = 8u / ipw;                                               // list length
             const uint32_t groups = (nb + 4u * ipw - 1) / (4u * ipw);                   // workgroups of 4 waves
             const uint32_t nsplit = std::max(1u, std::min((1024u + groups - 1) / groups, std::min(c->fb_steps, 16u)));
             r = ensure_candidates(c, (size_t)nb * nsplit * nk);
@@ -882,9 +882,11 @@ int process_wide_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void
     } while (0)
                 // PMAX: staged phases per step (2 to 32 antennas, 4 to 64); NOUT: outputs per item (4: n <= 2, 8: n = 3, 4)
                 if (c->m <= 32 && c->n <= 2) BAZ_WIDE_LAUNCH(2, 4);
-                else if (c->m <= 32) BAZ_WIDE_LAUNCH(2, 8);
+                else if (c->m <= 32 && c->n <= 4) BAZ_WIDE_LAUNCH(2, 8);
+                else if (c->m <= 32) BAZ_WIDE_LAUNCH(2, 16);
                 else if (c->n <= 2) BAZ_WIDE_LAUNCH(4, 4);
-                else BAZ_WIDE_LAUNCH(4, 8);
+                else if (c->n <= 4) BAZ_WIDE_LAUNCH(4, 8);
+                else BAZ_WIDE_LAUNCH(4, 16);
 #undef BAZ_WIDE_LAUNCH
 #undef BAZ_WIDE_ARGS
                 HIP_TRY(c, hipGetLastError());
@@ -899,7 +901,8 @@ int process_wide_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void
                        ang + (size_t)off * c->n, lvl ? lvl + (size_t)off * c->n : nullptr, nb, c->res, c->n, nsplit,    \
                        c->keep_mask, next_stat)
                 if (nk == 2) BAZ_WIDE_MERGE(2);
-                else BAZ_WIDE_MERGE(4);
+                else if (nk == 4) BAZ_WIDE_MERGE(4);
+                else BAZ_WIDE_MERGE(8);
 #undef BAZ_WIDE_MERGE
                 HIP_TRY(c, hipGetLastError());
             }
@@ -1348,7 +1351,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
             c->wide_cov_mfma = 1;
             c->wide_cov_blocks = 2u * (uint32_t)std::max(1, prop.multiProcessorCount);
             if (const char* v = getenv("BAZ_MUSIC_WIDE_COV_MFMA")) c->wide_cov_mfma = (c->wide_cov_mfma && atoi(v)) ? 1 : 0;   // lab / tests
-            c->wide_mfma = (n <= 4) ? 1 : 0;
+            c->wide_mfma = (n <= 8) ? 1 : 0;
             if (const char* v = getenv("BAZ_MUSIC_WIDE_MFMA")) c->wide_mfma = (c->wide_mfma && atoi(v)) ? 1 : 0;   // lab / tests
             if (c->wide_mfma) {
                 c->fb_steps = (resolution + 63) / 64;
@@ -1422,7 +1425,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         c->stage_name[BAZ_MUSIC_STAGE_COV] = !c->wide_cov_mfma ? "bazwide::cov_wide_kernel" : (m > 32 ? "bazwide::cov_wide_pairs_kernel" : "bazwide::cov_wide_mfma_kernel");
         c->stage_name[BAZ_MUSIC_STAGE_EVD] = "bazwide::evd_wide_kernel";
         c->stage_name[BAZ_MUSIC_STAGE_SCAN] = c->wide_mfma ? "bazwide::scan_wide_mfma_kernel" : "bazwide::scan_wide_kernel";
-        c->stage_name[BAZ_MUSIC_STAGE_MERGE] = c->wide_mfma ? (n <= 2 ? "bazmusic::topn_merge_kernel<2>" : "bazmusic::topn_merge_kernel<4>") : "bazwide::topn_wide_kernel";
+        c->stage_name[BAZ_MUSIC_STAGE_MERGE] = c->wide_mfma ? (n <= 2 ? "bazmusic::topn_merge_kernel<2>" : (n <= 4 ? "bazmusic::topn_merge_kernel<4>" : "bazmusic::topn_merge_kernel<8>")) : "bazwide::topn_wide_kernel";
         *out = c;
         return BAZ_MUSIC_OK;
     }

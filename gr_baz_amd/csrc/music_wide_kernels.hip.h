@@ -692,7 +692,7 @@ __global__ __launch_bounds__(WB) void scan_wide_kernel(const double2* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// 3b. The scan on the fp64 matrix core for 17 <= m <= 64, n <= 4 (round 3; scan_wide_kernel above stays for everything
+// 3b. The scan on the fp64 matrix core for 17 <= m <= 64, n <= 8 (round 3; scan_wide_kernel above stays for everything
 //     else).  Short form  d = ||a||^2 - sum_c |s_c^H a|^2  (music_kernels.hip.h, SIG): per (item, bin) 2n real inner products
 //     of length 2m -- Re and Im of s_c^H a against the table's real coordinates (re a_0, im a_0, re a_1, ...) -- as a
 //     GEMM [4 items x 4 outputs] x [2m] . [2m x 64 bins] on v_mfma_f64_16x16x4: tile row = item + 4 output, so that the
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(WB) void scan_wide_kernel(const double2* __restrict
 //     NOUT = real outputs per item: 4 for n <= 2 (a tile = 4 items x 4 outputs, the four of an (item, bin) in the four accumulator
 //     registers of one lane), 8 for n = 3, 4 (a tile = 2 items x 8 outputs, tile row = item + 2 output: an item's eight outputs
 //     sit in lane groups g and g ^ 2, whose partial sums of squares meet through one cross-lane add; lane groups 2, 3 then only
-//     mirror 0, 1).  The list length follows (2 / 4 keys).
+//     mirror 0, 1), 16 for n = 5 .. 8 (one item per tile, two cross-lane adds).  The list length follows (2 / 4 / 8 keys).
 template <bool SPEC, bool VEC4, int PMAX = 2, int NOUT = 4>
 __global__ __launch_bounds__(256) void scan_wide_mfma_kernel(const double2* __restrict__ Ssig, const double2* __restrict__ G,
                                                              const double2* __restrict__ TB, const double* __restrict__ A2p,
@@ -728,8 +728,8 @@ __global__ __launch_bounds__(256) void scan_wide_mfma_kernel(const double2* __re
     const uint32_t KS = (2 * m + 3) >> 2;          // 9 .. 16 (PMAX = 2), 17 .. 32 (PMAX = 4)
     const uint32_t pps = (KS + SCH - 1) / SCH;     // phases per step (2 .. PMAX)
     const uint32_t split = blockIdx.x % nsplit;
-    constexpr int IPT = 16 / NOUT;                 // items per tile: 4 or 2
-    constexpr int NK = NOUT / 2;                   // list length: 2 or 4
+    constexpr int IPT = 16 / NOUT;                 // items per tile: 4, 2 or 1
+    constexpr int NK = NOUT / 2;                   // list length: 2, 4 or 8
     const uint32_t item0 = ((blockIdx.x / nsplit) * 4 + wave) * IPT;        // this wave's items
     const uint32_t nsteps = (res + 63u) >> 6;
     const uint32_t st_begin = (uint32_t)(((uint64_t)nsteps * split) / nsplit);
@@ -834,7 +834,8 @@ __global__ __launch_bounds__(256) void scan_wide_mfma_kernel(const double2* __re
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             double ssq = (acc[t][0] * acc[t][0] + acc[t][1] * acc[t][1]) + (acc[t][2] * acc[t][2] + acc[t][3] * acc[t][3]);
-            if constexpr (NOUT == 8) ssq += __shfl_xor(ssq, 32, 64);       // the other four outputs of the item (lane group g ^ 2)
+            if constexpr (NOUT == 16) ssq += __shfl_xor(ssq, 16, 64);      // (one item per tile: its outputs span all four lane groups)
+            if constexpr (NOUT >= 8) ssq += __shfl_xor(ssq, 32, 64);       // the other outputs of the item (lane group g ^ 2)
             d[t] = a2v[t] - ssq;
             low |= !(d[t] > below) && (bin + t < res);        // (also a negative or NaN difference, like scan_wide_kernel)
         }

@@ -170,7 +170,7 @@ BAZ_MUSIC_API int baz_music_set_peak_mode(baz_music_ctx* ctx, int mode);
  * -1 on error.  See DESIGN.md 2 (near-nulls).  (The name is kept from round 1, which redid whole items.) */
 BAZ_MUSIC_API int64_t baz_music_refined_values(baz_music_ctx* ctx);
 /* The same number under its round-1 name (round 1 redid whole ITEMS; since round 2 the unit is one (item, bin) value, so
- * do not compare it with a batch size).  Past BAZ_MUSIC_FAST_M antennas only the matrix-core scan (n <= 4) counts; the
+ * do not compare it with a batch size).  Past BAZ_MUSIC_FAST_M antennas only the matrix-core scan (n <= 8) counts; the
  * general wide scan evaluates the literal form near nulls per bin and keeps no count (0).  Without the spectrum port only values that could still enter
  * the top-n list are evaluated at all, so fewer are counted than with it. */
 BAZ_MUSIC_API int64_t baz_music_refined_items(baz_music_ctx* ctx);

@@ -164,7 +164,7 @@ def test_wide_arrays_match_the_oracle(m, n, N, res, batch, gpu_device):
         R = torch.zeros(batch, m * m, 2, dtype=torch.float64, device=gpu_device)
         ctx.debug_cov(x.data_ptr(), batch, R.data_ptr())
         ctx.sync()
-        assert ctx.refined_values() >= 0          # (counted by the matrix-core scan only: n <= 4)
+        assert ctx.refined_values() >= 0          # (counted by the matrix-core scan only: n <= 8)
     assert_spectrum_close(spec, so)
     assert_doa_match(ang, lvl, ao, lo, res, st)
     assert np.array_equal(a1, ang)
@@ -248,9 +248,12 @@ def test_wide_arrays_short_form_and_literal_form_agree(m, n, K, res, snr, gpu_de
     (40, 3, 40, 360, 13, 20.0),       # (six of the eight output rows used; an odd item count: the last wave holds one item)
     (64, 4, 32, 724, 5, 20.0),
     (24, 3, 64, 640, 6, 80.0),        # ... with sharp nulls
+    (48, 7, 64, 500, 6, 20.0),        # five to eight emitters: one item per tile, eight keys per list
+    (64, 8, 96, 724, 5, 20.0),
+    (20, 5, 64, 360, 9, 80.0),        # ... with sharp nulls
 ])
 def test_wide_arrays_matrix_core_scan(m, n, K, res, batch, snr, gpu_device, monkeypatch):
-    """scan_wide_mfma_kernel (17 <= m <= 64, n <= 4) against scan_wide_kernel + topn_wide_kernel (BAZ_MUSIC_WIDE_MFMA=0) and
+    """scan_wide_mfma_kernel (17 <= m <= 64, n <= 8) against scan_wide_kernel + topn_wide_kernel (BAZ_MUSIC_WIDE_MFMA=0) and
     the oracle; an item's bits do not depend on the batch around it (hence not on how its bins were split)"""
     N = m * K
     arr = mo.array_geometry(m)
