@@ -16,7 +16,7 @@ fails = 0
 worst = 0.0
 t0 = time.time()
 for case in range(ncases):
-    m = int(rng.integers(2, 17)) if rng.random() > 0.12 else int(rng.integers(17, 49))     # some wide arrays (run-time-m kernels)
+    m = int(rng.integers(2, 17)) if rng.random() > 0.12 else int(rng.integers(17, 65))     # some wide arrays (run-time-m kernels)
     n = int(rng.integers(1, m))
     K = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 31, 64, 100, 128, 256, 300]))
     res = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 90, 127, 128, 129, 360, 361, 1000, 1440, 3600]))
