@@ -127,7 +127,23 @@ def wide_fixtures():
     fixture("wide_m64_n3_N4096_r256", 64, 3, 4096, 256, mo.array_geometry(64), 1, 20.0, 2105, angles=(40.3, 121.7, 250.0))
 
 
+def wide_fixtures_r3():
+    """round 3: the shapes the matrix-core kernels for 33..64 antennas and 3..8 emitters take (cov_wide_pairs_kernel,
+    scan_wide_mfma_kernel with four staged phases / two or one items per tile, sub_wide_kernel<5..8>)"""
+    fixture("wide_m48_n8_N3072_r724", 48, 8, 48 * 64, 724, mo.array_geometry(48), 2, 20.0, 2106,
+            angles=tuple(np.linspace(11.0, 331.0, 8)))
+    fixture("wide_m40_n4_N2000_r1001", 40, 4, 40 * 50, 1001, mo.array_geometry(40), 2, 25.0, 2107, angles=(31.0, 122.5, 201.0, 299.0))
+    fixture("wide_m64_n6_N4160_r360", 64, 6, 64 * 65, 360, mo.array_geometry(64), 1, 20.0, 2108,
+            angles=(15.0, 70.0, 133.0, 190.0, 255.0, 320.0))
+
+
 def main():
+    if "--wide-r3-only" in sys.argv:
+        if not mr.have_ref():
+            mr.build()
+        print("LAPACK zheev backend:", mr.ref_use_lapack(True))
+        wide_fixtures_r3()
+        return
     if "--resamp-only" in sys.argv:
         resamp_fixtures()
         return
@@ -170,6 +186,7 @@ def main():
     fixture("m10_n3_N1000_r1001", 10, 3, 1000, 1001, mo.array_geometry(10), 3, 20.0, 2011, angles=(70.0, 190.0, 300.5))
     fixture("m9_n1_N630_r250", 9, 1, 630, 250, mo.array_geometry(9), 3, 15.0, 2012, angles=(222.0,))
     wide_fixtures()
+    wide_fixtures_r3()
     # baz_agc_cc: defaults of lib/baz_agc_cc.h:41 and a fast loop; stateful call sequences
     # that straddle the 4096-sample chunk of the HIP scan
     agc_fixture("agc_default_rate1e-4", 1e-4, 1.0, (12000,), 3001)
