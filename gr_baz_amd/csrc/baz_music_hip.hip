@@ -844,15 +844,25 @@ int process_wide_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void
             ProfScope ps(c, BAZ_MUSIC_STAGE_EVD);
             const uint8_t* only = nullptr;
             if (c->sub_evd && c->n <= 8) {     // few emitters: signal subspace by orthogonal iteration, Jacobi for what it hands back
-                const size_t lds = ((size_t)c->m * (c->m + 1) + (size_t)c->n * 64) * sizeof(double2);
-                if (c->n == 1) hipLaunchKernelGGL(bazwide::sub_wide_kernel<1>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
-                else if (c->n == 2) hipLaunchKernelGGL(bazwide::sub_wide_kernel<2>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
-                else if (c->n == 3) hipLaunchKernelGGL(bazwide::sub_wide_kernel<3>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
-                else if (c->n == 4) hipLaunchKernelGGL(bazwide::sub_wide_kernel<4>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
-                else if (c->n == 5) hipLaunchKernelGGL(bazwide::sub_wide_kernel<5>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
-                else if (c->n == 6) hipLaunchKernelGGL(bazwide::sub_wide_kernel<6>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
-                else if (c->n == 7) hipLaunchKernelGGL(bazwide::sub_wide_kernel<7>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
-                else hipLaunchKernelGGL(bazwide::sub_wide_kernel<8>, dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);
+                // from 50 antennas on the lower triangle of R only (sub_wide_kernel, TRI): four workgroups per CU instead of two or three
+                const bool tri = c->m >= 50;
+                const size_t lds = ((tri ? (size_t)c->m * (c->m + 1) / 2 : (size_t)c->m * (c->m + 1)) + (size_t)c->n * 64) * sizeof(double2);
+#define BAZ_SUB_WIDE(P)                                                                                                          \
+    do {                                                                                                                         \
+        if (tri) hipLaunchKernelGGL((bazwide::sub_wide_kernel<P, true>), dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);  \
+        else hipLaunchKernelGGL((bazwide::sub_wide_kernel<P, false>), dim3(nb), dim3(64), lds, c->stream, c->dR, c->dGw, c->dSw, c->dRedo, c->m);     \
+    } while (0)
+                switch (c->n) {
+                    case 1: BAZ_SUB_WIDE(1); break;
+                    case 2: BAZ_SUB_WIDE(2); break;
+                    case 3: BAZ_SUB_WIDE(3); break;
+                    case 4: BAZ_SUB_WIDE(4); break;
+                    case 5: BAZ_SUB_WIDE(5); break;
+                    case 6: BAZ_SUB_WIDE(6); break;
+                    case 7: BAZ_SUB_WIDE(7); break;
+                    default: BAZ_SUB_WIDE(8); break;
+                }
+#undef BAZ_SUB_WIDE
                 HIP_TRY(c, hipGetLastError());
                 only = c->dRedo;
             }
@@ -1328,14 +1338,15 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
                 const int sub_lds = (int)(((size_t)MX * (MX + 1) + 8u * 64u) * sizeof(double2));
                 const void* fn[10] = {reinterpret_cast<const void*>(bazwide::evd_wide_kernel),
                                       reinterpret_cast<const void*>(bazwide::scan_wide_kernel),
-                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<1>),
-                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<2>),
-                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<3>),
-                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<4>),
-                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<5>),
-                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<6>),
-                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<7>),
-                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<8>)};
+                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<1, false>),
+                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<2, false>),
+                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<3, false>),
+                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<4, false>),
+                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<5, false>),
+                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<6, false>),
+                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<7, false>),
+                                      reinterpret_cast<const void*>(bazwide::sub_wide_kernel<8, false>)};
+                // (the triangular instantiations, m >= 50, stay below 64 KiB: 33 KiB + 8 KiB at 64 antennas and 8 emitters)
                 const int sz[10] = {evd_lds, scan_lds, sub_lds, sub_lds, sub_lds, sub_lds, sub_lds, sub_lds, sub_lds, sub_lds};
                 bool ok = true;
                 for (int k = 0; k < 10; ++k)

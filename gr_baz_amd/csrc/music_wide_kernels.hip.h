@@ -459,7 +459,7 @@ __device__ __forceinline__ double wave_allmax(double v)
     return v;
 }
 
-template <int P>
+template <int P, bool TRI = false>
 __global__ __launch_bounds__(64) void sub_wide_kernel(const double2* __restrict__ R, double2* __restrict__ G,
                                                       double2* __restrict__ Ssig, uint8_t* __restrict__ redo, uint32_t m)
 {
@@ -470,18 +470,36 @@ __global__ __launch_bounds__(64) void sub_wide_kernel(const double2* __restrict_
     extern __shared__ double2 sw[];
     const uint32_t item = blockIdx.x;
     const int j = threadIdx.x;
+    // TRI (from 50 antennas on, where the full matrix leaves room for fewer than four of these one-wave workgroups per CU): R is
+    // Hermitian bit for bit (the covariance kernels mirror it), so only its lower triangle is kept, T(a, b) = R[a][b] for a >= b
+    // at a (a + 1) / 2 + b, and lane j reads its row as T(j, k) for k <= j and conj T(k, j) beyond -- 33 instead of 66 KiB at 64
+    // antennas: four workgroups per CU instead of two (EVD stage 0.196 -> 0.145 ms at n = 2, 1.36 -> 0.72 ms at n = 8).  Below
+    // that the full rows (stride m + 1, no index arithmetic, no bank conflicts) are faster: 17 .. 48 antennas lose 10-20 % in
+    // the triangular form.  Same values in the same order either way: the same bits.
     const uint32_t ld = m + 1;
-    double2* sR = sw;                                      // [m][ld]: row j is read by lane j only
-    double2* sY = sR + (size_t)m * ld;                     // [P][64]
+    double2* sR = sw;                                      // TRI: [m (m + 1) / 2], else [m][ld] (row j is read by lane j only)
+    double2* sY = sR + (TRI ? ((size_t)m * (m + 1)) / 2 : (size_t)m * ld);   // [P][64]
     const bool row = (uint32_t)j < m;
+    const uint32_t tj = TRI ? (uint32_t)j * ((uint32_t)j + 1u) / 2u : (uint32_t)j * ld;     // where row j starts
+    auto elem = [&](uint32_t k) -> double2 {               // R[j][k] of the scaled matrix
+        if constexpr (TRI) {
+            const bool low = k <= (uint32_t)j;
+            double2 v = sR[low ? tj + k : k * (k + 1u) / 2u + (uint32_t)j];
+            if (!low) v.y = -v.y;
+            return v;
+        } else {
+            return sR[tj + k];
+        }
+    };
+    const uint32_t kend = TRI ? (uint32_t)j + 1u : m;      // entries of row j this lane owns
 
     double psum = 0.0, dj = 0.0;
     if (row) {
-        for (uint32_t k = 0; k < m; ++k) {
+        for (uint32_t k = 0; k < kend; ++k) {
             double2 v = R[((size_t)item * m + j) * m + k];
             psum += v.x + v.y;
             if (k == (uint32_t)j) { v.y = 0.0; dj = fabs(v.x); }
-            sR[j * ld + k] = v;
+            sR[tj + k] = v;
         }
     }
     const double poison = wave_allsum(psum * 0.0);
@@ -490,7 +508,8 @@ __global__ __launch_bounds__(64) void sub_wide_kernel(const double2* __restrict_
     (void)frexp(dmax, &ex);
     const double scl = (dmax > 0.0 && dmax < __builtin_huge_val()) ? ldexp(1.0, -ex) : 1.0;
     if (row)
-        for (uint32_t k = 0; k < m; ++k) { double2 v = sR[j * ld + k]; v.x *= scl; v.y *= scl; sR[j * ld + k] = v; }
+        for (uint32_t k = 0; k < kend; ++k) { double2 v = sR[tj + k]; v.x *= scl; v.y *= scl; sR[tj + k] = v; }
+    if constexpr (TRI) bazmusic::wave_lds_fence();         // (rows read each other's entries from here on)
 
     auto orth = [&](double2 (&z)[P], double2 (&yn)[P]) -> bool {
         bool ok = true;
@@ -516,7 +535,7 @@ __global__ __launch_bounds__(64) void sub_wide_kernel(const double2* __restrict_
 
     double2 y[P], z[P];
 #pragma unroll
-    for (int c = 0; c < P; ++c) z[c] = row ? sR[j * ld + c] : make_double2(0.0, 0.0);
+    for (int c = 0; c < P; ++c) z[c] = row ? elem((uint32_t)c) : make_double2(0.0, 0.0);
     bool ok = orth(z, y) && !(poison != poison);
     bool conv = false;
     double d2prev = __builtin_huge_val();
@@ -529,7 +548,7 @@ __global__ __launch_bounds__(64) void sub_wide_kernel(const double2* __restrict_
         for (int c = 0; c < P; ++c) z[c] = make_double2(0.0, 0.0);
         if (row) {
             for (uint32_t k = 0; k < m; ++k) {
-                const double2 r = sR[j * ld + k];
+                const double2 r = elem(k);
 #pragma unroll
                 for (int c = 0; c < P; ++c) {
                     const double2 yk = sY[c * 64 + k];
