@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -85,7 +86,7 @@ long double sincl_(long double x)
 // the band-limited (|f| <= B = 1/4) squared error between sum_j h_j e^{-i 2 pi f j} and the ideal delay
 // e^{-i 2 pi f (4 - mu)} -- linear least squares, normal equations A h = b with A_jl = 2B sinc(2B (j - l)),
 // b_j = 2B sinc(2B (j - 4 + mu)).  (GNU Radio solves the same problem with a numerical optimiser and prints
-// 6 digits; the published mu = 1/128 row is reproduced to 9.5e-7.)  Rows 0 and 128 are pure delays.
+// 6 digits; see the rounding below.)  Rows 0 and 128 are pure delays.
 void build_taps(float* taps)
 {
     const long double B = 0.25L;
@@ -108,7 +109,13 @@ void build_taps(float* taps)
                 for (int k = c; k <= RS_NTAPS; ++k) a[r][k] -= f * a[c][k];
             }
         }
-        for (int j = 0; j < RS_NTAPS; ++j) taps[i * RS_NTAPS + j] = (float)(a[j][RS_NTAPS] / a[j][j]);
+        // gnuradio-filter's interpolator_taps.h holds these values as printed by its generator ("%12.5e": six significant
+        // digits) and compiled as float: the same decimal rounding here, then the float nearest to that decimal
+        for (int j = 0; j < RS_NTAPS; ++j) {
+            char dec[40];
+            snprintf(dec, sizeof dec, "%.5Le", a[j][RS_NTAPS] / a[j][j]);
+            taps[i * RS_NTAPS + j] = (float)strtod(dec, nullptr);
+        }
     }
     for (int j = 0; j < RS_NTAPS; ++j) taps[j] = taps[RS_NSTEPS * RS_NTAPS + j] = 0.0f;
     taps[4] = 1.0f;

@@ -13,7 +13,9 @@
  * Arithmetic: out[o] = sum_k in[ii_o + k] * taps[imu_o][7-k] (float accumulation), imu_o = rint((float)mu_o * 128).
  * The 8-tap x 129-phase table belongs to gnuradio-filter's MMSE interpolator, which gr-baz does not vendor: a fresh
  * context starts from the table regenerated from the library's published criterion (closed-form least squares,
- * gr_baz_amd/csrc/baz_resamp_hip.hip: build_taps; ~1e-6 from the published rows) -- PARITY UNPINNED for that default --
+ * gr_baz_amd/csrc/baz_resamp_hip.hip: build_taps, rounded to the six significant digits the library's generator prints:
+ * the rows of the published header known here, mu = 1/128 .. 4/128 and 64/128, come out digit for digit) -- PARITY
+ * UNPINNED for that default in the strict sense, as the published file itself is not available offline --
  * and baz_resamp_set_taps() installs the host's own table, which the host block does wherever it is compiled against
  * a real gnuradio-filter: bit-exact with whatever gnuradio-filter the host has.  The reference's x87 `long double` phase recurrence mu <- frac(mu + mu_inc),
  * ii <- ii + floor(mu + mu_inc) is evaluated in closed form, P_o = mu_0 + o * mu_inc in 64.64-bit fixed point
@@ -100,8 +102,8 @@ BAZ_RESAMP_API double baz_resamp_ratio(const baz_resamp_ctx* ctx);              
 BAZ_RESAMP_API int baz_resamp_phase_exact(const baz_resamp_ctx* ctx);
 /* The 129 x 8 tap table in use (float, host copy). */
 BAZ_RESAMP_API const float* baz_resamp_taps(const baz_resamp_ctx* ctx);
-/* The table a fresh context starts with: the closed-form MMSE solution (see the header comment), written to
- * out[129 * 8].  Pure host arithmetic, no device needed. */
+/* The table a fresh context starts with: the closed-form MMSE solution at six significant digits (see the header
+ * comment), written to out[129 * 8].  Pure host arithmetic, no device needed. */
 BAZ_RESAMP_API void baz_resamp_default_taps(float* out);
 /* Replaces the table: taps[imu * 8 + j] = tap j of phase imu as gnuradio-filter's interpolator stores it (interpolate()
  * forms sum_k in[k] * taps[imu][7 - k]; /root/reference/lib/baz_fractional_resampler_cc.cc:172,203 call it).  This is how

@@ -18,14 +18,18 @@
  *         integral_{-B}^{B} | sum_j h_j e^{-i 2 pi f j} - e^{-i 2 pi f (4 - mu)} |^2 df,   B = 0.25,
  *     numerically (praxis) and prints 6 significant digits.  That problem is linear least squares with
  *     the closed form  A h = b,  A_jl = 2B sinc(2B (j-l)),  b_j = 2B sinc(2B (j - (4 - mu))), used here.
- *     The only published row we can anchor on (mu = 1/128:
- *       -1.54700e-04  8.53777e-04 -2.76968e-03  7.89295e-03  9.98534e-01 -5.41054e-03  1.24642e-03 -1.98047e-04)
- *     is reproduced to 9.5e-7 absolute (tests/test_resamp.py) -- the residual of the reference table's own
- *     numerical optimiser.  PARITY UNPINNED: no golden vectors exist in the reference, and the true table is
- *     not available offline; outputs agree with a real GNU Radio to ~1e-6 of the signal scale, not bit for bit.
+ *     The published header holds the generator's printout ("%12.5e") as float literals, so the table here is
+ *     the closed form ROUNDED TO SIX SIGNIFICANT DECIMAL DIGITS and then to float.  Rows of that header as far as
+ *     they are known here without a copy of it (mu = 1/128 .. 4/128 and 64/128, written down from memory in
+ *     tests/test_resamp.py) are reproduced digit for digit, 40 of 40 entries -- which a closed form could not do
+ *     for misremembered digits, nor a numerical minimiser's residue survive.  PARITY STILL UNPINNED in the strict
+ *     sense: no golden vectors exist in the reference and the file itself is not available offline; a host that has
+ *     gnuradio-filter installs ITS table through baz_resamp_set_taps() (include/baz_resamp_hip.h).
  */
 #include <math.h>
 #include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define RS_NSTEPS 128
@@ -71,7 +75,12 @@ void resamp_ref_taps(float taps[RS_NSTEPS + 1][RS_NTAPS])
                 for (int k = c; k <= RS_NTAPS; ++k) A[r][k] -= f * A[c][k];
             }
         }
-        for (int j = 0; j < RS_NTAPS; ++j) taps[i][j] = (float)(A[j][RS_NTAPS] / A[j][j]);
+        /* the published table holds the generator's printout ("%12.5e", six significant digits) compiled as float */
+        for (int j = 0; j < RS_NTAPS; ++j) {
+            char dec[40];
+            snprintf(dec, sizeof dec, "%.5Le", A[j][RS_NTAPS] / A[j][j]);
+            taps[i][j] = (float)strtod(dec, NULL);
+        }
     }
     /* the end rows are pure delays in the published table */
     memset(taps[0], 0, sizeof(taps[0]));
