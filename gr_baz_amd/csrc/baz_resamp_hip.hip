@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <locale.h>
 #include <mutex>
 #include <new>
 
@@ -89,6 +90,9 @@ long double sincl_(long double x)
 // 6 digits; see the rounding below.)  Rows 0 and 128 are pure delays.
 void build_taps(float* taps)
 {
+    // the decimal round trip below must read "." as the decimal point whatever locale the host application has set
+    locale_t cloc = newlocale(LC_ALL_MASK, "C", (locale_t)0);
+    locale_t prev = cloc ? uselocale(cloc) : (locale_t)0;
     const long double B = 0.25L;
     for (int i = 0; i <= RS_NSTEPS; ++i) {
         long double a[RS_NTAPS][RS_NTAPS + 1];
@@ -117,6 +121,7 @@ void build_taps(float* taps)
             taps[i * RS_NTAPS + j] = (float)strtod(dec, nullptr);
         }
     }
+    if (cloc) { uselocale(prev); freelocale(cloc); }
     for (int j = 0; j < RS_NTAPS; ++j) taps[j] = taps[RS_NSTEPS * RS_NTAPS + j] = 0.0f;
     taps[4] = 1.0f;
     taps[RS_NSTEPS * RS_NTAPS + 3] = 1.0f;

@@ -26,6 +26,8 @@
  *     sense: no golden vectors exist in the reference and the file itself is not available offline; a host that has
  *     gnuradio-filter installs ITS table through baz_resamp_set_taps() (include/baz_resamp_hip.h).
  */
+#define _POSIX_C_SOURCE 200809L
+#include <locale.h>
 #include <math.h>
 #include <stddef.h>
 #include <stdio.h>
@@ -58,6 +60,8 @@ static long double sincl_(long double x)
 void resamp_ref_taps(float taps[RS_NSTEPS + 1][RS_NTAPS])
 {
     const long double B = 0.25L;
+    locale_t cloc = newlocale(LC_ALL_MASK, "C", (locale_t)0);      /* "." is the decimal point of the round trip below */
+    locale_t prev = cloc ? uselocale(cloc) : (locale_t)0;
     for (int i = 0; i <= RS_NSTEPS; ++i) {
         long double A[RS_NTAPS][RS_NTAPS + 1];
         const long double delay = 4.0L - (long double)i / RS_NSTEPS;
@@ -82,6 +86,7 @@ void resamp_ref_taps(float taps[RS_NSTEPS + 1][RS_NTAPS])
             taps[i][j] = (float)strtod(dec, NULL);
         }
     }
+    if (cloc) { uselocale(prev); freelocale(cloc); }
     /* the end rows are pure delays in the published table */
     memset(taps[0], 0, sizeof(taps[0]));
     memset(taps[RS_NSTEPS], 0, sizeof(taps[RS_NSTEPS]));
