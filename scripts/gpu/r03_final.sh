@@ -8,8 +8,10 @@ TAG=${1:-r03final}; HEAD=${2:-unknown}; P=r03
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG; mkdir -p $O $O/profiles
 T0=$(date +%s)
 cd $R
+if [ "${TESTS_FIRST:-1}" = 1 ]; then
 timeout 120 python -m pytest tests/test_resamp.py tests/test_frontend.py -x -q -m gpu 2>&1 | tail -4 | tee $O/tests_resamp_frontend.txt
 echo "t=$(( $(date +%s) - T0 )) s after tests"
+fi
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-extras"
 timeout 60 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $B --steps 20 --warmup 3 > $O/stats_bench_line.json 2> $O/stats_err.txt
@@ -49,3 +51,8 @@ else timeout $LEFT python bench.py --steps 20 --warmup 3 --no-extras > $O/bench_
 head -8 $O/bench_kernel_stats.csv | cut -c1-200; tail -8 $O/pmc_traffic_out.txt; python -c "
 import json; d=json.load(open('$O/bench_line.json')); print(d['value'], d['ms_per_step'], d['rounds']); print(d['roofline']); print(d.get('cpu_baseline'))"
 echo "t=$(( $(date +%s) - T0 )) s total"
+# the whole GPU suite with what is left of the call (FULL_SUITE_S seconds; 0 = skip)
+if [ "${FULL_SUITE_S:-0}" -gt 0 ]; then
+timeout ${FULL_SUITE_S} python -m pytest tests -q -m gpu -x 2>&1 | tail -6 | tee $O/tests_full_gpu_suite.txt
+echo "t=$(( $(date +%s) - T0 )) s after the whole GPU suite"
+fi
