@@ -70,6 +70,26 @@ def dot_bf16x3(q, t):
     return acc
 
 
+def split2_f16(x, scale):
+    """x * scale -> two float16 parts (the product's coarse form uses the same kind of split, scan_coarse_kernels.hip.h)."""
+    xs = (x * scale).astype(np.float32)
+    h = xs.astype(np.float16).astype(np.float32)
+    l = (xs - h).astype(np.float32).astype(np.float16).astype(np.float32)
+    return h, l
+
+
+def dot_f16x2(q, t):
+    """two f16 parts per operand, all four cross products (exact in float32), float32 accumulation, small terms first."""
+    sq, st = 2.0 ** 10, 2.0 ** 12
+    qh, ql = split2_f16(q, sq)
+    th, tl = split2_f16(t, st)
+    acc = np.zeros((q.shape[0], t.shape[0]), np.float32)
+    for a, b in ((ql, tl), (ql, th), (qh, tl), (qh, th)):
+        for k in range(q.shape[1]):
+            acc = (acc + (a[:, k, None] * b[None, :, k]).astype(np.float32)).astype(np.float32)
+    return acc.astype(np.float64) / (sq * st)
+
+
 def main():
     items = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     res = int(sys.argv[2]) if len(sys.argv) > 2 else 3600
@@ -91,6 +111,7 @@ def main():
         d32 = dot_f32(q, t).astype(np.float64)
         rel = np.abs(d32 - d64) / d64
         relb = np.abs(dot_bf16x3(q, t).astype(np.float64) - d64) / d64
+        relh = np.abs(dot_f16x2(q, t) - d64) / d64
         frac = d64 / float(m)
         line = "snr %4.0f dB: " % snr
         for thr in (0.5, 0.25, 0.125, 0.05, 0.02):
@@ -105,6 +126,8 @@ def main():
                   % (100.0 * (f >= 0.125).mean(), 100.0 * (f >= 0.05).mean()))
         print("           three-part bf16 split (6 cross products, f32 accumulation): worst rel above 0.125: %.1e, above 0.05: %.1e, median %.1e"
               % (relb[frac >= 0.125].max(), relb[frac >= 0.05].max(), np.median(relb)))
+        print("           two-part f16 split (4 cross products, f32 accumulation):   worst rel above 0.125: %.1e, above 0.05: %.1e, median %.1e"
+              % (relh[frac >= 0.125].max(), relh[frac >= 0.05].max(), np.median(relh)))
         print("           overall worst rel %.1e at d/m = %.2e; median rel %.1e" % (rel.max(), frac.flat[rel.argmax()], np.median(rel)))
 
 
