@@ -20,8 +20,8 @@
  *     the closed form  A h = b,  A_jl = 2B sinc(2B (j-l)),  b_j = 2B sinc(2B (j - (4 - mu))), used here.
  *     The published header holds the generator's printout ("%12.5e") as float literals, so the table here is
  *     the closed form ROUNDED TO SIX SIGNIFICANT DECIMAL DIGITS and then to float.  Rows of that header as far as
- *     they are known here without a copy of it (mu = 1/128 .. 4/128 and 64/128, written down from memory in
- *     tests/test_resamp.py) are reproduced digit for digit, 40 of 40 entries -- which a closed form could not do
+ *     they are known here without a copy of it (mu = 1/128 .. 5/128 and 64/128, written down from memory in
+ *     tests/test_resamp.py) are reproduced digit for digit, 48 of 48 entries -- which a closed form could not do
  *     for misremembered digits, nor a numerical minimiser's residue survive.  PARITY STILL UNPINNED in the strict
  *     sense: no golden vectors exist in the reference and the file itself is not available offline; a host that has
  *     gnuradio-filter installs ITS table through baz_resamp_set_taps() (include/baz_resamp_hip.h).

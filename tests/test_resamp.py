@@ -55,12 +55,12 @@ def make(cls, g, **kw):
 
 
 # ------------------------------------------------------------------ CPU: the oracle
-# Rows of the published table (gnuradio-filter's interpolator_taps.h: mu = 1/128 .. 4/128 and the mid row 64/128), written
+# Rows of the published table (gnuradio-filter's interpolator_taps.h: mu = 1/128 .. 5/128 and the mid row 64/128), written
 # down from memory of that file -- there is no copy of it in this image -- and therefore cross-checked here rather than
-# trusted: all 40 entries equal the closed form at the table's print precision ("%12.5e", six significant digits), which
+# trusted: all 48 entries equal the closed form at the table's print precision ("%12.5e", six significant digits), which
 # an independent computation would not do for misremembered digits.  (An earlier round's note had -1.98047e-04 and
 # -5.94874e-04 in the outermost tap of rows 1 and 3 and read the 1e-6 gaps as the residue of GNU Radio's minimiser;
-# rows 2, 4 and 64 show no such residue in any tap, and those two digits were the recollection's, not the table's.)
+# rows 2, 4, 5 and 64 show no such residue in any tap, and those two digits were the recollection's, not the table's.)
 # The table of the restatement and of the engine is therefore the closed form rounded the way the generator prints, and
 # then to float the way the compiler reads the header: equal to the rows below bit for bit.
 PUBLISHED_ROWS = {
@@ -68,6 +68,7 @@ PUBLISHED_ROWS = {
     2: np.array([-3.09412e-04, 1.70888e-03, -5.55134e-03, 1.58840e-02, 9.96891e-01, -1.07209e-02, 2.47942e-03, -3.96391e-04]),
     3: np.array([-4.64053e-04, 2.56486e-03, -8.34364e-03, 2.39714e-02, 9.95074e-01, -1.59305e-02, 3.69852e-03, -5.92100e-04]),
     4: np.array([-6.18544e-04, 3.42130e-03, -1.11453e-02, 3.21531e-02, 9.93082e-01, -2.10389e-02, 4.90322e-03, -7.86031e-04]),
+    5: np.array([-7.72802e-04, 4.27773e-03, -1.39548e-02, 4.04274e-02, 9.90917e-01, -2.60456e-02, 6.09305e-03, -9.78093e-04]),
     64: np.array([-6.77751e-03, 3.94578e-02, -1.42658e-01, 6.09836e-01, 6.09836e-01, -1.42658e-01, 3.94578e-02, -6.77751e-03]),
 }
 
