@@ -1,6 +1,7 @@
 """Builds the in-tree native artefacts of gr_baz_amd (gfx950 only, no JIT cache):
 
   csrc/libbaz_music_hip.so   HIP kernels + the C-ABI of include/baz_music_hip.h   (hipcc)
+  csrc/libbaz_music_hip_lab.so   the same with -DBAZ_MUSIC_LAB: lab switches compiled in (tests/lab, A/B tests only)
   csrc/libbaz_agc_hip.so     AGC kernels + the C-ABI of include/baz_agc_hip.h      (hipcc)
   csrc/libbaz_resamp_hip.so  fractional resampler kernel + the C-ABI of include/baz_resamp_hip.h (hipcc)
   host/libgnuradio_baz_music.so   the gr::sync_block host block on the GNU Radio API shim (g++)
@@ -23,6 +24,7 @@ HOST = os.path.join(HERE, "host")
 INCLUDE = os.path.join(ROOT, "include")
 
 HIP_LIB = os.path.join(CSRC, "libbaz_music_hip.so")
+HIP_LAB_LIB = os.path.join(CSRC, "libbaz_music_hip_lab.so")   # -DBAZ_MUSIC_LAB (tests/lab, A/B tests)
 AGC_LIB = os.path.join(CSRC, "libbaz_agc_hip.so")
 RESAMP_LIB = os.path.join(CSRC, "libbaz_resamp_hip.so")
 HOST_LIB = os.path.join(HOST, "libgnuradio_baz_music.so")
@@ -47,28 +49,32 @@ def _hipcc():
 
 
 def build_hip(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, "baz_music_hip.hip"), os.path.join(CSRC, "music_kernels.hip.h"),
-            os.path.join(CSRC, "music_wide_kernels.hip.h"), os.path.join(CSRC, "scan_coarse_kernels.hip.h"),
-            os.path.join(INCLUDE, "baz_music_hip.h")]
-    if force or _newer(HIP_LIB, srcs):
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", HIP_LIB, srcs[0]]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd, cwd=CSRC)
+    """The three HIP libraries, plus the LAB form of the MUSIC library (-DBAZ_MUSIC_LAB: the same sources with the
+    ablation / geometry / older-kernel switches that the release form does not read; loaded only by tests/lab and the
+    A/B tests through capi.Context(..., lab=True)).  Out-of-date targets compile side by side."""
+    music_srcs = [os.path.join(CSRC, "baz_music_hip.hip"), os.path.join(CSRC, "music_kernels.hip.h"),
+                  os.path.join(CSRC, "music_wide_kernels.hip.h"), os.path.join(CSRC, "scan_coarse_kernels.hip.h"),
+                  os.path.join(CSRC, "scan_i8_kernels.hip.h"), os.path.join(INCLUDE, "baz_music_hip.h")]
     agc_srcs = [os.path.join(CSRC, "baz_agc_hip.hip"), os.path.join(CSRC, "agc_kernels.hip.h"),
                 os.path.join(INCLUDE, "baz_agc_hip.h")]
-    if force or _newer(AGC_LIB, agc_srcs):
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", AGC_LIB, agc_srcs[0]]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd, cwd=CSRC)
     rs_srcs = [os.path.join(CSRC, "baz_resamp_hip.hip"), os.path.join(CSRC, "resamp_kernels.hip.h"),
                os.path.join(INCLUDE, "baz_resamp_hip.h")]
-    if force or _newer(RESAMP_LIB, rs_srcs):
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", RESAMP_LIB, rs_srcs[0]]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd, cwd=CSRC)
+    jobs = []
+    for target, srcs, extra in ((HIP_LIB, music_srcs, []), (HIP_LAB_LIB, music_srcs, ["-DBAZ_MUSIC_LAB"]),
+                                (AGC_LIB, agc_srcs, []), (RESAMP_LIB, rs_srcs, [])):
+        if force or _newer(target, srcs):
+            cmd = [_hipcc()] + HIPCC_FLAGS + extra + ["-I", INCLUDE, "-o", target + ".tmp", srcs[0]]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            jobs.append((target, cmd, subprocess.Popen(cmd, cwd=CSRC)))
+    failed = []
+    for target, cmd, proc in jobs:
+        if proc.wait() != 0:
+            failed.append(" ".join(cmd))
+        else:
+            os.replace(target + ".tmp", target)
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
     return HIP_LIB
 
 

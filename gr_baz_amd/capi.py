@@ -14,6 +14,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbaz_music_hip.so")
+# the same sources built with -DBAZ_MUSIC_LAB: reads the lab switches (ablations, geometry overrides, older kernels) the
+# release library does not contain.  Only tests/lab and the A/B tests ask for it (Context(..., lab=True)).
+LAB_LIB_PATH = os.path.join(_HERE, "csrc", "libbaz_music_hip_lab.so")
 
 OK = 0
 E_INVALID, E_NOMEM, E_HIP, E_UNSUPPORTED, E_NODEVICE = -1, -2, -3, -4, -5
@@ -29,6 +32,7 @@ SYMBOLS = [
     "baz_music_last_hip_error", "baz_music_version", "baz_music_device_count", "baz_music_device", "baz_music_set_peak_mode", "baz_music_refined_items",
     "baz_music_refined_values", "baz_music_debug_coarse_margin", "baz_music_debug_coarse_fired",
     "baz_music_host_register", "baz_music_set_host_pinning", "baz_music_host_unregister_all", "baz_music_host_pinned_bytes",
+    "baz_music_debug_i8_margin", "baz_music_debug_i8_stats", "baz_music_uses_i8_scan", "baz_music_debug_i8_image",
 ]
 
 _vp = ctypes.c_void_p
@@ -36,6 +40,7 @@ _u32 = ctypes.c_uint32
 _f32p = ctypes.POINTER(ctypes.c_float)
 
 _lib = None
+_lab_lib = None
 
 
 class MusicError(RuntimeError):
@@ -47,15 +52,25 @@ class MusicError(RuntimeError):
         super().__init__(msg)
 
 
-def lib():
-    """Loads libbaz_music_hip.so (built in-tree by gr_baz_amd.build); never falls back."""
-    global _lib
+def lib(lab=False):
+    """Loads libbaz_music_hip.so (built in-tree by gr_baz_amd.build); never falls back.  lab=True: the -DBAZ_MUSIC_LAB form."""
+    global _lib, _lab_lib
+    if lab:
+        if _lab_lib is None:
+            if not os.path.exists(LAB_LIB_PATH):
+                raise ImportError("gr_baz_amd: %s is missing - run `python -m gr_baz_amd.build`" % LAB_LIB_PATH)
+            _lab_lib = _bind(ctypes.CDLL(LAB_LIB_PATH))
+        return _lab_lib
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("gr_baz_amd: %s is missing - run `python -m gr_baz_amd.build` "
                           "(there is no CPU fallback for the MUSIC-DoA path)" % LIB_PATH)
-    L = ctypes.CDLL(LIB_PATH)
+    _lib = _bind(ctypes.CDLL(LIB_PATH))
+    return _lib
+
+
+def _bind(L):
     L.baz_music_create.restype = ctypes.c_int
     L.baz_music_create.argtypes = [ctypes.POINTER(_vp), _u32, _u32, _u32, _u32, _f32p, ctypes.c_int]
     L.baz_music_destroy.restype = None
@@ -119,7 +134,15 @@ def lib():
     L.baz_music_host_unregister_all.argtypes = [_vp]
     L.baz_music_host_pinned_bytes.restype = ctypes.c_uint64
     L.baz_music_host_pinned_bytes.argtypes = [_vp]
-    _lib = L
+    L.baz_music_debug_i8_margin.restype = ctypes.c_int
+    L.baz_music_debug_i8_margin.argtypes = [_vp, _vp, _u32, ctypes.POINTER(ctypes.c_float)]
+    L.baz_music_debug_i8_stats.restype = ctypes.c_int
+    L.baz_music_debug_i8_stats.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    L.baz_music_uses_i8_scan.restype = ctypes.c_int
+    L.baz_music_uses_i8_scan.argtypes = [_vp]
+    L.baz_music_debug_i8_image.restype = ctypes.c_size_t
+    L.baz_music_debug_i8_image.argtypes = [_u32, _u32, _f32p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t,
+                                           ctypes.POINTER(ctypes.c_double)]
     return L
 
 
@@ -133,8 +156,8 @@ def _table_f32(table, res, m):
 class Context:
     """One baz_music_ctx: the device-side state of one baz_music_doa block instance."""
 
-    def __init__(self, m, n, nsamples, resolution, table, device_id=-1):
-        L = lib()
+    def __init__(self, m, n, nsamples, resolution, table, device_id=-1, lab=False):
+        L = self._L = lib(lab)
         self.m, self.n, self.nsamples, self.res = int(m), int(n), int(nsamples), int(resolution)
         t = _table_f32(table, self.res, self.m) if (self.res > 0 and self.m > 0) else \
             np.zeros((1, 1), np.complex64)
@@ -147,12 +170,12 @@ class Context:
 
     def _chk(self, r, where):
         if r < 0:
-            raise MusicError(r, where, lib().baz_music_last_hip_error(self._h).decode())
+            raise MusicError(r, where, self._L.baz_music_last_hip_error(self._h).decode())
         return r
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().baz_music_destroy(self._h)
+            self._L.baz_music_destroy(self._h)
             self._h = None
 
     __del__ = close
@@ -165,7 +188,7 @@ class Context:
 
     def set_table(self, table):
         t = _table_f32(table, self.res, self.m)
-        self._chk(lib().baz_music_set_table(self._h, t.view(np.float32).ctypes.data_as(_f32p)),
+        self._chk(self._L.baz_music_set_table(self._h, t.view(np.float32).ctypes.data_as(_f32p)),
                   "baz_music_set_table")
 
     def process(self, items, want_lvl=True, want_spectrum=True, out=None):
@@ -188,7 +211,7 @@ class Context:
             ang = np.zeros((B, self.n), np.float32)
             lvl = np.zeros((B, self.n), np.float32) if want_lvl else None
             spec = np.zeros((B, self.res), np.float32) if want_spectrum else None
-        r = lib().baz_music_process(
+        r = self._L.baz_music_process(
             self._h, x.view(np.float32).ctypes.data_as(_f32p), B, ang.ctypes.data_as(_f32p),
             lvl.ctypes.data_as(_f32p) if want_lvl else None,
             spec.ctypes.data_as(_f32p) if want_spectrum else None)
@@ -201,10 +224,10 @@ class Context:
         orders: set_stream(), sync(), or a device-wide synchronize).  stream=<hipStream_t as int, 0 = the legacy
         default stream, e.g. torch.cuda.current_stream().cuda_stream>: with stream semantics relative to it."""
         if stream is None:
-            r = lib().baz_music_process_device(self._h, _vp(d_in), int(batch), _vp(d_ang),
+            r = self._L.baz_music_process_device(self._h, _vp(d_in), int(batch), _vp(d_ang),
                                                _vp(d_lvl) if d_lvl else None, _vp(d_spec) if d_spec else None)
         else:
-            r = lib().baz_music_process_device_on(self._h, _vp(stream) if stream else None, _vp(d_in), int(batch),
+            r = self._L.baz_music_process_device_on(self._h, _vp(stream) if stream else None, _vp(d_in), int(batch),
                                                   _vp(d_ang), _vp(d_lvl) if d_lvl else None,
                                                   _vp(d_spec) if d_spec else None)
         self._chk(r, "baz_music_process_device")
@@ -213,77 +236,109 @@ class Context:
         """(item, bin) VALUES of the last process call that were recomputed in the reference's literal form (near-null
         bins, extreme SNR) -- not items: one item can contribute up to `resolution` of them.  On the wide path counted by the
         matrix-core scan only (17 <= m <= 64, n <= 8), else 0."""
-        return int(lib().baz_music_refined_values(self._h))
+        return int(self._L.baz_music_refined_values(self._h))
 
     refined_items = refined_values      # the round-1 name of the same statistic (kept for callers; the unit is values)
 
     def debug_coarse_fired(self):
         """Lab statistic (context created under BAZ_MUSIC_COARSE_STATS=1): exact tile evaluations since the last read."""
-        return int(lib().baz_music_debug_coarse_fired(self._h))
+        return int(self._L.baz_music_debug_coarse_fired(self._h))
 
     def debug_coarse_margin(self, d_in, batch):
         """Worst observed |coarse - exact| / allowance of the coarse-gated scan over every (item, bin) of the batch
         (baz_music_debug_coarse_margin; the gate is sound below 1)."""
         w = ctypes.c_float(0.0)
-        self._chk(lib().baz_music_debug_coarse_margin(self._h, _vp(d_in), int(batch), ctypes.byref(w)),
+        self._chk(self._L.baz_music_debug_coarse_margin(self._h, _vp(d_in), int(batch), ctypes.byref(w)),
                   "baz_music_debug_coarse_margin")
         return float(w.value)
+
+    def uses_i8_scan(self):
+        """True when this context's scan runs on the int8 matrix core (6 <= m <= 16, n <= 4, not BAZ_MUSIC_EXACT=1)."""
+        return bool(self._L.baz_music_uses_i8_scan(self._h))
+
+    def debug_i8_margin(self, d_in, batch):
+        """Worst observed |d_int - d| / E of the int8 scan over every (item, bin) of the batch (the bound holds below 1)."""
+        w = ctypes.c_float(0.0)
+        self._chk(self._L.baz_music_debug_i8_margin(self._h, _vp(d_in), int(batch), ctypes.byref(w)),
+                  "baz_music_debug_i8_margin")
+        return float(w.value)
+
+    def debug_i8_stats(self):
+        """(wave steps recomputed in the fp64 form, wave steps walked) of the int8 scan since the last read; resets."""
+        a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._chk(self._L.baz_music_debug_i8_stats(self._h, ctypes.byref(a), ctypes.byref(b)), "baz_music_debug_i8_stats")
+        return int(a.value), int(b.value)
 
     # ---- page-locking of caller buffers that live across calls (a scheduler's stream buffers) ----
     def host_register(self, array):
         """Page-locks a numpy array's memory for this context (the array must outlive the registration: call
         host_unregister_all() or close() before dropping it).  Returns the library's code: 0 = locked (or already was)."""
-        return int(lib().baz_music_host_register(self._h, _vp(array.ctypes.data), array.nbytes))
+        return int(self._L.baz_music_host_register(self._h, _vp(array.ctypes.data), array.nbytes))
 
     def set_host_pinning(self, enable):
         """process() page-locks the ranges of every call the first time it sees them (persistent buffers only)."""
-        self._chk(lib().baz_music_set_host_pinning(self._h, 1 if enable else 0), "baz_music_set_host_pinning")
+        self._chk(self._L.baz_music_set_host_pinning(self._h, 1 if enable else 0), "baz_music_set_host_pinning")
 
     def host_unregister_all(self):
-        self._chk(lib().baz_music_host_unregister_all(self._h), "baz_music_host_unregister_all")
+        self._chk(self._L.baz_music_host_unregister_all(self._h), "baz_music_host_unregister_all")
 
     def host_pinned_bytes(self):
-        return int(lib().baz_music_host_pinned_bytes(self._h))
+        return int(self._L.baz_music_host_pinned_bytes(self._h))
 
     def set_peak_mode(self, mode):
         """0: the reference's n strongest bins (default); 1: n strongest local maxima (opt-in extension)."""
-        self._chk(lib().baz_music_set_peak_mode(self._h, int(mode)), "baz_music_set_peak_mode")
+        self._chk(self._L.baz_music_set_peak_mode(self._h, int(mode)), "baz_music_set_peak_mode")
 
     def set_stream(self, hip_stream):
-        self._chk(lib().baz_music_set_stream(self._h, _vp(hip_stream) if hip_stream else None),
+        self._chk(self._L.baz_music_set_stream(self._h, _vp(hip_stream) if hip_stream else None),
                   "baz_music_set_stream")
 
     def sync(self):
-        self._chk(lib().baz_music_sync(self._h), "baz_music_sync")
+        self._chk(self._L.baz_music_sync(self._h), "baz_music_sync")
 
     def reserve(self, max_batch):
-        self._chk(lib().baz_music_reserve(self._h, int(max_batch)), "baz_music_reserve")
+        self._chk(self._L.baz_music_reserve(self._h, int(max_batch)), "baz_music_reserve")
 
     def profile(self, enable):
         """enable: False/0 off, True/1 every stage, 2 only the scan stage (cheapest)."""
-        self._chk(lib().baz_music_profile(self._h, int(enable)), "baz_music_profile")
+        self._chk(self._L.baz_music_profile(self._h, int(enable)), "baz_music_profile")
 
     def stage_ms(self, stage):
         ms = ctypes.c_double(0.0)
         cnt = ctypes.c_uint64(0)
-        self._chk(lib().baz_music_stage_ms(self._h, stage, ctypes.byref(ms), ctypes.byref(cnt)),
+        self._chk(self._L.baz_music_stage_ms(self._h, stage, ctypes.byref(ms), ctypes.byref(cnt)),
                   "baz_music_stage_ms")
         return ms.value, cnt.value
 
     def stage_name(self, stage):
-        return lib().baz_music_stage_name(self._h, stage).decode()
+        return self._L.baz_music_stage_name(self._h, stage).decode()
 
     def debug_cov(self, d_in, batch, d_R):
-        self._chk(lib().baz_music_debug_cov(self._h, _vp(d_in), int(batch), _vp(d_R)), "baz_music_debug_cov")
+        self._chk(self._L.baz_music_debug_cov(self._h, _vp(d_in), int(batch), _vp(d_R)), "baz_music_debug_cov")
 
     def debug_evd(self, d_R, batch, d_Q):
-        self._chk(lib().baz_music_debug_evd(self._h, _vp(d_R), int(batch), _vp(d_Q)), "baz_music_debug_evd")
+        self._chk(self._L.baz_music_debug_evd(self._h, _vp(d_R), int(batch), _vp(d_Q)), "baz_music_debug_evd")
 
     def debug_q(self, d_in, batch, d_Q):
-        self._chk(lib().baz_music_debug_q(self._h, _vp(d_in), int(batch), _vp(d_Q)), "baz_music_debug_q")
+        self._chk(self._L.baz_music_debug_q(self._h, _vp(d_in), int(batch), _vp(d_Q)), "baz_music_debug_q")
 
     def bytes_per_item(self, with_spectrum=True):
-        return int(lib().baz_music_bytes_per_item(self._h, 1 if with_spectrum else 0))
+        return int(self._L.baz_music_bytes_per_item(self._h, 1 if with_spectrum else 0))
+
+
+def debug_i8_image(m, resolution, table):
+    """HOST-ONLY: (image bytes as a uint8 array [step][tile][block][digit][lane][16], params dict) that the library builds for
+    the int8 scan from `table`, or (None, None) when the table has no image.  Needs no device."""
+    t = _table_f32(table, int(resolution), int(m))
+    tp = t.view(np.float32).ctypes.data_as(_f32p)
+    n = lib().baz_music_debug_i8_image(int(m), int(resolution), tp, None, 0, None)
+    if n == 0:
+        return None, None
+    img = np.zeros(n, np.uint8)
+    par = np.zeros(16, np.float64)
+    lib().baz_music_debug_i8_image(int(m), int(resolution), tp, img.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n,
+                                   par.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    return img, {"wt": par[:5].copy(), "sq": par[5], "t_acc": par[6], "e_bound": par[7], "ns": int(par[8])}
 
 
 def q_stride(batch):

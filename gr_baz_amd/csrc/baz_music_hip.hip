@@ -8,6 +8,7 @@
 #include "music_kernels.hip.h"
 #include "music_wide_kernels.hip.h"
 #include "scan_coarse_kernels.hip.h"
+#include "scan_i8_kernels.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -21,6 +22,17 @@
 #include <vector>
 
 using namespace bazmusic;
+
+// Environment switches.  The RELEASE library reads only the documented tuning knobs: BAZ_MUSIC_EXACT,
+// BAZ_MUSIC_COARSE, BAZ_MUSIC_CHUNK_MIB, BAZ_MUSIC_PIN_LIMIT_MIB, BAZ_MUSIC_ZERO_COPY, BAZ_MUSIC_SINGLE_MIB -- none of them
+// can make a result wrong.  Everything else (ablations, older kernels, geometry overrides, dumps) exists only in the lab
+// build, -DBAZ_MUSIC_LAB = libbaz_music_hip_lab.so, which tests/lab and the A/B tests load explicitly
+// (tests/test_abi.py::test_release_library_reads_only_the_documented_knobs lists the strings of the release .so).
+#ifdef BAZ_MUSIC_LAB
+#define BAZ_LAB_ENV(NAME) getenv(NAME)
+#else
+#define BAZ_LAB_ENV(NAME) (static_cast<const char*>(nullptr))
+#endif
 
 namespace {
 
@@ -114,6 +126,12 @@ struct baz_music_ctx {
     int coarse_lab = 0;            // BAZ_MUSIC_COARSE_LAB=1: never run an exact tile (cost of the coarse passes alone; wrong results)
     int coarse_stats = 0;          // BAZ_MUSIC_COARSE_STATS=1: count exact tile evaluations (baz_music_debug_coarse_fired)
     unsigned long long* dMargin = nullptr;   // baz_music_debug_coarse_margin: worst error / allowance (float bits << 32 | where)
+    // int8-matrix-core scan (scan_i8_kernels.hip.h): 6 <= m <= 16, n <= 4
+    uint4* dIB = nullptr;          // digit image of the table (build_i8_image)
+    I8Params i8 = {};
+    bool i8_ok = false;            // image built (finite table, scale representable, size within I8_IMAGE_LIMIT)
+    int i8_on = 1;                 // BAZ_MUSIC_EXACT=1: every value on the fp64 matrix core (A/B; the round-3 scan)
+    unsigned long long* dI8Stat = nullptr;   // [0] wave steps recomputed in the fp64 form, [1] wave steps walked, [2] VAL margin
     int peak_mode = 0;      // 0: the reference's n strongest bins; 1 (opt-in extension): n strongest local maxima
     float* dPeakSpec = nullptr;   // internal spectrum when peak mode runs without the spectrum port
     size_t peak_spec_cap = 0;     // floats
@@ -333,11 +351,68 @@ bool build_coarse_image(const std::vector<double>& F, uint32_t m, uint32_t res, 
     return true;
 }
 
+
+// Digit image of the table for the int8-matrix-core scan (scan_i8_kernels.hip.h): Fi = rint(F 2^(8 NS - 2) / Fscale) cut into
+// NS balanced base-256 digits, most significant first (digits 1.. in [-128, 127], the first what is left: |.| <= 65), laid
+// out as the B operand of v_mfma_i32_16x16x64_i8:
+//     img[(((st*4 + t)*NKB + kb)*NS + s)*1024 + lane*16 + j] = digit s of Fi[bin = 64 st + 4 c + t][e = 64 kb + 16 g + j]
+// (lane = 16 g + c; 0 for e >= m^2 and for bins outside the table: such a bin gives d_int = 0 and its step takes the fp64
+// form, whose image carries the huge diagonal there).  Fills the kernel's parameters.  false: table not finite / all zero /
+// scale out of range (the fp64 scan runs then).
+constexpr size_t I8_IMAGE_LIMIT = (size_t)256 << 20;
+size_t i8_image_bytes(uint32_t m, uint32_t steps) { return (size_t)steps * 4 * i8_nkb((int)m) * I8_NS * 1024; }
+
+bool build_i8_image(const std::vector<double>& F, uint32_t m, uint32_t res, uint32_t steps, std::vector<uint8_t>& img,
+                    I8Params& ip)
+{
+    const uint32_t mm = m * m, nkb = (uint32_t)i8_nkb((int)m);
+    constexpr int NS = I8_NS;
+    double fmax = 0.0;
+    for (double v : F) {
+        if (!std::isfinite(v)) return false;
+        fmax = std::max(fmax, std::fabs(v));
+    }
+    if (!(fmax > 0.0)) return false;
+    int ex = 0;
+    (void)std::frexp(fmax / I8_QMAX, &ex);          // fmax / QMAX = f 2^ex, f in [0.5, 1)  ->  fmax / 2^ex < QMAX
+    if (ex < -400 || ex > 400) return false;
+    const double fscale = std::ldexp(1.0, ex);
+    const double sq = std::ldexp(1.0, 8 * NS - 2), sf = sq / fscale;
+    const double unit = std::ldexp(fscale, -8 * NS - 4);
+    for (int l = 0; l < NS; ++l) ip.wt[l] = std::ldexp(unit, 8 * (NS - 1 - l));
+    ip.sq = sq;
+    ip.e_bound = (double)mm * fscale * (double)NS * 1.01 * std::ldexp(1.0, 2 - 8 * NS);
+    ip.t_acc = ip.e_bound * (1.0 + 1.0 / I8_EPS);
+    ip.t_acc_f = std::nextafter((float)ip.t_acc, INFINITY);
+    img.assign(i8_image_bytes(m, steps), 0);
+    for (uint32_t bin = 0; bin < res; ++bin) {
+        const uint32_t st = bin >> 6, w = bin & 63u, c = w >> 2, t = w & 3u;
+        for (uint32_t e = 0; e < mm; ++e) {
+            const uint32_t kb = e >> 6, g = (e >> 4) & 3u, j = e & 15u;
+            long long v = std::llrint(F[(size_t)bin * mm + e] * sf);
+            uint8_t* base = img.data() + ((size_t)((st * 4 + t) * nkb + kb) * NS) * 1024 + (size_t)(g * 16 + c) * 16 + j;
+            for (int s = NS - 1; s >= 1; --s) {
+                const long long h = (v + 128) >> 8;          // floor((v + 128) / 256)  (arithmetic shift)
+                base[(size_t)s * 1024] = (uint8_t)((v - h * 256) & 255);
+                v = h;
+            }
+            base[0] = (uint8_t)(v & 255);
+        }
+    }
+    return true;
+}
+
 // the scan's short form (scan_mfma_kernel, SIG) needs fewer MFMAs than the projector GEMM
 bool short_form_applies(uint32_t m, uint32_t n) { return (n == 2 && m >= 9 && m <= 16) || (n == 1 && m >= 6 && m <= 16); }
+// The int8-matrix-core scan applies: 6 .. 16 antennas (row classes below, run-time-m kernels above), lists of <= 4 keys.
+bool i8_active(const baz_music_ctx* c)
+{
+    return c->i8_on && c->i8_ok && c->dIB && c->m >= 6 && c->m <= 16 && c->n <= 4 && !c->lab_variant;
+}
 bool short_form_in_use(const baz_music_ctx* c)
 {
-    return short_form_applies(c->m, c->n) && c->sig_scan && c->dSs && c->dA2p && !c->lab_variant;
+    // (the integer form evaluates the projector form: the EVD must write its coefficients)
+    return short_form_applies(c->m, c->n) && c->sig_scan && c->dSs && c->dA2p && !c->lab_variant && !i8_active(c);
 }
 
 int ensure_workspace(baz_music_ctx* c, uint32_t batch)
@@ -593,8 +668,10 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
                         c->dCand, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, stats, nullptr
             if constexpr (M > 4) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, coarse_rg_wide(M, NMAX), 4>), BAZ_COARSE_ARGS);
             else if (CG.tpp == 4) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 2, 4>), BAZ_COARSE_ARGS);
+#ifdef BAZ_MUSIC_LAB
             else if (c->coarse_lab == 1) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8, false, 1>), BAZ_COARSE_ARGS);
             else if (c->coarse_lab == 2) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8, false, 2>), BAZ_COARSE_ARGS);
+#endif
             else hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8>), BAZ_COARSE_ARGS);
 #undef BAZ_COARSE_ARGS
             HIP_TRY(c, hipGetLastError());
@@ -608,6 +685,31 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
     if ((size_t)batch * G.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;   // reserve_candidates() sized it
     const bool spec = d_spec != nullptr;
     const bool vec4 = (c->res % 4u) == 0 && (reinterpret_cast<uintptr_t>(d_spec) % 16u) == 0;
+    if constexpr (M >= 6 && NMAX <= 4) {
+        // the bulk of the values on the int8 matrix core, exactly accumulated; steps with a value under the accuracy
+        // threshold in this kernel's own fp64 form (scan_i8_kernels.hip.h).  Same launch geometry (nclass = 1 from m = 6 on).
+        // (5 .. 8 antennas without the spectrum port belong to the coarse-gated scan above; BAZ_MUSIC_COARSE=0 is its A/B and
+        // must stay bit-identical to it: the fp64 scan below.  One emitter from 6 antennas on has no gated scan: here.)
+        const bool gated_shape = M <= 8 && NMAX <= 4 && !short_form_applies(c->m, c->n);
+        if (i8_active(c) && dQ == c->dQ && (spec || !gated_shape)) {
+            ScanRefine rf;
+            rf.Gs = c->refine_off ? nullptr : c->dG;
+            rf.TB = c->dTB + c->tb_step_elems;
+            rf.below = c->refine_below;
+            rf.count = c->dRefined + c->stat_parity;
+            rf.A2 = nullptr;
+#define BAZ_I8_LAUNCH(SPEC, VEC4)                                                                                       \
+    hipLaunchKernelGGL((scan_i8_kernel<M, NMAX, SPEC, VEC4>), dim3(G.blocks), dim3(256), 0, c->stream, dQ, c->dIB,      \
+                       c->dFB + c->fb_step_elems, d_spec, cand, batch, c->res, qstride, G.nsplit, c->keep_mask, c->n, rf, \
+                       c->i8, c->dI8Stat, nullptr)
+            if (spec && vec4) BAZ_I8_LAUNCH(true, true);
+            else if (spec) BAZ_I8_LAUNCH(true, false);
+            else BAZ_I8_LAUNCH(false, false);
+#undef BAZ_I8_LAUNCH
+            HIP_TRY(c, hipGetLastError());
+            return BAZ_MUSIC_OK;
+        }
+    }
     ScanRefine rf;
     rf.Gs = c->refine_off ? nullptr : c->dG;
     rf.TB = c->dTB + c->tb_step_elems;
@@ -643,6 +745,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
 #define BAZ_SCAN_LAUNCH(SPEC, VEC4, ABLV, AUXV)                                                                    \
     hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4, ABLV, AUXV>), dim3(G.blocks), dim3(256), 0, c->stream, \
                        BAZ_SCAN_ARGS)
+#ifdef BAZ_MUSIC_LAB
     if constexpr (M == 4 && NMAX == 2) {   // lab switches for the A/Bs in profiles/HISTORY_r01_r02.md 5.3 (BAZ_MUSIC_SCAN_VARIANT)
         if (spec && vec4 && c->lab_variant) {
             switch (c->lab_variant) {
@@ -660,6 +763,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             return BAZ_MUSIC_OK;
         }
     }
+#endif
     if (spec && vec4) BAZ_SCAN_LAUNCH(true, true, 0, (1 | 2 | 16));
     else if (spec) BAZ_SCAN_LAUNCH(true, false, 0, (1 | 2 | 16));
     else BAZ_SCAN_LAUNCH(false, false, 0, (1 | 2 | 16));
@@ -1003,9 +1107,17 @@ int upload_table(baz_music_ctx* c, const float* table_ri)
     if (c->dCS) {    // coarse-gated scan: f16 pieces of the scaled table + the fp64 operand, per 16-bin tile
         std::vector<uint8_t> img;
         if (build_coarse_image(F, c->m, c->res, c->cs_tiles, img, c->cs)) {
-            if (const char* v = getenv("BAZ_MUSIC_COARSE_LAZY")) c->cs.lazy = atoi(v);            // lab
+            if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COARSE_LAZY")) c->cs.lazy = atoi(v);            // lab
             HIP_TRY(c, hipMemcpy(c->dCS, img.data(), img.size(), hipMemcpyHostToDevice));
             c->cs_ok = true;
+        }
+    }
+    c->i8_ok = false;
+    if (c->dIB) {    // int8-matrix-core scan: the table's digit image
+        std::vector<uint8_t> img;
+        if (build_i8_image(F, c->m, c->res, c->fb_steps, img, c->i8)) {
+            HIP_TRY(c, hipMemcpy(c->dIB, img.data(), img.size(), hipMemcpyHostToDevice));
+            c->i8_ok = true;
         }
     }
     if (c->dA2p) {   // ||a||^2 per bin for the scan's short form; huge outside the table, like FB's diagonal there
@@ -1318,7 +1430,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     if (!c) return BAZ_MUSIC_E_NOMEM;
     c->m = m; c->n = n; c->nsamples = nsamples; c->res = resolution; c->K = nsamples / m;
     c->device = dev;
-    if (const char* v = getenv("BAZ_MUSIC_SCAN_VARIANT")) c->lab_variant = atoi(v);
+    if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SCAN_VARIANT")) c->lab_variant = atoi(v);
     if (const char* v = getenv("BAZ_MUSIC_CHUNK_MIB")) c->chunk_bytes = (size_t)std::max(1, std::min(1024, atoi(v))) << 20;
     if (const char* v = getenv("BAZ_MUSIC_PIN_LIMIT_MIB")) c->pin_limit = (uint64_t)std::max(0, atoi(v)) << 20;
     if (const char* v = getenv("BAZ_MUSIC_ZERO_COPY")) c->zero_copy = atoi(v) != 0;
@@ -1353,17 +1465,17 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
                     ok = ok && hipFuncSetAttribute(fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, sz[k]) == hipSuccess;
                 if (!ok) { r = BAZ_MUSIC_E_HIP; break; }
             }
-            if (const char* v = getenv("BAZ_MUSIC_SUB_EVD")) c->sub_evd = atoi(v);                   // lab / tests
+            if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SUB_EVD")) c->sub_evd = atoi(v);                   // lab / tests
             if (hipMalloc((void**)&c->dTA, (size_t)m * resolution * sizeof(float2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMalloc((void**)&c->dA2, (size_t)resolution * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
-            if (const char* v = getenv("BAZ_MUSIC_WIDE_LITERAL")) c->wide_literal_only = atoi(v);   // lab / tests
+            if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_WIDE_LITERAL")) c->wide_literal_only = atoi(v);   // lab / tests
             if (hipMalloc((void**)&c->dRefined, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMemset(c->dRefined, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
             c->wide_cov_mfma = 1;
             c->wide_cov_blocks = 2u * (uint32_t)std::max(1, prop.multiProcessorCount);
-            if (const char* v = getenv("BAZ_MUSIC_WIDE_COV_MFMA")) c->wide_cov_mfma = (c->wide_cov_mfma && atoi(v)) ? 1 : 0;   // lab / tests
+            if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_WIDE_COV_MFMA")) c->wide_cov_mfma = (c->wide_cov_mfma && atoi(v)) ? 1 : 0;   // lab / tests
             c->wide_mfma = (n <= 8) ? 1 : 0;
-            if (const char* v = getenv("BAZ_MUSIC_WIDE_MFMA")) c->wide_mfma = (c->wide_mfma && atoi(v)) ? 1 : 0;   // lab / tests
+            if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_WIDE_MFMA")) c->wide_mfma = (c->wide_mfma && atoi(v)) ? 1 : 0;   // lab / tests
             if (c->wide_mfma) {
                 c->fb_steps = (resolution + 63) / 64;
                 c->keep_mask = (resolution <= (1u << 16)) ? 0xFFFF0000u : 0xFFF00000u;
@@ -1388,14 +1500,14 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
             while (resolution % gcd) gcd >>= 1;
             c->nclass = 64u / gcd;
         }
-        if (const char* v = getenv("BAZ_MUSIC_NO_ROWCLASS")) { if (atoi(v)) c->nclass = 1; }   // lab: round-1 row order
-        if (const char* v = getenv("BAZ_MUSIC_NO_REFINE")) c->refine_off = atoi(v);              // lab
-        if (const char* v = getenv("BAZ_MUSIC_COV_OLD")) c->lab_cov_old = atoi(v);               // lab
-        if (const char* v = getenv("BAZ_MUSIC_SUB_EVD")) c->sub_evd = atoi(v);                   // lab / tests
-        if (const char* v = getenv("BAZ_MUSIC_NSPLIT")) c->force_nsplit = std::max(0, atoi(v));  // tests / lab
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_NO_ROWCLASS")) { if (atoi(v)) c->nclass = 1; }   // lab: round-1 row order
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_NO_REFINE")) c->refine_off = atoi(v);              // lab
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COV_OLD")) c->lab_cov_old = atoi(v);               // lab
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SUB_EVD")) c->sub_evd = atoi(v);                   // lab / tests
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_NSPLIT")) c->force_nsplit = std::max(0, atoi(v));  // tests / lab
         {   // covariance + EVD fused (cov4_evd_kernel) wherever the dwordx4 covariance applies
             int fuse = 1;
-            if (const char* v = getenv("BAZ_MUSIC_FUSE")) fuse = atoi(v);                        // lab: 0 = two kernels
+            if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_FUSE")) fuse = atoi(v);                        // lab: 0 = two kernels
             c->fused_covevd = (fuse > 0 && m == 4 && (c->K % 256u) == 0 && !c->lab_cov_old) ? 1 : 0;
             int per_cu = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cov4_evd_kernel, 256, 0) == hipSuccess && per_cu > 0)
@@ -1404,16 +1516,22 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         }
         if (hipMalloc((void**)&c->dFB, (size_t)(c->fb_steps + 2) * c->fb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         if (hipMalloc((void**)&c->dTB, (size_t)(c->fb_steps + 2) * c->tb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
-        if (const char* v = getenv("BAZ_MUSIC_SIG_SCAN")) c->sig_scan = atoi(v);                  // lab / tests
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SIG_SCAN")) c->sig_scan = atoi(v);                  // lab / tests
         if (const char* v = getenv("BAZ_MUSIC_COARSE")) c->coarse = atoi(v);                      // A/B, tests
-        if (const char* v = getenv("BAZ_MUSIC_COARSE_RG")) c->coarse_rg = atoi(v);                // lab
-        if (const char* v = getenv("BAZ_MUSIC_COARSE_LAB")) c->coarse_lab = atoi(v);              // lab
-        if (const char* v = getenv("BAZ_MUSIC_COARSE_STATS")) c->coarse_stats = atoi(v);          // lab
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COARSE_RG")) c->coarse_rg = atoi(v);                // lab
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COARSE_LAB")) c->coarse_lab = atoi(v);              // lab
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COARSE_STATS")) c->coarse_stats = atoi(v);          // lab
         if (m <= 8) {
             c->cs_tiles = round_up((resolution + 15) / 16, 8);
             if (hipMalloc((void**)&c->dCS, ((size_t)(c->cs_tiles + 1) * cs_c_units((int)m) + (size_t)c->cs_tiles * CS_X_UNITS * cs_groups((int)m)) * 16) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMalloc((void**)&c->dMargin, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMemset(c->dMargin, 0, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
+        }
+        if (const char* v = getenv("BAZ_MUSIC_EXACT")) c->i8_on = atoi(v) ? 0 : 1;                // A/B: 1 = the fp64 scan everywhere
+        if (m >= 6 && n <= 4 && i8_image_bytes(m, c->fb_steps) <= I8_IMAGE_LIMIT) {
+            if (hipMalloc((void**)&c->dIB, i8_image_bytes(m, c->fb_steps)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+            if (hipMalloc((void**)&c->dI8Stat, 3 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+            if (hipMemset(c->dI8Stat, 0, 3 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         }
         if (short_form_applies(m, n) && hipMalloc((void**)&c->dA2p, (size_t)(c->fb_steps + 2) * 64 * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         {
@@ -1421,7 +1539,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
             // 6 (the occupancy limit) / 8 per CU, the fewest concurrent input streams read fastest -- 0.370 vs 0.396 ms per
             // 262,144 items inside the pipeline (profiles/r02_cov_grid.txt); more waves only queue more requests.
             c->cov4_resident_blocks = (uint32_t)std::max(1, prop.multiProcessorCount);
-            if (const char* v = getenv("BAZ_MUSIC_COV_BLOCKS_PER_CU"))    // lab: grid of the covariance kernel
+            if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COV_BLOCKS_PER_CU"))    // lab: grid of the covariance kernel
                 if (atoi(v) > 0) c->cov4_resident_blocks = (uint32_t)atoi(v) * (uint32_t)std::max(1, prop.multiProcessorCount);
         }
         if (hipMalloc((void**)&c->dRefined, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
@@ -1447,7 +1565,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     if (c->fused_covevd) c->stage_name[BAZ_MUSIC_STAGE_COV] = "bazmusic::cov4_evd_kernel";
     snprintf(buf, sizeof(buf), m <= 4 ? "bazmusic::evd_proj_kernel<%u>" : "bazmusic::evd_proj_lds_kernel<%u>", m);
     c->stage_name[BAZ_MUSIC_STAGE_EVD] = buf;
-    snprintf(buf, sizeof(buf), "bazmusic::scan_mfma_kernel<%u,", m);
+    snprintf(buf, sizeof(buf), i8_active(c) ? "bazmusic::scan_i8_kernel<%u," : "bazmusic::scan_mfma_kernel<%u,", m);
     c->stage_name[BAZ_MUSIC_STAGE_SCAN] = buf;
     snprintf(buf, sizeof(buf), "bazmusic::topn_merge_kernel<%u>", topn_list_len(n));
     c->stage_name[BAZ_MUSIC_STAGE_MERGE] = buf;
@@ -1473,6 +1591,8 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->dA2p) (void)hipFree(c->dA2p);
         if (c->dTB) (void)hipFree(c->dTB);
         if (c->dCS) (void)hipFree(c->dCS);
+        if (c->dIB) (void)hipFree(c->dIB);
+        if (c->dI8Stat) (void)hipFree(c->dI8Stat);
         if (c->dMargin) (void)hipFree(c->dMargin);
         if (c->dRefined) (void)hipFree(c->dRefined);
         if (c->dPeakSpec) (void)hipFree(c->dPeakSpec);
@@ -1837,7 +1957,7 @@ int baz_music_debug_coarse_margin(baz_music_ctx* c, const void* d_in, uint32_t b
     const uint32_t per_group = big ? 64u * (uint32_t)coarse_rg_wide((int)c->m, 2) : 256u;
     const uint32_t groups = (batch + per_group - 1) / per_group, nph = c->cs_tiles / (big ? 4 : 8);
     float* d_dump = nullptr;                     // lab (BAZ_MUSIC_DEBUG_DUMP=<file>): every ratio, [item][bin] float32
-    const char* dump_path = getenv("BAZ_MUSIC_DEBUG_DUMP");
+    const char* dump_path = BAZ_LAB_ENV("BAZ_MUSIC_DEBUG_DUMP");
     if (dump_path && hipMalloc((void**)&d_dump, (size_t)batch * c->res * sizeof(float)) != hipSuccess) d_dump = nullptr;
     if (d_dump) (void)hipMemsetAsync(d_dump, 0, (size_t)batch * c->res * sizeof(float), c->stream);
 #define BAZ_VAL(MV, NV, RGV, TPV)                                                                                           \
@@ -1867,7 +1987,7 @@ int baz_music_debug_coarse_margin(baz_music_ctx* c, const void* d_in, uint32_t b
     }
     const unsigned int bits = (unsigned int)(packed >> 32);
     std::memcpy(worst, &bits, sizeof(float));
-    if (getenv("BAZ_MUSIC_DEBUG_MARGIN"))   // lab: where the worst value sits
+    if (BAZ_LAB_ENV("BAZ_MUSIC_DEBUG_MARGIN"))   // lab: where the worst value sits
         fprintf(stderr, "[baz_music] coarse margin %.4g at bin %u, item %% 4096 = %u\n", *worst, (unsigned)(packed & 0xFFFFFu),
                 (unsigned)((packed >> 20) & 0xFFFu));
     return BAZ_MUSIC_OK;
@@ -1884,6 +2004,89 @@ int64_t baz_music_debug_coarse_fired(baz_music_ctx* c)
     if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&v, c->dMargin, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemset(c->dMargin, 0, sizeof(v)) != hipSuccess) return -1;
     return (int64_t)v;
+}
+
+// Validation of the int8 scan's a-priori bound on this hardware (scan_i8_kernels.hip.h, VAL): covariance + EVD of the batch,
+// then EVERY (item, bin) in both forms; *worst = max |d_int - d| / E over the items that take the integer form.
+int baz_music_debug_i8_margin(baz_music_ctx* c, const void* d_in, uint32_t batch, float* worst)
+{
+    if (!c || !d_in || !worst || batch == 0) return BAZ_MUSIC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    DeviceGuard guard(c->device);
+    if (c->wide || !c->dIB || !c->i8_ok || c->m < 6 || c->m > 16 || c->n > 4) return BAZ_MUSIC_E_UNSUPPORTED;
+    int r = ensure_workspace(c, batch);
+    if (r) return r;
+    r = reserve_candidates(c, batch);
+    if (r) return r;
+    const uint32_t qstride = baz_music_q_stride(batch);
+    const int on = c->i8_on;
+    c->i8_on = 1;                       // (the EVD must write the projector coefficients: short_form_in_use())
+    r = launch_cov(c, static_cast<const float*>(d_in), batch, c->dR);
+    if (!r) r = launch_evd(c, c->dR, batch, c->dQ, qstride, c->dG);
+    c->i8_on = on;
+    if (r) return r;
+    HIP_TRY(c, hipMemsetAsync(c->dI8Stat + 2, 0, sizeof(unsigned long long), c->stream));
+    ScanRefine rf;
+    rf.Gs = nullptr; rf.TB = c->dTB + c->tb_step_elems; rf.below = 0.0; rf.count = nullptr; rf.A2 = nullptr;
+    const uint32_t blocks = (batch + 63) / 64;
+#define BAZ_VAL8(MV)                                                                                                      \
+    case MV: hipLaunchKernelGGL((scan_i8_kernel<MV, 2, false, false, true>), dim3(blocks), dim3(256), 0, c->stream, c->dQ, \
+                                c->dIB, c->dFB + c->fb_step_elems, nullptr, c->dCand, batch, c->res, qstride, 1u, c->keep_mask, \
+                                c->n, rf, c->i8, nullptr, c->dI8Stat + 2); break;
+    switch (c->m) {
+        BAZ_VAL8(6) BAZ_VAL8(7) BAZ_VAL8(8) BAZ_VAL8(9) BAZ_VAL8(10) BAZ_VAL8(11) BAZ_VAL8(12) BAZ_VAL8(13) BAZ_VAL8(14)
+        BAZ_VAL8(15) BAZ_VAL8(16)
+        default: return BAZ_MUSIC_E_UNSUPPORTED;
+    }
+#undef BAZ_VAL8
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long packed = 0;
+    HIP_TRY(c, hipMemcpyAsync(&packed, c->dI8Stat + 2, sizeof(packed), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const unsigned int bits = (unsigned int)packed;
+    std::memcpy(worst, &bits, sizeof(float));
+    return BAZ_MUSIC_OK;
+}
+
+// Statistic of the int8 scan since the last read (resets): wave steps (16 items x 64 bins) recomputed in the fp64 form, and
+// wave steps walked.  BAZ_MUSIC_E_UNSUPPORTED where that scan does not exist for the configuration.
+int baz_music_debug_i8_stats(baz_music_ctx* c, uint64_t* fp64_steps, uint64_t* steps)
+{
+    if (!c) return BAZ_MUSIC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    DeviceGuard guard(c->device);
+    if (!c->dI8Stat) return BAZ_MUSIC_E_UNSUPPORTED;
+    unsigned long long v[2] = {0, 0};
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(v, c->dI8Stat, sizeof(v), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemset(c->dI8Stat, 0, sizeof(v)));
+    if (fp64_steps) *fp64_steps = v[0];
+    if (steps) *steps = v[1];
+    return BAZ_MUSIC_OK;
+}
+
+// 1 when this context's scan runs on the int8 matrix core (6 <= m <= 16, n <= 4, a table whose digit image exists, not
+// BAZ_MUSIC_EXACT=1), else 0.
+int baz_music_uses_i8_scan(const baz_music_ctx* c) { return (c && !c->wide && i8_active(c)) ? 1 : 0; }
+
+// HOST-ONLY tap (no device needed): the digit image and parameters build_i8_image() produces for a table.  Returns the
+// image's size in bytes (also when `out` is NULL or too small: nothing is written then), 0 when the table has no image.
+// params[0 .. NS-1] = level weights, [NS] = 2^(8 NS - 2), [NS + 1] = T, [NS + 2] = E, [NS + 3] = NS.
+size_t baz_music_debug_i8_image(uint32_t m, uint32_t resolution, const float* table_ri, uint8_t* out, size_t out_bytes,
+                                double* params)
+{
+    if (!table_ri || m < 6 || m > BAZ_MUSIC_FAST_M || resolution == 0) return 0;
+    std::vector<double> F;
+    build_F(table_ri, m, resolution, F);
+    std::vector<uint8_t> img;
+    I8Params ip = {};
+    if (!build_i8_image(F, m, resolution, (resolution + 63) / 64, img, ip)) return 0;
+    if (params) {
+        for (int l = 0; l < I8_NS; ++l) params[l] = ip.wt[l];
+        params[I8_NS] = ip.sq; params[I8_NS + 1] = ip.t_acc; params[I8_NS + 2] = ip.e_bound; params[I8_NS + 3] = (double)I8_NS;
+    }
+    if (out && out_bytes >= img.size()) std::memcpy(out, img.data(), img.size());
+    return img.size();
 }
 
 int baz_music_debug_evd(baz_music_ctx* c, const void* d_R, uint32_t batch, void* d_Q)

@@ -20,7 +20,7 @@ def pytest_sessionstart(session):
     """A fresh clone has no built artefacts (the .so files are git-ignored): build what is MISSING once, so that the
     suite does not depend on __graft_entry__.build() having run first.  Never rebuilds what is there."""
     from gr_baz_amd import build as native
-    missing = [p for p in (native.HIP_LIB, native.AGC_LIB, native.RESAMP_LIB, native.HOST_LIB, native.pybind_module_path())
+    missing = [p for p in (native.HIP_LIB, native.HIP_LAB_LIB, native.AGC_LIB, native.RESAMP_LIB, native.HOST_LIB, native.pybind_module_path())
                if not os.path.exists(p)]
     if missing:
         native.build_all(verbose=False)

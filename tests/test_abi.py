@@ -151,6 +151,40 @@ def test_plain_c_consumer_finds_the_emitter(tmp_path, gpu_device):
         assert abs(float(f[3]) - 137.0) <= 1.0 and f[-1] == "1"
 
 
+# the tuning knobs INTEGRATION.md 5 documents; none of them can make a result wrong
+RELEASE_KNOBS = {
+    "BAZ_MUSIC_EXACT",           # 1: every value on the fp64 matrix core (no int8 form) -- A/B
+    "BAZ_MUSIC_COARSE",          # 0: the full fp64 scan also without the spectrum port -- A/B, bit-identical outputs
+    "BAZ_MUSIC_CHUNK_MIB", "BAZ_MUSIC_PIN_LIMIT_MIB", "BAZ_MUSIC_ZERO_COPY", "BAZ_MUSIC_SINGLE_MIB",     # host-fed path
+}
+
+
+def _env_names(path):
+    data = open(path, "rb").read()
+    return set(x.decode() for x in re.findall(rb"BAZ_MUSIC_[A-Z0-9_]+", data))
+
+
+def test_release_library_reads_only_the_documented_knobs():
+    """A drop-in block must not change its results because of a stray environment variable (the reference has no hidden
+    modes, lib/baz_music_doa.cc:35-53).  Ablations, older kernels, geometry overrides and dumps are compiled only into
+    libbaz_music_hip_lab.so (-DBAZ_MUSIC_LAB); the release library contains the names of the documented knobs and no other
+    BAZ_MUSIC_* string."""
+    from gr_baz_amd import build as native
+    rel = _env_names(native.HIP_LIB)
+    assert rel == RELEASE_KNOBS, sorted(rel ^ RELEASE_KNOBS)
+    lab = _env_names(native.HIP_LAB_LIB)
+    assert RELEASE_KNOBS < lab and {"BAZ_MUSIC_SCAN_VARIANT", "BAZ_MUSIC_NO_REFINE", "BAZ_MUSIC_COARSE_LAB", "BAZ_MUSIC_NSPLIT"} <= lab
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for k in RELEASE_KNOBS:
+        assert k in doc, "%s is not documented in INTEGRATION.md" % k
+
+
+def test_lab_library_exports_the_same_abi():
+    L = capi.lib(lab=True)
+    for sym in capi.SYMBOLS:
+        assert hasattr(L, sym), sym
+
+
 def test_collecting_the_suite_does_not_load_the_native_libraries():
     """pytest imports every test module before the first test runs.  A module that imports gr_baz_amd.baz (or calls
     capi.lib()) at import time loads /opt/rocm's HIP runtime BEFORE torch brings its own copy of the same soname, and the

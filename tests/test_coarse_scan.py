@@ -45,12 +45,13 @@ def _scene(m, n, nsamples, res, batch, snr_db, seed, incoherent):
 
 
 def _both(monkeypatch, m, n, nsamples, res, table, items, gpu_device, env=None):
+    """env: lab switches (geometry overrides) -- those exist only in the lab build of the library (capi.Context(lab=True))."""
     out = {}
     for coarse in ("1", "0"):
         monkeypatch.setenv("BAZ_MUSIC_COARSE", coarse)
         for k, v in (env or {}).items():
             monkeypatch.setenv(k, v)
-        with _capi().Context(m, n, nsamples, res, table) as ctx:
+        with _capi().Context(m, n, nsamples, res, table, lab=bool(env)) as ctx:
             out[coarse] = _run_nospec(ctx, items, gpu_device) + (ctx.refined_values(),)
     return out["1"], out["0"]
 

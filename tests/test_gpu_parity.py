@@ -194,7 +194,7 @@ def test_wide_arrays_subspace_iteration_and_hand_back(m, n, K, res, gpu_device, 
     outs = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("BAZ_MUSIC_SUB_EVD", mode)
-        with _capi().Context(m, n, N, res, table) as ctx:
+        with _capi().Context(m, n, N, res, table, lab=True) as ctx:
             outs[mode] = (device_run(ctx, items, gpu_device), device_run(ctx, items[::-1].copy(), gpu_device),
                           device_run(ctx, items[4:5], gpu_device))
     full, rev, one = outs["1"]
@@ -223,7 +223,7 @@ def test_wide_arrays_short_form_and_literal_form_agree(m, n, K, res, snr, gpu_de
     outs = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("BAZ_MUSIC_WIDE_LITERAL", mode)
-        with _capi().Context(m, n, N, res, table) as ctx:
+        with _capi().Context(m, n, N, res, table, lab=True) as ctx:
             outs[mode] = device_run(ctx, items, gpu_device)
     s_short, s_lit = outs["0"][2].astype(np.float64), outs["1"][2].astype(np.float64)
     assert np.all(np.abs(s_short - s_lit) <= 3e-6 * s_lit)
@@ -268,7 +268,7 @@ def test_wide_arrays_matrix_core_scan(m, n, K, res, batch, snr, gpu_device, monk
     outs = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("BAZ_MUSIC_WIDE_MFMA", mode)
-        with _capi().Context(m, n, N, res, table) as ctx:
+        with _capi().Context(m, n, N, res, table, lab=True) as ctx:
             outs[mode] = device_run(ctx, items, gpu_device)
             if mode == "1":
                 assert ctx.stage_name(2).endswith("scan_wide_mfma_kernel")
@@ -477,7 +477,7 @@ def test_fused_covariance_evd_kernel_equals_the_two_kernel_form(gpu_device, monk
     outs = []
     for fuse in ("1", "0"):
         monkeypatch.setenv("BAZ_MUSIC_FUSE", fuse)
-        with _capi().Context(g["m"], g["n"], g["nsamples"], g["res"], g["table"]) as ctx:
+        with _capi().Context(g["m"], g["n"], g["nsamples"], g["res"], g["table"], lab=True) as ctx:
             assert ("cov4_evd_kernel" in ctx.stage_name(0)) == (fuse == "1")
             outs.append(device_run(ctx, items, gpu_device))
     for x, y in zip(*outs):
@@ -522,7 +522,7 @@ def test_signal_subspace_iteration_and_its_hand_back(m, n, K, res, gpu_device, m
     res_by_mode = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("BAZ_MUSIC_SUB_EVD", mode)
-        with _capi().Context(m, n, N, res, table) as ctx:
+        with _capi().Context(m, n, N, res, table, lab=True) as ctx:
             out = device_run(ctx, items, gpu_device)
             outp = device_run(ctx, items[perm], gpu_device)
             one = [device_run(ctx, items[i:i + 1], gpu_device) for i in (0, 13, B - 1)]
@@ -556,9 +556,10 @@ def test_short_form_scan_equals_the_projector_scan(m, n, K, res, batch, snr, gpu
     table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
     items = mo.synth_items(batch, m, N, arr, mo.FREQUENCY, mo.SPACING, angles_deg=(40.3, 121.7)[:n], snr_db=snr, seed=17 * m + K)
     outs = {}
+    monkeypatch.setenv("BAZ_MUSIC_EXACT", "1")      # the fp64 scan (by default these shapes run the int8 scan, which evaluates the projector form)
     for mode in ("1", "0"):
         monkeypatch.setenv("BAZ_MUSIC_SIG_SCAN", mode)
-        with _capi().Context(m, n, N, res, table) as ctx:
+        with _capi().Context(m, n, N, res, table, lab=True) as ctx:
             outs[mode] = (device_run(ctx, items, gpu_device), device_run(ctx, items, gpu_device, want_spec=False))
     (a1, l1, s1), (a1n, l1n, _) = outs["1"]
     (a0, l0, s0), _ = outs["0"]
@@ -581,7 +582,7 @@ def test_outputs_do_not_depend_on_the_range_split_of_the_scan(name, gpu_device, 
     outs = []
     for split in ("1", "3", "0"):                     # 0 = by batch size
         monkeypatch.setenv("BAZ_MUSIC_NSPLIT", split)
-        with _capi().Context(g["m"], g["n"], g["nsamples"], g["res"], g["table"]) as ctx:
+        with _capi().Context(g["m"], g["n"], g["nsamples"], g["res"], g["table"], lab=True) as ctx:
             a, l, s = device_run(ctx, g["items"], gpu_device)
             a2, l2, _ = device_run(ctx, g["items"], gpu_device, want_spec=False)
             a3, _, _ = device_run(ctx, g["items"], gpu_device, want_lvl=False, want_spec=False)

@@ -1,0 +1,311 @@
+"""The int8-matrix-core scan (gr_baz_amd/csrc/scan_i8_kernels.hip.h): what evaluates 1 / ||G^H a||^2
+(/root/reference/lib/baz_music_doa.cc:101-121) from 6 to 16 antennas.  Both operands of d = sum_e q_e F_e are cut into five
+balanced base-256 digits; digit products are accumulated exactly in int32 on the matrix core; a 16-item x 64-bin step keeps
+the integer value only where the a-priori bound E makes it accurate to 7.5e-7, else it is recomputed in the fp64 form.
+
+CPU part (no device): the digit image the library builds for a table equals the numpy restatement of the scheme digit for
+digit, the integer form evaluated FROM THAT IMAGE stays inside E, and the parameters are the documented formulas.
+GPU part (through the C-ABI): against the fp64 scan of the same build (BAZ_MUSIC_EXACT=1), against the CPU oracle, the bound
+on the hardware over every (item, bin) (baz_music_debug_i8_margin), the fp64-step statistic, poisoned items, arbitrary
+tables, ragged shapes."""
+import numpy as np
+import pytest
+
+from helpers import assert_doa_match, assert_spectrum_close
+from oracle import music_oracle as mo
+
+NS = 5
+EPS = 7.5e-7
+
+
+def _capi():
+    from gr_baz_amd import capi
+    return capi
+
+
+# ---- numpy restatement of the scheme (the same arithmetic as tests/lab/i8_split_study.py) -------------------------------
+def q_image(Q):
+    """evd_finish(): q[i*m+i] = Q_ii, q[i*m+j] = 2 Re Q_ij, q[j*m+i] = -2 Im Q_ij (i < j)."""
+    m = Q.shape[-1]
+    q = np.zeros(Q.shape[:-2] + (m * m,))
+    for i in range(m):
+        q[..., i * m + i] = Q[..., i, i].real
+        for j in range(i + 1, m):
+            q[..., i * m + j] = 2.0 * Q[..., i, j].real
+            q[..., j * m + i] = -2.0 * Q[..., i, j].imag
+    return q
+
+
+def f_image(table):
+    """build_F(): F[i*m+i] = |a_i|^2, F[i*m+j] = Re(conj(a_i) a_j), F[j*m+i] = Im(conj(a_i) a_j) (i < j)."""
+    A = table.astype(np.complex128)
+    res, m = A.shape
+    F = np.zeros((res, m * m))
+    for i in range(m):
+        F[:, i * m + i] = np.abs(A[:, i]) ** 2
+        for j in range(i + 1, m):
+            c = np.conj(A[:, i]) * A[:, j]
+            F[:, i * m + j] = c.real
+            F[:, j * m + i] = c.imag
+    return F
+
+
+def digits(v):
+    v = np.asarray(v).astype(np.int64)
+    out = []
+    for _ in range(NS - 1):
+        h = (v + 128) >> 8
+        out.append(v - (h << 8))
+        v = h
+    out.append(v)
+    return out[::-1]          # most significant first
+
+
+def fscale_of(fmax):
+    return 2.0 ** np.frexp(fmax / 1.0009765625)[1]
+
+
+def image_digits(img, m, res):
+    """The library's image -> Fd[s][bin][e] (int64), through the B-operand layout of v_mfma_i32_16x16x64_i8 documented in
+    scan_i8_kernels.hip.h: [step][tile t][block kb][digit s][lane = 16 g + c][byte j] = bin 64 st + 4 c + t, e = 64 kb + 16 g + j."""
+    mm, nkb, steps = m * m, (m * m + 63) // 64, (res + 63) // 64
+    a = img.view(np.int8).reshape(steps, 4, nkb, NS, 4, 16, 16)             # st, t, kb, s, g, c, j
+    full = a.transpose(3, 0, 5, 1, 2, 4, 6).reshape(NS, steps * 64, nkb * 64)   # s, (st, c, t) -> bin, (kb, g, j) -> e
+    assert not full[:, res:, :].any() and not full[:, :, mm:].any(), "padding of the image is not zero"
+    return full[:, :res, :mm].astype(np.int64)
+
+
+@pytest.mark.parametrize("m,res", [(6, 100), (8, 360), (8, 1001), (11, 130), (12, 64), (16, 257)])
+def test_digit_image_equals_the_numpy_restatement(m, res):
+    table = mo.steering_table_c64(mo.array_geometry(m), res, mo.FREQUENCY, mo.SPACING)
+    img, par = _capi().debug_i8_image(m, res, table)
+    assert img is not None and par["ns"] == NS
+    F = f_image(table)
+    fs = fscale_of(np.abs(F).max())
+    assert fs == 1.0                                     # unit-modulus table rounded to float32: max|F| = 1 + 8e-8
+    sq = 2.0 ** (8 * NS - 2)
+    Fd = image_digits(img, m, res)
+    ref = digits(np.rint(F * (sq / fs)))
+    for s in range(NS):
+        assert np.array_equal(Fd[s], ref[s]), "digit %d of the image differs" % s
+    assert np.abs(Fd[0]).max() <= 65 and all(np.abs(Fd[s]).max() <= 128 for s in range(1, NS))
+    # the parameters are the documented formulas
+    E = m * m * fs * NS * 1.01 * 2.0 ** (2 - 8 * NS)
+    unit = fs * 2.0 ** (-8 * NS - 4)
+    assert par["sq"] == sq and par["e_bound"] == E and par["t_acc"] == E * (1.0 + 1.0 / EPS)
+    assert np.array_equal(par["wt"], [unit * 256.0 ** (NS - 1 - l) for l in range(NS)])
+
+
+@pytest.mark.parametrize("scale", [1.0, 3e-12, 7e11])
+@pytest.mark.parametrize("m", [8, 13])
+def test_integer_form_from_the_image_stays_inside_the_bound(m, scale):
+    """The integer form exactly as the kernel evaluates it -- level sums of digit products, levels >= NS dropped, Horner with the
+    library's weights -- on the library's own image, against the fp64 (long double) value: |d_int - d| <= E."""
+    res, n, K, items = 200, 2, 64, 48
+    arr = mo.array_geometry(m)
+    table = (mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING) * np.float32(scale)).astype(np.complex64)
+    img, par = _capi().debug_i8_image(m, res, table)
+    Fd = image_digits(img, m, res)
+    x = mo.synth_items(items, m, m * K, arr, mo.FREQUENCY, mo.SPACING, snr_db=25.0, seed=31 + m)
+    xs = x.astype(np.complex128).reshape(items, K, m).transpose(0, 2, 1)
+    w, V = np.linalg.eigh(xs @ xs.conj().transpose(0, 2, 1) / K)
+    G = V[:, :, :m - n]
+    q = q_image(G @ G.conj().transpose(0, 2, 1))
+    assert np.abs(q).max() <= 1.0 + 1e-12               # a projector's coefficients (what the kernel's sanity check admits)
+    qd = digits(np.rint(q * par["sq"]))
+    d_int = np.zeros((items, res))
+    for l in range(NS):
+        A = sum(qd[s] @ Fd[l - s].T for s in range(l + 1))
+        assert np.abs(A).max() < 2 ** 31 // 256
+        d_int += A.astype(np.float64) * par["wt"][l]     # (every term an integer times a power of two: exact in fp64)
+    F = f_image(table)
+    d = (q.astype(np.longdouble) @ F.T.astype(np.longdouble)).astype(np.float64)
+    err = np.abs(d_int - d).max()
+    assert err <= par["e_bound"], (err, par["e_bound"])
+    keep = d_int > par["t_acc"]
+    assert keep.mean() > 0.9 and (np.abs(d_int - d)[keep] / d[keep]).max() <= EPS
+
+
+def test_tables_without_an_image():
+    z = np.zeros((90, 8), np.complex64)
+    assert _capi().debug_i8_image(8, 90, z)[0] is None                          # all zero: no scale
+    t = mo.steering_table_c64(mo.array_geometry(8), 90, mo.FREQUENCY, mo.SPACING).copy()
+    t[5, 3] = np.nan
+    assert _capi().debug_i8_image(8, 90, t)[0] is None                          # not finite
+    assert _capi().debug_i8_image(4, 90, t[:, :4].copy())[0] is None            # m < 6: row classes, fp64 scan
+
+
+# ---- on the GPU ----------------------------------------------------------------------------------------------------------
+def _run(ctx, items, gpu_device, want_spec=True):
+    import torch
+    B = items.shape[0]
+    x = torch.from_numpy(np.ascontiguousarray(items).view(np.float32)).to(gpu_device)
+    ang = torch.full((B, ctx.n), -1.0, dtype=torch.float32, device=gpu_device)
+    lvl = torch.full((B, ctx.n), -1.0, dtype=torch.float32, device=gpu_device)
+    spec = torch.full((B, ctx.res), -1.0, dtype=torch.float32, device=gpu_device) if want_spec else None
+    ctx.process_device(x.data_ptr(), B, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr() if want_spec else None,
+                       stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return ang.cpu().numpy(), lvl.cpu().numpy(), (spec.cpu().numpy() if want_spec else None)
+
+
+def _scene(m, n, nsamples, res, batch, snr_db, seed, incoherent=False):
+    arr = mo.array_geometry(m)
+    table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
+    rng = np.random.default_rng(seed)
+    if not incoherent:
+        return table, mo.synth_items(batch, m, nsamples, arr, mo.FREQUENCY, mo.SPACING, angles_deg=tuple(rng.uniform(0.0, 360.0, size=n)),
+                                     snr_db=snr_db, seed=seed)
+    return table, np.concatenate([mo.synth_items(1, m, nsamples, arr, mo.FREQUENCY, mo.SPACING, angles_deg=tuple(rng.uniform(0.0, 360.0, size=n)),
+                                                 snr_db=snr_db, seed=seed + 7 * i) for i in range(batch)], axis=0)
+
+
+def _both(monkeypatch, m, n, nsamples, res, table, items, gpu_device, want_spec=True):
+    """(int8 scan, fp64 scan of the same build) + the int8 context's statistics."""
+    out = {}
+    for exact in ("0", "1"):
+        monkeypatch.setenv("BAZ_MUSIC_EXACT", exact)
+        monkeypatch.setenv("BAZ_MUSIC_COARSE", "0")           # (without port 2 and m <= 8 the gated scan would run instead)
+        with _capi().Context(m, n, nsamples, res, table) as ctx:
+            assert ctx.uses_i8_scan() == (exact == "0")
+            r = _run(ctx, items, gpu_device, want_spec)
+            out[exact] = r + ((ctx.debug_i8_stats() if exact == "0" else None), ctx.refined_values())
+    return out["0"], out["1"]
+
+
+def _assert_same_choice(a_i, a_x, spec_x, res):
+    """DoA bins of the two scans: identical, or the fp64 scan's own strengths at the two bins agree to 2 eps."""
+    if np.array_equal(a_i, a_x):
+        return
+    for b, i in zip(*np.nonzero(a_i != a_x)):
+        ba, bx = int(round(float(a_i[b, i]) * res / 360.0)) % res, int(round(float(a_x[b, i]) * res / 360.0)) % res
+        sa, sx = float(spec_x[b, ba]), float(spec_x[b, bx])
+        assert abs(sa - sx) <= 2.0e-6 * max(sa, sx), "item %d slot %d: bins %d / %d are not a tie (%.9g vs %.9g)" % (b, i, ba, bx, sa, sx)
+
+
+SHAPES = [(8, 2, 1024, 3600, 150), (8, 3, 512, 1000, 70), (7, 2, 280, 721, 130), (6, 2, 384, 500, 200), (6, 1, 384, 64, 65),
+          (8, 1, 512, 1002, 33), (9, 2, 576, 360, 100), (11, 4, 704, 250, 50), (12, 2, 768, 720, 64), (13, 3, 832, 129, 40),
+          (16, 2, 4096, 3600, 96), (16, 4, 1024, 500, 20), (15, 1, 960, 333, 30), (10, 3, 1000, 1001, 17)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("incoherent", [False, True])
+@pytest.mark.parametrize("snr", [0.0, 20.0, 40.0, 80.0, 120.0])
+@pytest.mark.parametrize("m,n,nsamples,res,batch", SHAPES)
+def test_int8_scan_against_the_fp64_scan_and_the_oracle(m, n, nsamples, res, batch, snr, incoherent, gpu_device, monkeypatch):
+    table, items = _scene(m, n, nsamples, res, batch, snr, 4000 + int(snr) + 17 * m + n, incoherent)
+    (a_i, l_i, s_i, st, r_i), (a_x, l_x, s_x, _, r_x) = _both(monkeypatch, m, n, nsamples, res, table, items, gpu_device)
+    assert (s_i >= 0).all() and (a_i >= 0).all() and (l_i >= 0).all()                     # every value written
+    # the integer form promises 7.5e-7 on d; both scans then convert and take the reciprocal the same way
+    worst = assert_spectrum_close(s_i, s_x, rtol=1.0e-6, what="int8 vs fp64 scan")
+    _assert_same_choice(a_i, a_x, s_x, res)
+    bins = np.round(a_i.astype(np.float64) * res / 360.0).astype(np.int64) % res
+    assert np.array_equal(l_i.view(np.uint32), np.take_along_axis(s_i, bins, axis=1).view(np.uint32)), "lvl != spectrum[bin] (.cc:153)"
+    fp64_steps, steps = st
+    assert steps == -(-batch // 64) * 4 * ((res + 63) // 64) or steps >= ((res + 63) // 64) * (-(-batch // 16)), (steps, batch, res)
+    if snr >= 80.0:
+        assert r_i == r_x                                  # the literal form recomputes the same near-null values in both
+    if snr <= 40.0:                                        # and the CPU oracle (above, the oracle's own d loses digits: test_gpu_parity)
+        ao, lo, so, s64 = mo.music_doa_work_batch(items, table, m, n)
+        w2 = assert_spectrum_close(s_i, so, what="int8 scan vs oracle")
+        assert w2 <= 1.0e-6, w2
+        assert_doa_match(a_i, l_i, ao, lo, res, s64)
+    print("m=%d n=%d res=%d snr=%g %s: worst vs fp64 scan %.3g, fp64 steps %d of %d" %
+          (m, n, res, snr, "incoherent" if incoherent else "coherent", worst, fp64_steps, steps))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,nsamples,res,batch", [(8, 2, 4096, 36000, 64), (16, 2, 4096, 3600, 128)])
+def test_config_shapes_mostly_take_the_integer_form(m, n, nsamples, res, batch, gpu_device, monkeypatch):
+    """BASELINE configs[2] (m8, 36,000 bins) and configs[4]'s MUSIC stage (m16): a 20-dB stream keeps > 90 % of its steps on the
+    int8 matrix core, and the values agree with the fp64 scan to 1e-6."""
+    arr = mo.array_geometry(m)
+    table = mo.steering_table_c64(arr, res, mo.FREQUENCY, mo.SPACING)
+    items = mo.synth_items(batch, m, nsamples, arr, mo.FREQUENCY, mo.SPACING, snr_db=20.0, seed=1003)
+    (a_i, l_i, s_i, (fp64_steps, steps), _), (a_x, l_x, s_x, _, _) = _both(monkeypatch, m, n, nsamples, res, table, items, gpu_device)
+    assert_spectrum_close(s_i, s_x, rtol=1.0e-6)
+    _assert_same_choice(a_i, a_x, s_x, res)
+    assert steps > 0 and fp64_steps < 0.1 * steps, (fp64_steps, steps)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,K", [(6, 2, 64), (7, 3, 40), (8, 2, 128), (9, 1, 64), (10, 2, 100), (11, 2, 64), (12, 4, 64), (13, 2, 64), (14, 2, 64),
+                                   (15, 3, 64), (16, 2, 256)])
+def test_error_bound_holds_on_the_hardware(m, n, K, gpu_device):
+    """Both forms on EVERY (item, bin): the worst |d_int - d| / E must stay below 1 (E is a worst-case bound: typical digits
+    give ~0.1), coherent and incoherent scenes, 0 ... 60 dB."""
+    import torch
+    res = 720
+    for snr, inc in ((20.0, False), (0.0, True), (60.0, True)):
+        table, items = _scene(m, n, m * K, res, 200, snr, 600 + m + int(snr), inc)
+        x = torch.from_numpy(np.ascontiguousarray(items).view(np.float32)).to(gpu_device)
+        with _capi().Context(m, n, m * K, res, table) as ctx:
+            w = ctx.debug_i8_margin(x.data_ptr(), items.shape[0])
+        assert 0.0 < w < 0.5, "m=%d snr=%g: worst error / bound = %.3g" % (m, snr, w)
+        print("m=%d n=%d snr=%g %s: worst |d_int - d| / E = %.3g" % (m, n, snr, "incoherent" if inc else "coherent", w))
+
+
+@pytest.mark.gpu
+def test_poisoned_items_and_ragged_batches(gpu_device, monkeypatch):
+    """Items whose covariance is zero / NaN / inf / huge / tiny sit between ordinary ones: their coefficients are not a
+    projector's, so every step of their row group takes the fp64 form and the outputs are the fp64 scan's bit for bit."""
+    m, n, N, res = 8, 2, 512, 777
+    table, items = _scene(m, n, N, res, 211, 20.0, 5, True)
+    items = items.copy()
+    items[3] = 0
+    items[17, 5] = np.nan
+    items[64, 100] = np.inf
+    items[65] *= np.float32(1e18)
+    items[130] *= np.float32(1e-18)
+    (a_i, l_i, s_i, _, _), (a_x, l_x, s_x, _, _) = _both(monkeypatch, m, n, N, res, table, items, gpu_device)
+    for b in (3, 17, 64):
+        assert np.array_equal(s_i[b].view(np.uint32), s_x[b].view(np.uint32)) and np.array_equal(a_i[b], a_x[b])
+        assert np.array_equal(l_i[b].view(np.uint32), l_x[b].view(np.uint32))
+    assert (a_i[17] == 0).all() and (l_i[17] == 0).all()
+    ok = np.ones(211, bool)
+    ok[[3, 17, 64]] = False
+    assert_spectrum_close(s_i[ok], s_x[ok], rtol=1.0e-6)
+    _assert_same_choice(a_i[ok], a_x[ok], s_x[ok], res)
+
+
+@pytest.mark.gpu
+def test_arbitrary_tables_and_a_table_swap(gpu_device, monkeypatch):
+    """set_array_response takes ANY res x m complex table (.cc:60-70): random magnitudes over six decades (d then spans many
+    orders: small values take the fp64 form), scaled copies, and a swap in a live context (the digit image is rebuilt)."""
+    rng = np.random.default_rng(4)
+    m, n, N, res = 8, 2, 512, 500
+    _, items = _scene(m, n, N, res, 150, 15.0, 8, True)
+    mag = 10.0 ** rng.uniform(-3, 3, size=(res, m))
+    table = (mag * np.exp(2j * np.pi * rng.uniform(size=(res, m)))).astype(np.complex64)
+    for tb in (table, (table * np.float32(3e-12)).astype(np.complex64), (table * np.float32(7e11)).astype(np.complex64)):
+        (a_i, l_i, s_i, _, _), (a_x, l_x, s_x, _, _) = _both(monkeypatch, m, n, N, res, tb, items, gpu_device)
+        assert_spectrum_close(s_i, s_x, rtol=1.0e-6)
+        _assert_same_choice(a_i, a_x, s_x, res)
+    monkeypatch.setenv("BAZ_MUSIC_EXACT", "0")
+    steer = mo.steering_table_c64(mo.array_geometry(m), res, mo.FREQUENCY, mo.SPACING)
+    with _capi().Context(m, n, N, res, steer) as ctx:
+        a_s, l_s, s_s = _run(ctx, items, gpu_device)
+        ctx.set_table(table)
+        a_t, l_t, s_t = _run(ctx, items, gpu_device)
+        ctx.set_table(steer)
+        a_b, l_b, s_b = _run(ctx, items, gpu_device)
+    assert np.array_equal(s_b.view(np.uint32), s_s.view(np.uint32)) and np.array_equal(a_b, a_s)
+    with _capi().Context(m, n, N, res, table) as ctx:
+        a_r, l_r, s_r = _run(ctx, items, gpu_device)
+    assert np.array_equal(s_t.view(np.uint32), s_r.view(np.uint32)) and np.array_equal(a_t, a_r)
+
+
+@pytest.mark.gpu
+def test_without_the_spectrum_port_and_more_than_four_emitters(gpu_device, monkeypatch):
+    """From 9 antennas on the int8 scan also serves ang / lvl alone (m <= 8 has the coarse-gated scan for that); lists of more
+    than four keys keep the fp64 scan."""
+    m, n, N, res = 12, 2, 768, 720
+    table, items = _scene(m, n, N, res, 100, 20.0, 9)
+    (a_i, l_i, _, st, _), (a_x, l_x, _, _, _) = _both(monkeypatch, m, n, N, res, table, items, gpu_device, want_spec=False)
+    ao, lo, so, s64 = mo.music_doa_work_batch(items, table, m, n)
+    assert_doa_match(a_i, l_i, ao, lo, res, s64)
+    assert_doa_match(a_x, l_x, ao, lo, res, s64)
+    assert st[1] > 0
+    monkeypatch.setenv("BAZ_MUSIC_EXACT", "0")
+    with _capi().Context(12, 5, 768, 720, table) as ctx:
+        assert not ctx.uses_i8_scan()
