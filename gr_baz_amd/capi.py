@@ -135,7 +135,7 @@ def _bind(L):
     L.baz_music_host_pinned_bytes.restype = ctypes.c_uint64
     L.baz_music_host_pinned_bytes.argtypes = [_vp]
     L.baz_music_debug_i8_margin.restype = ctypes.c_int
-    L.baz_music_debug_i8_margin.argtypes = [_vp, _vp, _u32, ctypes.POINTER(ctypes.c_float)]
+    L.baz_music_debug_i8_margin.argtypes = [_vp, _vp, _u32, ctypes.POINTER(ctypes.c_float)]   # float worst[2]
     L.baz_music_debug_i8_stats.restype = ctypes.c_int
     L.baz_music_debug_i8_stats.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     L.baz_music_uses_i8_scan.restype = ctypes.c_int
@@ -257,14 +257,14 @@ class Context:
         return bool(self._L.baz_music_uses_i8_scan(self._h))
 
     def debug_i8_margin(self, d_in, batch):
-        """Worst observed |d_int - d| / E of the int8 scan over every (item, bin) of the batch (the bound holds below 1)."""
-        w = ctypes.c_float(0.0)
-        self._chk(self._L.baz_music_debug_i8_margin(self._h, _vp(d_in), int(batch), ctypes.byref(w)),
-                  "baz_music_debug_i8_margin")
-        return float(w.value)
+        """(worst |d5 - d| / E5, worst |d7 - d| / allowance) of the int8 scan's bulk and refined forms over every (item, bin)
+        of the batch, against the fp64 form (the bounds hold below 1)."""
+        w = (ctypes.c_float * 2)(0.0, 0.0)
+        self._chk(self._L.baz_music_debug_i8_margin(self._h, _vp(d_in), int(batch), w), "baz_music_debug_i8_margin")
+        return float(w[0]), float(w[1])
 
     def debug_i8_stats(self):
-        """(wave steps recomputed in the fp64 form, wave steps walked) of the int8 scan since the last read; resets."""
+        """(wave tiles -- 16 items x 16 bins -- that ran the refined form, wave tiles walked) of the int8 scan since the last read; resets."""
         a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
         self._chk(self._L.baz_music_debug_i8_stats(self._h, ctypes.byref(a), ctypes.byref(b)), "baz_music_debug_i8_stats")
         return int(a.value), int(b.value)
@@ -327,8 +327,9 @@ class Context:
 
 
 def debug_i8_image(m, resolution, table):
-    """HOST-ONLY: (image bytes as a uint8 array [step][tile][block][digit][lane][16], params dict) that the library builds for
-    the int8 scan from `table`, or (None, None) when the table has no image.  Needs no device."""
+    """HOST-ONLY: (image bytes as a uint8 array -- [step][tile][block][digit 0..4][lane][16] followed by the same with
+    [digit 5, 6] --, params dict) that the library builds for the int8 scan from `table`, or (None, None) when the table has
+    no image.  Needs no device."""
     t = _table_f32(table, int(resolution), int(m))
     tp = t.view(np.float32).ctypes.data_as(_f32p)
     n = lib().baz_music_debug_i8_image(int(m), int(resolution), tp, None, 0, None)
@@ -338,7 +339,8 @@ def debug_i8_image(m, resolution, table):
     par = np.zeros(16, np.float64)
     lib().baz_music_debug_i8_image(int(m), int(resolution), tp, img.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n,
                                    par.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
-    return img, {"wt": par[:5].copy(), "sq": par[5], "t_acc": par[6], "e_bound": par[7], "ns": int(par[8])}
+    return img, {"wt": par[:7].copy(), "sq": par[7], "t_acc": par[8], "e_bound": par[9], "e_refined": par[10],
+                 "ns": int(par[11]), "nd": int(par[12])}
 
 
 def q_stride(batch):

@@ -131,7 +131,8 @@ struct baz_music_ctx {
     I8Params i8 = {};
     bool i8_ok = false;            // image built (finite table, scale representable, size within I8_IMAGE_LIMIT)
     int i8_on = 1;                 // BAZ_MUSIC_EXACT=1: every value on the fp64 matrix core (A/B; the round-3 scan)
-    unsigned long long* dI8Stat = nullptr;   // [0] wave steps recomputed in the fp64 form, [1] wave steps walked, [2] VAL margin
+    int i8_abl = 0;                // lab (BAZ_MUSIC_I8_ABL): ablation mask of scan_i8_kernel (timing only)
+    unsigned long long* dI8Stat = nullptr;   // [0] wave tiles that ran the refined form, [1] wave tiles walked, [2], [3] VAL margins
     int peak_mode = 0;      // 0: the reference's n strongest bins; 1 (opt-in extension): n strongest local maxima
     float* dPeakSpec = nullptr;   // internal spectrum when peak mode runs without the spectrum port
     size_t peak_spec_cap = 0;     // floats
@@ -352,21 +353,23 @@ bool build_coarse_image(const std::vector<double>& F, uint32_t m, uint32_t res, 
 }
 
 
-// Digit image of the table for the int8-matrix-core scan (scan_i8_kernels.hip.h): Fi = rint(F 2^(8 NS - 2) / Fscale) cut into
-// NS balanced base-256 digits, most significant first (digits 1.. in [-128, 127], the first what is left: |.| <= 65), laid
-// out as the B operand of v_mfma_i32_16x16x64_i8:
-//     img[(((st*4 + t)*NKB + kb)*NS + s)*1024 + lane*16 + j] = digit s of Fi[bin = 64 st + 4 c + t][e = 64 kb + 16 g + j]
-// (lane = 16 g + c; 0 for e >= m^2 and for bins outside the table: such a bin gives d_int = 0 and its step takes the fp64
-// form, whose image carries the huge diagonal there).  Fills the kernel's parameters.  false: table not finite / all zero /
-// scale out of range (the fp64 scan runs then).
-constexpr size_t I8_IMAGE_LIMIT = (size_t)256 << 20;
-size_t i8_image_bytes(uint32_t m, uint32_t steps) { return (size_t)steps * 4 * i8_nkb((int)m) * I8_NS * 1024; }
+// Digit images of the table for the int8-matrix-core scan (scan_i8_kernels.hip.h): Fi = rint(F 2^54 / Fscale) cut into ND = 7
+// balanced base-256 digits, most significant first (digits 1.. in [-128, 127], the first what is left: |.| <= 65), laid out as
+// B operands of v_mfma_i32_16x16x64_i8 -- the five leading digits in `img` (staged through LDS by every tile), digits 5 and 6
+// behind them (read from L2 by the tiles that refine):
+//     img [(((st*4 + t)*NKB + kb)*5 + s)*1024 + lane*16 + j]          = digit s     of Fi[bin = 64 st + 4 c + t][e = 64 kb + 16 g + j]
+//     img2[(((st*4 + t)*NKB + kb)*2 + s)*1024 + lane*16 + j]          = digit 5 + s   (img2 = img + i8_image_bytes5)
+// (lane = 16 g + c; 0 for e >= m^2 and for bins outside the table, which the kernel gives a huge d).  Fills the kernel's
+// parameters.  false: table not finite / all zero / scale out of range (the fp64 scan runs then).
+constexpr size_t I8_IMAGE_LIMIT = (size_t)384 << 20;
+size_t i8_image_bytes5(uint32_t m, uint32_t steps) { return (size_t)steps * 4 * i8_nkb((int)m) * I8_NS * 1024; }
+size_t i8_image_bytes(uint32_t m, uint32_t steps) { return (size_t)steps * 4 * i8_nkb((int)m) * I8_ND * 1024; }
 
 bool build_i8_image(const std::vector<double>& F, uint32_t m, uint32_t res, uint32_t steps, std::vector<uint8_t>& img,
                     I8Params& ip)
 {
     const uint32_t mm = m * m, nkb = (uint32_t)i8_nkb((int)m);
-    constexpr int NS = I8_NS;
+    constexpr int NS = I8_NS, ND = I8_ND;
     double fmax = 0.0;
     for (double v : F) {
         if (!std::isfinite(v)) return false;
@@ -377,26 +380,30 @@ bool build_i8_image(const std::vector<double>& F, uint32_t m, uint32_t res, uint
     (void)std::frexp(fmax / I8_QMAX, &ex);          // fmax / QMAX = f 2^ex, f in [0.5, 1)  ->  fmax / 2^ex < QMAX
     if (ex < -400 || ex > 400) return false;
     const double fscale = std::ldexp(1.0, ex);
-    const double sq = std::ldexp(1.0, 8 * NS - 2), sf = sq / fscale;
-    const double unit = std::ldexp(fscale, -8 * NS - 4);
-    for (int l = 0; l < NS; ++l) ip.wt[l] = std::ldexp(unit, 8 * (NS - 1 - l));
+    const double sq = std::ldexp(1.0, 8 * ND - 2), sf = sq / fscale;
+    for (int l = 0; l < ND; ++l) ip.wt[l] = std::ldexp(fscale, -12 - 8 * l);
     ip.sq = sq;
     ip.e_bound = (double)mm * fscale * (double)NS * 1.01 * std::ldexp(1.0, 2 - 8 * NS);
     ip.t_acc = ip.e_bound * (1.0 + 1.0 / I8_EPS);
-    ip.t_acc_f = std::nextafter((float)ip.t_acc, INFINITY);
+    // (VAL) the refined form against the fp64 form it is compared with: its own digits (7.07 2^-54 MM Fscale) plus the fp64
+    // form's accumulation error, <= MM 2^-53 sum_e |q_e F_e| <= MM^2 2^-53 Fscale in the worst case
+    ip.e_refined = (double)mm * fscale * std::ldexp(1.0, -54) * (7.07 + 2.0 * (double)mm);
     img.assign(i8_image_bytes(m, steps), 0);
+    uint8_t* img2 = img.data() + i8_image_bytes5(m, steps);
     for (uint32_t bin = 0; bin < res; ++bin) {
         const uint32_t st = bin >> 6, w = bin & 63u, c = w >> 2, t = w & 3u;
         for (uint32_t e = 0; e < mm; ++e) {
             const uint32_t kb = e >> 6, g = (e >> 4) & 3u, j = e & 15u;
-            long long v = std::llrint(F[(size_t)bin * mm + e] * sf);
-            uint8_t* base = img.data() + ((size_t)((st * 4 + t) * nkb + kb) * NS) * 1024 + (size_t)(g * 16 + c) * 16 + j;
-            for (int s = NS - 1; s >= 1; --s) {
+            long long v = std::llrint(F[(size_t)bin * mm + e] * sf);          // |v| <= 2^54 (1 + 2^-10); the product is exact
+            const size_t tile = (size_t)(st * 4 + t) * nkb + kb, in_lane = (size_t)(g * 16 + c) * 16 + j;
+            for (int s = ND - 1; s >= 1; --s) {
                 const long long h = (v + 128) >> 8;          // floor((v + 128) / 256)  (arithmetic shift)
-                base[(size_t)s * 1024] = (uint8_t)((v - h * 256) & 255);
+                const uint8_t dg = (uint8_t)((v - h * 256) & 255);
+                if (s >= NS) img2[(tile * (ND - NS) + (size_t)(s - NS)) * 1024 + in_lane] = dg;
+                else img[(tile * NS + (size_t)s) * 1024 + in_lane] = dg;
                 v = h;
             }
-            base[0] = (uint8_t)(v & 255);
+            img[(tile * NS) * 1024 + in_lane] = (uint8_t)(v & 255);
         }
     }
     return true;
@@ -700,8 +707,29 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             rf.A2 = nullptr;
 #define BAZ_I8_LAUNCH(SPEC, VEC4)                                                                                       \
     hipLaunchKernelGGL((scan_i8_kernel<M, NMAX, SPEC, VEC4>), dim3(G.blocks), dim3(256), 0, c->stream, dQ, c->dIB,      \
-                       c->dFB + c->fb_step_elems, d_spec, cand, batch, c->res, qstride, G.nsplit, c->keep_mask, c->n, rf, \
+                       c->dIB + i8_image_bytes5(c->m, c->fb_steps) / 16, c->dFB + c->fb_step_elems, d_spec, cand, batch, c->res, qstride, G.nsplit, c->keep_mask, c->n, rf, \
                        c->i8, c->dI8Stat, nullptr)
+#ifdef BAZ_MUSIC_LAB
+            if constexpr ((M == 8 || M == 16) && NMAX == 2) {        // lab: ablations of the bulk loop (timing only, wrong results)
+                if (spec && vec4 && c->i8_abl) {
+#define BAZ_I8_ABL(ABLV)                                                                                                  \
+    hipLaunchKernelGGL((scan_i8_kernel<M, NMAX, true, true, false, ABLV>), dim3(G.blocks), dim3(256), 0, c->stream, dQ, c->dIB, \
+                       c->dIB + i8_image_bytes5(c->m, c->fb_steps) / 16, c->dFB + c->fb_step_elems, d_spec, cand, batch, c->res, \
+                       qstride, G.nsplit, c->keep_mask, c->n, rf, c->i8, c->dI8Stat, nullptr)
+                    switch (c->i8_abl) {
+                        case 1: BAZ_I8_ABL(1); break;      // no spectrum stores
+                        case 2: BAZ_I8_ABL(2); break;      // no level combination
+                        case 3: BAZ_I8_ABL(3); break;
+                        case 4: BAZ_I8_ABL(4); break;      // no MFMAs
+                        case 6: BAZ_I8_ABL(6); break;
+                        default: BAZ_I8_ABL(7); break;     // staging, LDS reads, barriers, gate only
+                    }
+#undef BAZ_I8_ABL
+                    HIP_TRY(c, hipGetLastError());
+                    return BAZ_MUSIC_OK;
+                }
+            }
+#endif
             if (spec && vec4) BAZ_I8_LAUNCH(true, true);
             else if (spec) BAZ_I8_LAUNCH(true, false);
             else BAZ_I8_LAUNCH(false, false);
@@ -1528,10 +1556,11 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
             if (hipMemset(c->dMargin, 0, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         }
         if (const char* v = getenv("BAZ_MUSIC_EXACT")) c->i8_on = atoi(v) ? 0 : 1;                // A/B: 1 = the fp64 scan everywhere
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8_ABL")) c->i8_abl = atoi(v);                  // lab
         if (m >= 6 && n <= 4 && i8_image_bytes(m, c->fb_steps) <= I8_IMAGE_LIMIT) {
             if (hipMalloc((void**)&c->dIB, i8_image_bytes(m, c->fb_steps)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
-            if (hipMalloc((void**)&c->dI8Stat, 3 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
-            if (hipMemset(c->dI8Stat, 0, 3 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
+            if (hipMalloc((void**)&c->dI8Stat, 4 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+            if (hipMemset(c->dI8Stat, 0, 4 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         }
         if (short_form_applies(m, n) && hipMalloc((void**)&c->dA2p, (size_t)(c->fb_steps + 2) * 64 * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         {
@@ -2006,8 +2035,9 @@ int64_t baz_music_debug_coarse_fired(baz_music_ctx* c)
     return (int64_t)v;
 }
 
-// Validation of the int8 scan's a-priori bound on this hardware (scan_i8_kernels.hip.h, VAL): covariance + EVD of the batch,
-// then EVERY (item, bin) in both forms; *worst = max |d_int - d| / E over the items that take the integer form.
+// Validation of the int8 scan's a-priori bounds on this hardware (scan_i8_kernels.hip.h, VAL): covariance + EVD of the batch,
+// then EVERY (item, bin) in the bulk, the refined and the fp64 form; worst[0] = max |d5 - d| / E5, worst[1] = max |d7 - d| /
+// allowance over the items that take the integer forms.
 int baz_music_debug_i8_margin(baz_music_ctx* c, const void* d_in, uint32_t batch, float* worst)
 {
     if (!c || !d_in || !worst || batch == 0) return BAZ_MUSIC_E_INVALID;
@@ -2025,14 +2055,14 @@ int baz_music_debug_i8_margin(baz_music_ctx* c, const void* d_in, uint32_t batch
     if (!r) r = launch_evd(c, c->dR, batch, c->dQ, qstride, c->dG);
     c->i8_on = on;
     if (r) return r;
-    HIP_TRY(c, hipMemsetAsync(c->dI8Stat + 2, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dI8Stat + 2, 0, 2 * sizeof(unsigned long long), c->stream));
     ScanRefine rf;
     rf.Gs = nullptr; rf.TB = c->dTB + c->tb_step_elems; rf.below = 0.0; rf.count = nullptr; rf.A2 = nullptr;
     const uint32_t blocks = (batch + 63) / 64;
 #define BAZ_VAL8(MV)                                                                                                      \
     case MV: hipLaunchKernelGGL((scan_i8_kernel<MV, 2, false, false, true>), dim3(blocks), dim3(256), 0, c->stream, c->dQ, \
-                                c->dIB, c->dFB + c->fb_step_elems, nullptr, c->dCand, batch, c->res, qstride, 1u, c->keep_mask, \
-                                c->n, rf, c->i8, nullptr, c->dI8Stat + 2); break;
+                                c->dIB, c->dIB + i8_image_bytes5(c->m, c->fb_steps) / 16, c->dFB + c->fb_step_elems, nullptr, c->dCand, \
+                                batch, c->res, qstride, 1u, c->keep_mask, c->n, rf, c->i8, nullptr, c->dI8Stat + 2); break;
     switch (c->m) {
         BAZ_VAL8(6) BAZ_VAL8(7) BAZ_VAL8(8) BAZ_VAL8(9) BAZ_VAL8(10) BAZ_VAL8(11) BAZ_VAL8(12) BAZ_VAL8(13) BAZ_VAL8(14)
         BAZ_VAL8(15) BAZ_VAL8(16)
@@ -2040,17 +2070,19 @@ int baz_music_debug_i8_margin(baz_music_ctx* c, const void* d_in, uint32_t batch
     }
 #undef BAZ_VAL8
     HIP_TRY(c, hipGetLastError());
-    unsigned long long packed = 0;
-    HIP_TRY(c, hipMemcpyAsync(&packed, c->dI8Stat + 2, sizeof(packed), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long packed[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(packed, c->dI8Stat + 2, sizeof(packed), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const unsigned int bits = (unsigned int)packed;
-    std::memcpy(worst, &bits, sizeof(float));
+    for (int k = 0; k < 2; ++k) {
+        const unsigned int bits = (unsigned int)packed[k];
+        std::memcpy(worst + k, &bits, sizeof(float));
+    }
     return BAZ_MUSIC_OK;
 }
 
-// Statistic of the int8 scan since the last read (resets): wave steps (16 items x 64 bins) recomputed in the fp64 form, and
-// wave steps walked.  BAZ_MUSIC_E_UNSUPPORTED where that scan does not exist for the configuration.
-int baz_music_debug_i8_stats(baz_music_ctx* c, uint64_t* fp64_steps, uint64_t* steps)
+// Statistic of the int8 scan since the last read (resets): wave tiles (16 items x 16 bins) that ran the refined (seven-digit)
+// form, and wave tiles walked.  BAZ_MUSIC_E_UNSUPPORTED where that scan does not exist for the configuration.
+int baz_music_debug_i8_stats(baz_music_ctx* c, uint64_t* refined_tiles, uint64_t* tiles)
 {
     if (!c) return BAZ_MUSIC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mtx);
@@ -2060,8 +2092,8 @@ int baz_music_debug_i8_stats(baz_music_ctx* c, uint64_t* fp64_steps, uint64_t* s
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(v, c->dI8Stat, sizeof(v), hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemset(c->dI8Stat, 0, sizeof(v)));
-    if (fp64_steps) *fp64_steps = v[0];
-    if (steps) *steps = v[1];
+    if (refined_tiles) *refined_tiles = v[0];
+    if (tiles) *tiles = v[1];
     return BAZ_MUSIC_OK;
 }
 
@@ -2069,9 +2101,9 @@ int baz_music_debug_i8_stats(baz_music_ctx* c, uint64_t* fp64_steps, uint64_t* s
 // BAZ_MUSIC_EXACT=1), else 0.
 int baz_music_uses_i8_scan(const baz_music_ctx* c) { return (c && !c->wide && i8_active(c)) ? 1 : 0; }
 
-// HOST-ONLY tap (no device needed): the digit image and parameters build_i8_image() produces for a table.  Returns the
-// image's size in bytes (also when `out` is NULL or too small: nothing is written then), 0 when the table has no image.
-// params[0 .. NS-1] = level weights, [NS] = 2^(8 NS - 2), [NS + 1] = T, [NS + 2] = E, [NS + 3] = NS.
+// HOST-ONLY tap (no device needed): the digit images and parameters build_i8_image() produces for a table.  Returns the
+// images' size in bytes (also when `out` is NULL or too small: nothing is written then), 0 when the table has no image.
+// params[0 .. 6] = level weights, [7] = 2^54, [8] = T, [9] = E5, [10] = allowance of the refined form, [11] = 5, [12] = 7.
 size_t baz_music_debug_i8_image(uint32_t m, uint32_t resolution, const float* table_ri, uint8_t* out, size_t out_bytes,
                                 double* params)
 {
@@ -2082,8 +2114,9 @@ size_t baz_music_debug_i8_image(uint32_t m, uint32_t resolution, const float* ta
     I8Params ip = {};
     if (!build_i8_image(F, m, resolution, (resolution + 63) / 64, img, ip)) return 0;
     if (params) {
-        for (int l = 0; l < I8_NS; ++l) params[l] = ip.wt[l];
-        params[I8_NS] = ip.sq; params[I8_NS + 1] = ip.t_acc; params[I8_NS + 2] = ip.e_bound; params[I8_NS + 3] = (double)I8_NS;
+        for (int l = 0; l < I8_ND; ++l) params[l] = ip.wt[l];
+        params[7] = ip.sq; params[8] = ip.t_acc; params[9] = ip.e_bound; params[10] = ip.e_refined;
+        params[11] = (double)I8_NS; params[12] = (double)I8_ND;
     }
     if (out && out_bytes >= img.size()) std::memcpy(out, img.data(), img.size());
     return img.size();

@@ -1,6 +1,7 @@
-// scan_i8_kernels.hip.h -- the pseudo-spectrum scan (lib/baz_music_doa.cc:101-121) for 6 .. 16 antennas with the bulk of
-// the (item, bin) values on the INT8 matrix core, exactly accumulated, and the fp64 matrix core only where an a-priori
-// error bound says so.  gfx950 only.
+// scan_i8_kernels.hip.h -- the pseudo-spectrum scan (lib/baz_music_doa.cc:101-121) for 6 .. 16 antennas on the INT8 matrix
+// core: digit products accumulated exactly in int32, five digits per operand for the bulk of the (item, bin) values, seven
+// where an a-priori error bound says so (and the reference's literal form on the fp64 matrix core near nulls, as before).
+// gfx950 only.
 //
 // Why.  d(item, bin) = a^H Q a = sum_e q_e F_e over MM = m^2 real terms (music_kernels.hip.h 4.) cancels, so it cannot be
 // evaluated in float32, and on v_mfma_f64_16x16x4 it is bound by the fp64 matrix rate: config 3 (m = 8, 36,000 bins) ran its
@@ -8,65 +9,73 @@
 // faster and ACCUMULATES IN INT32 WITHOUT ROUNDING -- the only error of an integer form is the one made when the operands
 // are cut into digits, and that has a bound that needs no statistics (the Ozaki scheme, with integer slices).
 //
-// Integer form.  Both operands in fixed point with NS = 5 balanced base-256 digits (int8):
-//     Qi_e = rint(q_e 2^(8 NS - 2))           |q_e| <= 1 for a projector (|Q_ij| <= 1/2 off the diagonal, q = 2 Re / -2 Im)
-//     Fi_e = rint(F_e 2^(8 NS - 2) / Fscale)  Fscale = the power of two with max|F| / Fscale in (1/2 (1 + 2^-10), 1 + 2^-10]
-//     X = sum_s x_s 256^(NS - 1 - s),  x_s in [-128, 127] (s >= 1),  |x_0| <= 65
-// The product sum_e Qi_e Fi_e is the sum over digit pairs (s, t) of 256^(2 NS - 2 - s - t) A_st, A_st = sum_e q_es F_et: one
-// K = 64 int8 MFMA per pair, 16-item x 16-bin tile and block of 64 terms.  Pairs are accumulated per LEVEL l = s + t (one
-// int32 accumulator per level: |A| <= (l + 1) MM 2^14 < 2^31) and the levels l >= NS are dropped: NS (NS + 1) / 2 = 15 MFMAs
-// per tile and block where the fp64 form issues 16 fp64 MFMAs of 4 x the cycles each.  Levels are combined per value in
-// fp64 (every partial sum is an integer below 2^53 times a power of two: exact), d_int = H * unit.
+// Integer form.  Both operands in fixed point, cut into ND = 7 balanced base-256 digits (int8), most significant first:
+//     Qi_e = rint(q_e 2^54)            |q_e| <= 1 for a projector (|Q_ij| <= 1/2 off the diagonal, q = 2 Re / -2 Im)
+//     Fi_e = rint(F_e 2^54 / Fscale)   Fscale = the power of two with max|F| / Fscale in (1/2 (1 + 2^-10), 1 + 2^-10]
+//     X = sum_s x_s 256^(6 - s),  x_s in [-128, 127] (s >= 1),  |x_0| <= 65
+// The product sum_e Qi_e Fi_e is the sum over digit pairs (s, t) of 256^(12 - s - t) A_st, A_st = sum_e q_es F_et: one K = 64
+// int8 MFMA per pair, 16-item x 16-bin tile and block of 64 terms, accumulated per LEVEL l = s + t in one int32 accumulator
+// (|A| <= (l + 1) MM 2^14 < 2^31).  The BULK form keeps the levels l < NS = 5 -- 15 MFMAs per tile and block, where the fp64
+// form issues 16 fp64 MFMAs of 4 x the cycles each --, i.e. it multiplies the operands' five leading digits.  Levels are
+// combined per value in fp64 (every partial sum is an integer below 2^53 times a power of two: exact), d5 = H * 2^-12 Fscale.
 //
-// Error bound (a priori, in units of d):
-//     digits cut off    |q_e - Qi_e / Sq| <= 2^(1 - 8 NS),  the same for F / Fscale       ->  <= MM Fscale 2^(2 - 8 NS) 1.001
-//     levels dropped    pairs (s, t), s + t >= NS: <= MM 128^2 (NS - 1) 256^(NS - 2) 1.005 of the integer product
-//                                                                                          ->  <= MM Fscale (NS - 1) 2^(2 - 8 NS) 1.005
-//     E = MM Fscale NS 1.01 2^(2 - 8 NS)        (m = 8: 1.2e-9 Fscale; m = 16: 4.7e-9 Fscale;  ||a||^2 = m for the helper's tables)
-// tests/lab/i8_split_study.py restates the scheme in numpy (worst observed error 0.04 - 0.09 E), tests/test_i8_scan.py pins
-// the host-side image against it, and the VAL instantiation (baz_music_debug_i8_margin) evaluates both forms on EVERY
-// (item, bin) of a batch on the hardware and returns the worst |d_int - d| / E.
+// Error bound of the bulk form (a priori, in units of d):
+//     digits cut off    five leading BALANCED digits of seven: |q_e - Q5_e / 2^38| <= 0.502 2^-38, the same for F / Fscale
+//                                                                                          ->  <= MM Fscale 2^-38 1.006
+//     levels dropped    pairs (s, t) of the five digits with s + t >= 5: <= MM 128^2 4 256^3 1.005 of the integer product
+//                                                                                          ->  <= MM Fscale 4 2^-38 1.005
+//     E5 = MM Fscale 5 1.01 2^-38          (m = 8: 1.2e-9 Fscale; m = 16: 4.7e-9 Fscale;  ||a||^2 = m for the helper's tables)
+// A value is within eps = 7.5e-7 of the true one when d5 > T = E5 (1 + 1 / eps).
 //
-// Where the integer value is used.  A value is within eps = 7.5e-7 of the fp64 one when d_int > T = E (1 + 1 / eps).  A
-// 16-item x 64-bin step in which some |d_int| <= T (the bottom of the nulls: 0.5 % of the values of a 20-dB scene; bins
-// outside the table and items whose coefficients are not a projector's have zero digits and always land here) is recomputed
-// by scan_mfma_kernel's own fp64 instruction sequence (exact16: same operands, same k order, same bits), including its
-// literal-form refinement of near-null values (T >= refine_below by orders of magnitude), and the VALUES at or below T take
-// the fp64 result -- per value, so an (item, bin) pair's bits do not depend on its wave-mates.  Everything downstream of d --
-// (float) conversion, v_rcp_f32, the store pattern, the gated top-n network, the candidate lists -- is scan_mfma_kernel's.
-// The top-n keys of the other steps are built from d_int: two bins can change places against the fp64 scan only where their
-// strengths agree to 2 eps = 1.5e-6 (the parity rule allows 2e-5), and lvl[i] == spectrum[bin_i] holds bit for
-// bit as before (the merge reads lvl back from the spectrum it indexes).
+// Refined form.  A 16 x 16 tile in which some |d5| <= T (the bottom of the nulls: 0.5 % of the values of a 20-dB scene) adds
+// the levels 5 and 6 of ALL SEVEN digits -- 13 more MFMAs on top of the five accumulators it still holds; digits 5, 6 of q
+// from the lane's LDS slot, of F from a second image in L2 -- and the VALUES at or below T take d7 = d5 + (level 5, 6 sums):
+// per value, so an (item, bin) pair's bits do not depend on its wave-mates.  |d7 - d| <= MM Fscale 7.07 2^-54 + 2^-53 |d|
+// (digits; one rounding of the final sum): m = 8: 2.5e-14, the accuracy class of the fp64 form itself (m^2 eps ||a||^2 in
+// the worst case) -- so the refined form REPLACES it: at `refine_below` = m 1e-8 max||a||^2, where scan_mfma_kernel's
+// literal-form refinement of near-null values takes over (T exceeds it by orders of magnitude), d7 is good to 4e-8 relative.
+// Bins outside the table get a huge d (never selected, never stored); items whose coefficients are not a projector's
+// (non-finite or garbage covariance) have zero digits and take scan_mfma_kernel's own fp64 instruction sequence for their
+// rows (exact16: same operands, same k order, same bits).  Everything downstream of d -- (float) conversion, v_rcp_f32, the
+// store pattern, the gated top-n network, literal_tile(), the candidate lists -- is scan_mfma_kernel's.  Two bins can change
+// places in the top-n list against the fp64 scan only where their strengths agree to 2 eps = 1.5e-6 (the parity rule allows
+// 2e-5), and lvl[i] == spectrum[bin_i] holds bit for bit (the merge reads lvl back from the spectrum).
+// tests/lab/i8_split_study.py restates the scheme in numpy (worst observed error 0.04 - 0.09 E5), tests/test_i8_scan.py pins
+// the host-side images against it, and the VAL instantiation (baz_music_debug_i8_margin) evaluates all three forms on EVERY
+// (item, bin) of a batch on the hardware: worst |d5 - d| / E5 and worst |d7 - d| / allowance.
 //
 // Layouts.  int8 / f16 MFMA C/D: col = lane & 15, row = 4 (lane >> 4) + reg; f64 MFMA: row = (lane >> 4) + 4 reg.  The int8 A
 // operand therefore carries item pi(i) = (i >> 2) + 4 (i & 3) in row i, so that register r of lane (g, c) is item g + 4 r in
 // BOTH forms (the trick of scan_coarse_kernels.hip.h).  A / B operand of the K = 64 form: lane (g, c) holds row / column c,
 // k = 16 g + j in byte j of its 16 bytes (the same map on both sides: any consistent one gives the same dot product).
-// Table image IB (built at set_table, build_i8_image): [64-bin step][tile t][block kb][digit s][lane] x 16 B, tile t of a
-// step carrying the bins 64 st + 4 c + t in its columns like FB (a lane ends up with 4 consecutive bins: one 16-B store).
-// A phase = TPP tiles (20 KiB at m <= 8 and at m >= 12) goes L2 -> LDS by global_load_lds_dwordx4, double-buffered, shared by
-// the 4 waves of a workgroup; a wave owns 16 items and a range of steps, like scan_mfma_kernel (no row classes: m >= 6).
+// Table images (built at set_table, build_i8_image): IB = [64-bin step][tile t][block kb][digit 0 .. 4][lane] x 16 B, IB2 the
+// same with [digit 5, 6]; tile t of a step carries the bins 64 st + 4 c + t in its columns like FB (a lane ends up with 4
+// consecutive bins: one 16-B store).  A phase = TPP tiles of IB (20 KiB at m <= 8 and at m >= 12) goes L2 -> LDS by
+// global_load_lds_dwordx4, double-buffered, shared by the 4 waves of a workgroup; a wave owns 16 items and a range of steps,
+// like scan_mfma_kernel (no row classes: m >= 6).
 #pragma once
 
-#include "music_kernels.hip.h"
+#include "scan_coarse_kernels.hip.h"      // (music_kernels.hip.h, literal16)
 
 namespace bazmusic {
 
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
-constexpr int I8_NS = 5;                                           // digits per operand = levels kept
+constexpr int I8_NS = 5;                                           // digits of the bulk form = levels it keeps
+constexpr int I8_ND = 7;                                           // digits of the refined form (operands are cut into these)
 constexpr int i8_nkb(int m) { return (m * m + 63) / 64; }          // blocks of 64 terms
 constexpr int i8_tpp(int m) { return i8_nkb(m) == 1 ? 4 : (i8_nkb(m) == 2 ? 2 : 1); }     // tiles per staged phase
-constexpr int i8_tile_units(int m) { return i8_nkb(m) * I8_NS * 64; }                      // 16-B units per 16-bin tile
-constexpr double I8_QMAX = 1.0009765625;                           // |q_e| <= 1 + 2^-10, else the item never takes the integer form
-constexpr double I8_EPS = 7.5e-7;                                  // relative accuracy promised for values that keep the integer form
+constexpr int i8_tile_units(int m) { return i8_nkb(m) * I8_NS * 64; }                      // 16-B units per 16-bin tile (digits 0 .. 4)
+constexpr int i8_tile_units2(int m) { return i8_nkb(m) * (I8_ND - I8_NS) * 64; }           // ... of the refinement digits (5, 6)
+constexpr double I8_QMAX = 1.0009765625;                           // |q_e| <= 1 + 2^-10, else the item takes the fp64 form throughout
+constexpr double I8_EPS = 7.5e-7;                                  // relative accuracy promised for values that keep the bulk form
 
 struct I8Params {
-    double wt[I8_NS];     // wt[l] = unit 256^(NS - 1 - l): weight of the level-l sum (unit = Fscale 2^(-8 NS - 4))
-    double sq;            // 2^(8 NS - 2)
-    double t_acc;         // T = E (1 + 1 / eps): at or below it a value takes the fp64 form
-    float t_acc_f;        // (float) T rounded up
-    double e_bound;       // E (VAL only)
+    double wt[I8_ND];     // wt[l] = Fscale 2^(-12 - 8 l): weight of the level-l sum of digit products
+    double sq;            // 2^(8 ND - 2): the fixed-point scale of q
+    double t_acc;         // T = E5 (1 + 1 / eps): at or below it a value takes the refined form
+    double e_bound;       // E5 (VAL only)
+    double e_refined;     // allowance of the refined form against the fp64 form (VAL only)
 };
 
 // two adjacent levels fit one int32 (a_l 256 + a_(l+1)) while (l + 1) MM 2^22 + (l + 2) MM 2^14 < 2^31
@@ -74,7 +83,7 @@ constexpr bool i8_pair_ok(int mm, int l) { return (long long)(l + 1) * mm * 4194
 
 template <int MM, int L>
 struct I8Comb {
-    static __device__ __forceinline__ double run(const int (&a)[I8_NS], const double (&wt)[I8_NS])
+    static __device__ __forceinline__ double run(const int (&a)[I8_NS], const double (&wt)[I8_ND])
     {
         if constexpr (L >= I8_NS) return 0.0;
         else if constexpr (L + 1 < I8_NS && i8_pair_ok(MM, L))
@@ -85,7 +94,7 @@ struct I8Comb {
 
 // scan_mfma_kernel's projector GEMM for ONE 16-item x 16-bin tile (tile t of step st): same operands, same k order, hence
 // the same bits.  Both operands come from L2 (q of the natural row c, FB where the image has it).  Not inlined: the ordinary
-// steps do not pay its registers.
+// steps do not pay its registers.  Used for items whose coefficients are not a projector's, and by the validation build.
 template <int M>
 __device__ __noinline__ v4f64 exact16(const double* __restrict__ Qs, const double2* __restrict__ FB, const uint32_t itn,
                                       const int g, const int lane, const uint32_t qstride, const uint32_t st, const int t)
@@ -102,27 +111,37 @@ __device__ __noinline__ v4f64 exact16(const double* __restrict__ Qs, const doubl
     return acc;
 }
 
-// VAL: validation build (baz_music_debug_i8_margin): every step runs both forms; the worst |d_int - d| / E over all (item,
-// bin) whose item took the integer form is left in *margin (float bits, atomicMax); outputs are the fp64 form's.
-// stat (may be nullptr): [0] += wave steps recomputed in the fp64 form, [1] += wave steps walked.
-template <int M, int NMAX, bool SPEC, bool VEC4, bool VAL = false>
+// Order of the bulk form's 15 digit pairs (s = digit of q, l = level = s + digit of F): the levels go round so that two
+// MFMAs on the same accumulator are as far apart as the triangle allows (a dependent MFMA waits for its predecessor's passes).
+constexpr int i8_order_s(int i) { return i < 5 ? 0 : (i < 9 ? 1 : (i < 12 ? 2 : (i < 14 ? 3 : 4))); }
+constexpr int i8_order_l(int i) { return i < 5 ? 4 - i : (i < 9 ? 9 - i : (i < 12 ? 13 - i : (i < 14 ? 16 - i : 4))); }
+
+// VAL: validation build (baz_music_debug_i8_margin): every tile runs the bulk AND the refined form, every step the fp64 form;
+// margin[0] / margin[1] = the worst |d5 - d| / E5 and |d7 - d| / allowance over all (item, bin) of items that take the integer
+// forms (float bits, atomicMax); outputs are the fp64 form's.
+// stat (may be nullptr): [0] += wave tiles (16 items x 16 bins) that ran the refined form, [1] += wave tiles walked.
+// ABL (lab builds only): 1 no spectrum stores, 2 no level combination (one conversion per value), 4 no MFMAs -- timing only.
+template <int M, int NMAX, bool SPEC, bool VEC4, bool VAL = false, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restrict__ Qs, const uint4* __restrict__ IB,
-                                                         const double2* __restrict__ FB, float* __restrict__ spec,
-                                                         double* __restrict__ cand, uint32_t batch, uint32_t res,
-                                                         uint32_t qstride, uint32_t nsplit, uint32_t keep_mask, uint32_t n,
-                                                         ScanRefine rf, I8Params ip, unsigned long long* __restrict__ stat,
+                                                         const uint4* __restrict__ IB2, const double2* __restrict__ FB,
+                                                         float* __restrict__ spec, double* __restrict__ cand, uint32_t batch,
+                                                         uint32_t res, uint32_t qstride, uint32_t nsplit, uint32_t keep_mask,
+                                                         uint32_t n, ScanRefine rf, I8Params ip,
+                                                         unsigned long long* __restrict__ stat,
                                                          unsigned long long* __restrict__ margin)
 {
     constexpr int MM = M * M;
-    constexpr int NS = I8_NS;
-    static_assert(I8_NS == 5, "the level lists below are written out for five digits");
+    constexpr int NS = I8_NS, ND = I8_ND;
+    static_assert(I8_NS == 5 && I8_ND == 7, "the level lists below are written out for five + two digits");
     constexpr int NKB = i8_nkb(M);
     constexpr int TPP = i8_tpp(M);
     constexpr int PPS = 4 / TPP;                       // phases per 64-bin step
     constexpr int TU = i8_tile_units(M);               // 16-B units per tile
+    constexpr int TU2 = i8_tile_units2(M);
     constexpr int CH = TPP * NKB * NS;                 // 1-KiB chunks per phase
     static_assert(M >= 6 && M <= 16, "6 <= m <= 16 (row classes below, run-time-m kernels above)");
     __shared__ uint4 stage[2][CH * 64];
+    __shared__ v4i32 a56[4][NKB][ND - NS][64];         // digits 5, 6 of q, per wave and LANE (each lane reads back its own)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -140,14 +159,18 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
     // ---- int8 A operand: the digits of q(item pi(c)), k = 64 kb + 16 g + j ------------------------------------------
     v4i32 A[NKB][NS];
     bool sane_r[4];
+    bool any_insane;
     {
         const uint32_t it_p = item0 + (uint32_t)((c >> 2) + 4 * (c & 3));    // permuted row c
         const uint32_t itp = (it_p < batch) ? it_p : (batch - 1);
         int ok = 1;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
+            v4i32 lo[ND - NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) A[kb][s] = (v4i32){0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < ND - NS; ++s) lo[s] = (v4i32){0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int e = 64 * kb + 16 * g + j;
@@ -156,12 +179,14 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
                 const bool fine = fabs(qv) <= I8_QMAX;                       // false for NaN
                 ok &= fine ? 1 : 0;
                 qv = fine ? qv : 0.0;
-                double r = __builtin_rint(qv * ip.sq);
+                double r = __builtin_rint(qv * ip.sq);                       // |r| <= 2^54 (1 + 2^-10): every step below is exact
 #pragma unroll
-                for (int s = NS - 1; s >= 1; --s) {
+                for (int s = ND - 1; s >= 1; --s) {
                     const double h = __builtin_floor(__builtin_fma(r, 0x1p-8, 0.5));     // floor((r + 128) / 256)
                     const int dg = (int)__builtin_fma(-256.0, h, r);                     // in [-128, 127]
-                    A[kb][s][j >> 2] |= (int)((unsigned)(dg & 255) << (8 * (j & 3)));
+                    const int w = (int)((unsigned)(dg & 255) << (8 * (j & 3)));
+                    if (s >= NS) lo[s - NS][j >> 2] |= w;
+                    else A[kb][s][j >> 2] |= w;
                     r = h;
                 }
                 A[kb][0][j >> 2] |= (int)((unsigned)((int)r & 255) << (8 * (j & 3)));
@@ -169,17 +194,23 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
                 // its top and the 12 .. 15-antenna instantiations spill 150 .. 490 registers)
                 if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int s = 0; s < ND - NS; ++s) a56[wave][kb][s][lane] = lo[s];
         }
         ok &= __shfl_xor(ok, 16, 64);                  // the 4 lanes (g = 0 .. 3) that hold the row
         ok &= __shfl_xor(ok, 32, 64);
-        if (!ok) {                                     // not a projector's coefficients: zero digits, every step takes the fp64 form
+        if (!ok) {                                     // not a projector's coefficients: zero digits; the row takes the fp64 form
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
+            for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) A[kb][s] = (v4i32){0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < ND - NS; ++s) a56[wave][kb][s][lane] = (v4i32){0, 0, 0, 0};
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) sane_r[r] = __shfl(ok, 4 * g + r, 64) != 0;     // item g + 4 r = permuted row 4 g + r
+        any_insane = __any(!ok);
     }
 
     double key[4][NMAX];
@@ -195,8 +226,8 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
         gate_d[r] = __builtin_bit_cast(double, (uint64_t)BAZ_KEY_EMPTY_BITS | 0xFFFFFull);
     }
     const bool refine_on = rf.Gs != nullptr;
-    const double lit_below = refine_on ? rf.below : -1.0;
-    const float tacc_f = ip.t_acc_f;
+    [[maybe_unused]] const float below_f = refine_on ? (float)rf.below : -1.0f;
+    [[maybe_unused]] const double below_d = refine_on ? rf.below : -1.0;
     const double tacc_d = ip.t_acc;
 
     // ---- table staging: L2 -> LDS directly, 1 KiB per wave instruction ----------------------------------------------
@@ -223,22 +254,29 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
         row_ok[r] = (item0 + (uint32_t)(g + 4 * r)) < batch;
     }
     uint32_t refined = 0, fell = 0;
-    [[maybe_unused]] float worst = 0.0f;
+    [[maybe_unused]] float worst5 = 0.0f, worst7 = 0.0f;
 
     if (st_begin < st_end) stage_load(st_begin, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    const uint32_t nobin = ~keep_mask;
+    const int nn = (int)M - (int)n;
     for (uint32_t st = st_begin; st < st_end; ++st) {
-        v4f64 acc[4];
-        const uint32_t bin = st * 64 + 4 * (uint32_t)c;          // this lane's first bin of the step
+        const uint32_t bin = st * 64 + 4 * (uint32_t)c;          // this lane's first bin of the step (tile t: bin + t)
+        const bool tail_step = st * 64 + 64 > res;               // wave-uniform: the step reaches beyond the table
 #pragma unroll
         for (int p = 0; p < PPS; ++p) {
             const bool last_p = (p == PPS - 1);
             const bool more = !last_p || (st + 1 < st_end);      // wave-uniform
             if (more) stage_load(last_p ? st + 1 : st, last_p ? 0 : p + 1, buf ^ 1);
+            if (p == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(sv[r]));      // (see scan_mfma_kernel: the store data stays put)
+            }
 
-            // the phase's tiles: NKB NS (NS + 1) / 2 int8 MFMAs each, then the levels of every value combined in fp64
+            // the phase's tiles, one at a time: 15 NKB int8 MFMAs, the levels of every value combined in fp64, and
+            // scan_mfma_kernel's epilogue for the tile's 4 values per lane (gate, literal form near nulls, keys, reciprocals)
             const v4i32* __restrict__ Bp = reinterpret_cast<const v4i32*>(&stage[buf][0]) + lane;
 #pragma unroll
             for (int tl = 0; tl < TPP; ++tl) {
@@ -251,87 +289,122 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
                     v4i32 b[NS];
 #pragma unroll
                     for (int s = 0; s < NS; ++s) b[s] = Bp[((tl * NKB + kb) * NS + s) * 64];
-                    // level by level across the digits of q: consecutive MFMAs go to different accumulators
+                    if constexpr (ABL & 4) {
 #pragma unroll
-                    for (int s = 0; s < NS; ++s)
-#pragma unroll
-                        for (int l = s; l < NS; ++l)
-                            L[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][s], b[l - s], L[l], 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int a[NS] = {L[0][r], L[1][r], L[2][r], L[3][r], L[4][r]};
-                    acc[t][r] = I8Comb<MM, 0>::run(a, ip.wt);
-                }
-            }
-
-            if (last_p) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(sv[r]));      // (see scan_mfma_kernel: the store data stays put)
-                bool hit = false, low = false;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if constexpr (SPEC) {
-                        float fd[4];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) fd[t] = (float)acc[t][r];
-                        float mn;
-                        asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(mn) : "v"(fd[0]), "v"(fd[1]), "v"(fd[2]));
-                        asm("v_min_f32 %0, %1, |%2|" : "=v"(mn) : "v"(mn), "v"(fd[3]));
-                        hit |= (mn <= gate_f[r]);
-                        low |= (mn <= tacc_f);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) sv[r][t] = __builtin_amdgcn_rcpf(fabsf(fd[t]));
+                        for (int l = 0; l < NS; ++l) L[l] += b[l] ^ A[kb][l];
                     } else {
-                        double m01, m23, mn;
-                        asm("v_min_f64 %0, |%1|, |%2|" : "=v"(m01) : "v"(acc[0][r]), "v"(acc[1][r]));
-                        asm("v_min_f64 %0, |%1|, |%2|" : "=v"(m23) : "v"(acc[2][r]), "v"(acc[3][r]));
-                        mn = vmin64(m01, m23);
-                        hit |= (mn <= gate_d[r]);
-                        low |= (mn <= tacc_d);
+#pragma unroll
+                        for (int i = 0; i < 15; ++i) {
+                            const int s = i8_order_s(i), l = i8_order_l(i);
+                            L[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][s], b[l - s], L[l], 0, 0, 0);
+                        }
                     }
                 }
-                hit |= low;
-                if (VAL || __any(hit)) {
-                    if (VAL || __any(low)) {
-                        // some value of the step is too small for the integer form's bound: the whole step in the fp64 form
-                        ++fell;
-                        bool lit = false;
+                v4f64 d;
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const v4f64 ex = exact16<M>(Qs, FB, itn, g, lane, qstride, st, t);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                if constexpr (VAL) {
-                                    const float ratio = (float)(fabs(acc[t][r] - ex[r]) / ip.e_bound);
-                                    if (sane_r[r] && row_ok[r] && bin + t < res && ratio > worst) worst = ratio;   // (NaN never counts)
-                                }
-                                // Per VALUE: only a d_int at or below T is replaced, so what an (item, bin) pair gets never
-                                // depends on which items share its wave or on how a batch was cut (the rule of literal_tile()).
-                                const bool take = VAL || !(fabs(acc[t][r]) > tacc_d);
-                                acc[t][r] = take ? ex[r] : acc[t][r];
-                                lit |= take && (fabs(ex[r]) <= lit_below);
-                            }
-                        }
-                        if (refine_on && __any(lit)) {          // near-null values: the reference's literal form (scan_mfma_kernel)
-                            const v2f64* __restrict__ tbl = reinterpret_cast<const v2f64*>(rf.TB) + lane;
-                            refined += literal_tile<M>(acc, rf, tbl, st, itn, g, qstride, (int)M - (int)n, bin, res, row_ok);
-                        }
-                        if constexpr (SPEC) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                                for (int t = 0; t < 4; ++t) sv[r][t] = strength_f32(fabs(acc[t][r]));
-                        }
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (ABL & 2) d[r] = (double)(L[0][r] + L[1][r] + L[2][r] + L[3][r] + L[4][r]) * ip.wt[2];
+                    else {
+                        const int a[NS] = {L[0][r], L[1][r], L[2][r], L[3][r], L[4][r]};
+                        d[r] = I8Comb<MM, 0>::run(a, ip.wt);
                     }
-                    const uint32_t nobin = ~keep_mask;
+                }
+                [[maybe_unused]] const v4f64 d5 = d;
+                // Values at or below T: two more digits of both operands (levels 5 and 6 on top of the five accumulated ones:
+                // 13 NKB MFMAs), digits 5, 6 of q from this lane's LDS slot, of F from the image in L2.
+                bool lowt = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lowt |= !(fabs(d[r]) > tacc_d);
+                if (VAL || __any(lowt)) {
+                    ++fell;
+                    v4i32 L5 = {0, 0, 0, 0}, L6 = {0, 0, 0, 0};
+                    const v4i32* __restrict__ B2 = reinterpret_cast<const v4i32*>(IB2) + ((size_t)st * 4 + (size_t)t) * TU2 + lane;
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb) {
+                        const v4i32 b5 = B2[(kb * 2 + 0) * 64], b6 = B2[(kb * 2 + 1) * 64];
+                        const v4i32 a5 = a56[wave][kb][0][lane], a6 = a56[wave][kb][1][lane];
+                        v4i32 b[NS];
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) b[s] = Bp[((tl * NKB + kb) * NS + s) * 64];
+                        L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][0], b5, L5, 0, 0, 0);
+                        L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][0], b6, L6, 0, 0, 0);
+                        L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][1], b[4], L5, 0, 0, 0);
+                        L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][1], b5, L6, 0, 0, 0);
+                        L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][2], b[3], L5, 0, 0, 0);
+                        L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][2], b[4], L6, 0, 0, 0);
+                        L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][3], b[2], L5, 0, 0, 0);
+                        L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][3], b[3], L6, 0, 0, 0);
+                        L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][4], b[1], L5, 0, 0, 0);
+                        L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][4], b[2], L6, 0, 0, 0);
+                        L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a5, b[0], L5, 0, 0, 0);
+                        L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a5, b[1], L6, 0, 0, 0);
+                        L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a6, b[0], L6, 0, 0, 0);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        // the two level sums are exact (small integers times powers of two); ONE rounding, of the final sum
+                        const double d7 = d[r] + __builtin_fma((double)L5[r], ip.wt[5], (double)L6[r] * ip.wt[6]);
+                        // Per VALUE: only a d at or below T is replaced, so what an (item, bin) pair gets never depends on which
+                        // items share its wave or on how a batch was cut (the rule of literal_tile()).
+                        const bool take = VAL || !(fabs(d[r]) > tacc_d);
+                        d[r] = take ? d7 : d[r];
+                    }
+                }
+                // items whose coefficients are not a projector's (non-finite or garbage covariance): scan_mfma_kernel's fp64
+                // form for their rows, bit for bit (a wave-uniform branch, taken by waves that hold such an item)
+                if (VAL || any_insane) {
+                    const v4f64 ex = exact16<M>(Qs, FB, itn, g, lane, qstride, st, t);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            key_insert_new<NMAX>(key[r], make_key(acc[t][r], (bin + t < res) ? bin + t : nobin, keep_mask));
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (VAL) {
+                            const float r5 = (float)(fabs(d5[r] - ex[r]) / ip.e_bound);
+                            const float r7 = (float)(fabs(d[r] - ex[r]) / (ip.e_refined + 0x1p-50 * fabs(ex[r])));
+                            const bool counts = sane_r[r] && row_ok[r] && bin + t < res;        // (NaN never counts)
+                            if (counts && r5 > worst5) worst5 = r5;
+                            if (counts && r7 > worst7) worst7 = r7;
+                        }
+                        d[r] = (VAL || !sane_r[r]) ? ex[r] : d[r];
+                    }
+                }
+                // bins outside the table (last step of a row): zero digits gave d = 0; they must never be selected
+                const bool inside = bin + t < res;
+                if (tail_step) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d[r] = inside ? d[r] : 1e300;
+                }
+                // Top-n gate and near-null vote of scan_mfma_kernel, per tile
+                bool hit = false, low = false;
+                if constexpr (SPEC) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float fd = fabsf((float)d[r]);
+                        hit |= (fd <= gate_f[r]);
+                        low |= (fd <= below_f);
+                        sv[r][t] = __builtin_amdgcn_rcpf(fd);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        hit |= (fabs(d[r]) <= gate_d[r]);
+                        low |= (fabs(d[r]) <= below_d);
+                    }
+                }
+                if (__any(hit)) {
+                    if (refine_on && __any(low)) {          // near-null values: the reference's literal form, per value
+                        const v4f64 lit = literal16<M>(rf.Gs, rf.TB, itn, g, qstride, nn, bin + t);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool redo = (fabs(d[r]) <= rf.below) && inside;
+                            d[r] = redo ? lit[r] : d[r];
+                            refined += (redo && row_ok[r]) ? 1u : 0u;
+                            if constexpr (SPEC) sv[r][t] = strength_f32(fabs(d[r]));
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        key_insert_new<NMAX>(key[r], make_key(d[r], inside ? bin + t : nobin, keep_mask));
                         const uint64_t kb = __builtin_bit_cast(uint64_t, key[r][NMAX - 1]) | (uint64_t)(~keep_mask);
-                        gate_d[r] = fmax(__builtin_bit_cast(double, kb), tacc_d);
+                        gate_d[r] = fmax(__builtin_bit_cast(double, kb), below_d);
                         gate_f[r] = (float)gate_d[r];
                     }
                 }
@@ -341,10 +414,10 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // ... then this step's spectrum stores, then the barrier
             if (last_p) {
-                if constexpr (SPEC) {
+                if constexpr (SPEC && !(ABL & 1)) {
                     const int step_off = (int)(st * 256u);
                     if constexpr (VEC4) {
-                        if (st * 64 + 64 <= res) {              // wave-uniform: whole step inside the row
+                        if (!tail_step) {                       // wave-uniform: whole step inside the row
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
                                 if (row_ok[r]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, (1 | 2 | 16));
@@ -363,6 +436,9 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
                                     __builtin_amdgcn_raw_buffer_store_b32(u[t], spec_rsrc, (int)(soff[r] + 4u * t), step_off, (1 | 2 | 16));
                         }
                     }
+                } else if constexpr (SPEC) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(sv[r]));
                 }
             }
             __syncthreads();
@@ -377,16 +453,20 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
     }
     if (stat && lane == 0) {
         if (fell) atomicAdd(stat, (unsigned long long)fell);
-        atomicAdd(stat + 1, (unsigned long long)(st_end - st_begin));
+        atomicAdd(stat + 1, (unsigned long long)(st_end - st_begin) * 4ull);
     }
     if constexpr (VAL) {
-        unsigned int wb = __builtin_bit_cast(unsigned int, worst);
+        unsigned int w5 = __builtin_bit_cast(unsigned int, worst5), w7 = __builtin_bit_cast(unsigned int, worst7);
 #pragma unroll
         for (int msk = 1; msk < 64; msk <<= 1) {
-            const unsigned int o = __shfl_xor(wb, msk, 64);
-            wb = o > wb ? o : wb;
+            const unsigned int o5 = __shfl_xor(w5, msk, 64), o7 = __shfl_xor(w7, msk, 64);
+            w5 = o5 > w5 ? o5 : w5;
+            w7 = o7 > w7 ? o7 : w7;
         }
-        if (lane == 0 && margin) atomicMax(margin, (unsigned long long)wb);     // ratio >= 0: its bits order like the value
+        if (lane == 0 && margin) {                                 // ratios >= 0: their bits order like the values
+            atomicMax(margin, (unsigned long long)w5);
+            atomicMax(margin + 1, (unsigned long long)w7);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

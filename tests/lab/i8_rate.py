@@ -59,7 +59,7 @@ for M, NE, N, RES, B, kind, snr in CASES:
             ref = got
         rel = float(((got[1].double() - ref[1].double()).abs() / ref[1].double()).max())
         same_bins = float((got[0] == ref[0]).float().mean())
-        print("m%d n%d N%d res%d %6d items %-10s %2.0f dB %-10s: %.3f ms/step -> %.3e items/s | cov %.3f evd %.3f scan %.3f merge %.3f | fp64 steps %s | vs fp64 scan: worst %.2e, same bins %.4f"
+        print("m%d n%d N%d res%d %6d items %-10s %2.0f dB %-10s: %.3f ms/step -> %.3e items/s | cov %.3f evd %.3f scan %.3f merge %.3f | refined tiles %s | vs fp64 scan: worst %.2e, same bins %.4f"
               % (M, NE, N, RES, B, kind, snr, label, ms, B / ms * 1e3, *[s[0] / max(1, s[1]) for s in st],
                  ("%.2f %%" % (100.0 * fell[0] / max(1, fell[1]))) if fell[1] else "-", rel, same_bins), flush=True)
     del x, spec
