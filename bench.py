@@ -11,7 +11,10 @@ timing   : W warm-up steps, then EXACTLY K steps between barrier + synchronize o
            steps, each bracketed the same way) until >= --min-seconds of timed work has accumulated; the line
            reports the MEDIAN round (ms_per_step, value) and lists every round under "rounds".
 N GPUs   : one process per GPU, streams dealt s mod N, NO data-path collective; torch.distributed (RCCL) only
-           provides the barrier and the max-over-ranks clock.  scaling = weak (per-GPU work fixed).  "ranks" lists
+           provides the barrier and the max-over-ranks clock.  --scaling weak (default; per-GPU work fixed: 8 streams per
+           GPU) or --scaling strong = BASELINE configs[3] as written: the SAME 64 streams (seed 1002 + s) at every N,
+           dealt s mod N, a step = every stream of the rank once (groups of 8 streams per launch sequence), so N = 1
+           runs 2,097,152 items per step (17 GB in, 30 GB out, device-resident) and N = 8 262,144 per GPU.  "ranks" lists
            what every rank processed (asserted to be N entries).  Started either by the driver's
            `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` or as plain
            `python bench.py --gpus N`, which re-runs itself under that launcher (self_launch); a WORLD_SIZE that is
@@ -49,6 +52,7 @@ if ROOT not in sys.path:
 M, N_EMIT, NSAMPLES, RES = 4, 2, 1024, 3600
 FREQUENCY, SPACING = 299792458.0, 0.5
 STREAMS_PER_GPU, ITEMS_PER_STREAM = 8, 32768
+STRONG_STREAMS = 64        # BASELINE configs[3]: 64 independent 4-antenna streams, the same ones at every GPU count
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_MFMA_PEAK_TF = 78.6   # AMD datasheet; ubench: v_mfma_f64_16x16x4_f64 = 65 cycles/SIMD -> 77 TF (profiles/r01_ubench_fp64_rates.txt)
 TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03_scan_pmc_traffic.json")
@@ -347,6 +351,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("BAZ_BENCH_SCALING", "weak"),
+                    help="weak: 8 streams per GPU; strong: BASELINE configs[3], the same 64 streams dealt s mod N at every N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary cfg2-no-spectrum / cfg3 / cfg5 measurements")
     ap.add_argument("--ramp-seconds", type=float, default=0.25, help="untimed steady load before warm-up (clock ramp)")
@@ -363,6 +369,8 @@ def main():
     rank, local_rank, world = sharding.dist_env()
     if world != max(1, args.gpus):                           # never print a line whose n_gpus is not what was asked for
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if args.scaling == "strong" and STRONG_STREAMS % world:
+        raise SystemExit("--scaling strong deals %d streams: --gpus must divide it" % STRONG_STREAMS)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MUSIC-DoA path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -381,11 +389,19 @@ def main():
     arr, table = helper_table(np, synth, M, RES)
 
     # this rank's streams: global stream s lives on rank s mod world (config 4), seed = 1002 + s
-    n_streams = STREAMS_PER_GPU * world
+    strong = args.scaling == "strong"
+    n_streams = STRONG_STREAMS if strong else STREAMS_PER_GPU * world
     mine = sharding.streams_of_rank(n_streams, world, rank)
     batch = len(mine) * ITEMS_PER_STREAM
-    x = torch.cat([synth.synth_stream(torch, dev, ITEMS_PER_STREAM, M, NSAMPLES, arr, FREQUENCY, SPACING,
-                                      seed=1002 + s) for s in mine], dim=0)
+    # a launch sequence covers a group of up to 8 streams (262,144 items: the weak mode's whole step); the strong mode's
+    # step walks the rank's groups one after the other on the same stream
+    group_items = min(len(mine), STREAMS_PER_GPU) * ITEMS_PER_STREAM
+    assert batch % group_items == 0
+    n_groups = batch // group_items
+    x = torch.empty(batch, 2 * NSAMPLES, dtype=torch.float32, device=dev)
+    for i, s_id in enumerate(mine):
+        x[i * ITEMS_PER_STREAM:(i + 1) * ITEMS_PER_STREAM] = synth.synth_stream(
+            torch, dev, ITEMS_PER_STREAM, M, NSAMPLES, arr, FREQUENCY, SPACING, seed=1002 + s_id).reshape(ITEMS_PER_STREAM, -1)
     ang = torch.zeros(batch, N_EMIT, dtype=torch.float32, device=dev)
     lvl = torch.zeros_like(ang)
     spec = torch.zeros(batch, RES, dtype=torch.float32, device=dev)
@@ -394,11 +410,15 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     ctx = capi.Context(M, N_EMIT, NSAMPLES, RES, table, device_id=local_rank)
     ctx.set_stream(stream.cuda_stream)
-    ctx.reserve(batch)
+    ctx.reserve(group_items)
     torch.cuda.synchronize()
+    xb, ab, lb, sb = x.data_ptr(), ang.data_ptr(), lvl.data_ptr(), spec.data_ptr()
+    x_row, al_row, sp_row = 8 * NSAMPLES, 4 * N_EMIT, 4 * RES            # bytes per item
 
     def step():
-        ctx.process_device(x.data_ptr(), batch, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr())
+        for gi in range(n_groups):
+            o = gi * group_items
+            ctx.process_device(xb + o * x_row, group_items, ab + o * al_row, lb + o * al_row, sb + o * sp_row)
 
     # Clock ramp (untimed, before the W warm-up steps): the GPU's power management needs tens of milliseconds of
     # continuous load to leave its idle clocks -- a 3-step (1 ms) warm-up measures the ramp, not the steady state a
@@ -458,7 +478,7 @@ def main():
 
     if rank == 0:
         scan_avg_s = scan_ms_total / max(scan_launches, 1) * 1e-3
-        scan_bytes = (4 * RES + 8 * N_EMIT) * batch                 # spectrum + ang/lvl-equivalent written per launch
+        scan_bytes = (4 * RES + 8 * N_EMIT) * group_items           # spectrum + ang/lvl-equivalent written per launch
         achieved = scan_bytes / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
         src_sha = kernel_sources_sha()
         traffic, traffic_stale, traffic_src = None, None, None
@@ -466,14 +486,14 @@ def main():
             try:
                 tinfo = json.load(open(TRAFFIC_PROFILE))
                 traffic_src = os.path.relpath(TRAFFIC_PROFILE, ROOT)
-                if tinfo.get("kernel_sources_sha") == src_sha and tinfo.get("items_per_launch") == batch:
+                if tinfo.get("kernel_sources_sha") == src_sha and tinfo.get("items_per_launch") == group_items:
                     traffic, traffic_stale = tinfo.get("scan_hbm_bytes_per_launch"), False
                 else:
                     traffic_stale = True                            # profile of other code / launch size: not reported
             except Exception:
                 traffic_stale = True
         cov_s = stage[capi.STAGE_COV][0] / max(stage[capi.STAGE_COV][1], 1) * 1e-3
-        cov_tf = 8.0 * M * NSAMPLES * batch / cov_s / 1e12 if cov_s > 0 else 0.0
+        cov_tf = 8.0 * M * NSAMPLES * group_items / cov_s / 1e12 if cov_s > 0 else 0.0
         x4 = "cov4_" in cov_name
         fused = "cov4_evd" in cov_name
         cov_mfma = {"kernel": cov_name,
@@ -481,8 +501,8 @@ def main():
                                         "which HBM idles (DESIGN.md 5.1); the rates below divide by the WHOLE kernel's "
                                         "time, the stream alone runs at ~7 TB/s" if fused else None, "useful_tflops": cov_tf, "fp64_matrix_peak_tflops": FP64_MFMA_PEAK_TF,
                     "frac_of_peak": cov_tf / FP64_MFMA_PEAK_TF, "issued_over_useful": 4.0 / 3.0 if x4 else 2.0,
-                    "hbm_read_GBs": 8.0 * NSAMPLES * batch / cov_s / 1e9 if cov_s > 0 else 0.0,
-                    "hbm_read_frac_of_8TBs": 8.0 * NSAMPLES * batch / cov_s / 1e9 / HBM_PEAK_GBS if cov_s > 0 else 0.0,
+                    "hbm_read_GBs": 8.0 * NSAMPLES * group_items / cov_s / 1e9 if cov_s > 0 else 0.0,
+                    "hbm_read_frac_of_8TBs": 8.0 * NSAMPLES * group_items / cov_s / 1e9 / HBM_PEAK_GBS if cov_s > 0 else 0.0,
                     "note": ("v_mfma_f64_4x4x4_4b blocks: X0X0^T, X0X1^T, X1X1^T + one transposed duplicate per pair of "
                              "instructions; dwordx4 input stream; HBM-read bound while it streams") if x4 else
                             ("16x16x4 fp64 MFMA tiles hold 2 items block-diagonally at m=4 (half the issued flops are "
@@ -491,16 +511,19 @@ def main():
         line = {
             "metric": "MUSIC-DoA snapshots/s (4 ant, 1024 samp, 3600 bins)",
             "value": value, "unit": "snapshots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": t_med / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": t_med / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "rounds": {"count": len(rounds), "steps_each": args.steps, "statistic": "median",
                        "ms_per_step_min": min(per_round), "ms_per_step_max": max(per_round),
                        "timed_seconds_total": timed_total},
             "kernel_sources_sha": src_sha,
             "config": {"workload": "cfg2 (BASELINE.json configs[1]): m=4 n=2 nsamples=1024 (K=256) resolution=3600, "
-                                   "spectrum port wired, %d streams x %d items per GPU per step, device-resident"
-                                   % (STREAMS_PER_GPU, ITEMS_PER_STREAM),
-                       "items_per_gpu_per_step": batch, "parallelism": "independent streams, s mod %d, no collective" % world,
+                                   "spectrum port wired, %d streams x %d items per GPU per step, device-resident%s"
+                                   % (len(mine), ITEMS_PER_STREAM,
+                                      " (configs[3]: the same %d streams at every GPU count, dealt s mod N)" % STRONG_STREAMS if strong else ""),
+                       "items_per_gpu_per_step": batch, "items_per_step_all_gpus": int(total_items / args.steps + 0.5),
+                       "streams_total": n_streams, "launch_sequences_per_step": n_groups, "items_per_launch_sequence": group_items,
+                       "parallelism": "independent streams, s mod %d, no collective" % world,
                        "collective_backend_for_barrier_and_clock": backend, "ranks": ranks,
                        "algorithmic_bytes_per_item": bpi,
                        "pipeline_hbm_fraction_of_8TBs": value / world * bpi / 8e12,
@@ -533,8 +556,16 @@ def main():
                     ("cfg2_snr60", lambda: dict(extra_music(torch, np, capi, synth, dev, stream, 4, 1024, 3600, 262144, True, 0.4, snr_db=60.0),
                                                 workload="cfg2, spectrum port wired, 60 dB SNR: near-null values are recomputed in the reference's "
                                                          "literal form inside the scan")),
+                    ("cfg2_incoherent_snr60", lambda: dict(
+                        extra_music(torch, np, capi, synth, dev, stream, 4, 1024, 3600, 262144, True, 0.4, scene="incoherent", snr_db=60.0),
+                        workload="cfg2, spectrum port wired, emitter angles drawn per ITEM at 60 dB SNR: the product of the two unfavourable "
+                                 "cases (every wave's 16 items have their nulls in different bins, and the nulls need the literal form)")),
+                    ("cfg2_incoherent_snr60_without_spectrum_port", lambda: dict(
+                        extra_music(torch, np, capi, synth, dev, stream, 4, 1024, 3600, 262144, False, 0.4, scene="incoherent", snr_db=60.0),
+                        workload="the same with only ang/lvl wired")),
                     ("cfg3", lambda: dict(extra_music(torch, np, capi, synth, dev, stream, 8, 4096, 36000, 16384, True, 0.5),
-                                          bound="fp64 matrix (scan: 2*m^2 flop per item and bin)",
+                                          bound="spectrum stores (HBM write) + int8 matrix core / level combination on the vector unit "
+                                                "(scan_i8_kernel; BAZ_MUSIC_EXACT=1: fp64 matrix, 2*m^2 flop per item and bin)",
                                           workload="BASELINE configs[2]: m=8 n=2 nsamples=4096 (K=512) resolution=36000, spectrum wired")),
                     ("cfg3_without_spectrum_port", lambda: dict(
                         extra_music(torch, np, capi, synth, dev, stream, 8, 4096, 36000, 16384, False, 0.4),
@@ -556,6 +587,30 @@ def main():
                     extra[name] = {"error": repr(e)}
                 torch.cuda.empty_cache()
             extra["cfg2_host_fed_gr37_model"] = host_fed_extra()
+            # the secondary claims as SCALAR keys of config (a driver that keeps only scalar config keys still carries them;
+            # the dicts they come from follow under "extra")
+            def pick(name, *path):
+                v = extra.get(name, {})
+                for k in path:
+                    v = v.get(k) if isinstance(v, dict) else None
+                return v
+            cfgd = line["config"]
+            cfgd["default_wiring_snapshots_per_s"] = pick("cfg2_without_spectrum_port", "snapshots_per_s")
+            cfgd["default_wiring_hbm_read_frac"] = pick("cfg2_without_spectrum_port", "hbm_read_fraction_of_8TBs")
+            cfgd["incoherent_snapshots_per_s"] = pick("cfg2_incoherent_scene", "snapshots_per_s")
+            cfgd["incoherent_default_wiring_snapshots_per_s"] = pick("cfg2_incoherent_scene_without_spectrum_port", "snapshots_per_s")
+            cfgd["snr60_snapshots_per_s"] = pick("cfg2_snr60", "snapshots_per_s")
+            cfgd["incoherent_snr60_snapshots_per_s"] = pick("cfg2_incoherent_snr60", "snapshots_per_s")
+            cfgd["incoherent_snr60_default_wiring_snapshots_per_s"] = pick("cfg2_incoherent_snr60_without_spectrum_port", "snapshots_per_s")
+            cfgd["cfg3_snapshots_per_s"] = pick("cfg3", "snapshots_per_s")
+            cfgd["cfg3_scan_ms"] = pick("cfg3", "stage_ms_per_launch", "scan")
+            cfgd["cfg3_scan_frac_of_hbm_8TBs"] = pick("cfg3", "scan_frac_of_hbm_8TBs")
+            cfgd["cfg3_pipeline_hbm_frac"] = pick("cfg3", "pipeline_hbm_fraction_of_8TBs")
+            cfgd["cfg3_default_wiring_snapshots_per_s"] = pick("cfg3_without_spectrum_port", "snapshots_per_s")
+            cfgd["cfg5_chain_snapshots_per_s"] = pick("cfg5_chain", "snapshots_per_s")
+            cfgd["cfg5_chain_hbm_frac"] = pick("cfg5_chain", "chain_hbm_fraction_of_8TBs")
+            cfgd["cfg5_chain_music_scan_ms"] = pick("cfg5_chain", "music_stage_ms", "scan")
+            cfgd["host_fed_pinned_with_port2_items_per_s"] = pick("cfg2_host_fed_gr37_model", "runs", "with_spectrum_port_page_locked_buffers", "items_per_s")
             line["config"]["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(table)

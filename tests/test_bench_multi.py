@@ -43,6 +43,41 @@ def test_bench_two_ranks_share_one_gpu(gpu_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_strong_scaling_is_config_4_as_written(gpu_device):
+    """BASELINE configs[3] / SURVEY.md 8d cfg4: the SAME 64 streams at every GPU count, dealt s mod G.  N = 1 runs all
+    2,097,152 items per step (8 launch sequences of 262,144); at N = 2 every rank holds 32 disjoint streams and half the
+    items, and the whole-job items per step do not change."""
+    common = ("--scaling", "strong", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--min-seconds", "0.05",
+              "--ramp-seconds", "0.05")
+    r1, one = _bench("--gpus", "1", *common)
+    assert r1.returncode == 0 and one is not None, r1.stderr[-2000:]
+    assert one["scaling"] == "strong" and one["n_gpus"] == 1
+    c1 = one["config"]
+    assert c1["items_per_gpu_per_step"] == 2097152 == c1["items_per_step_all_gpus"] and c1["streams_total"] == 64
+    assert c1["ranks"][0]["streams"] == list(range(64)) and c1["launch_sequences_per_step"] == 8
+    assert abs(one["value"] - 2097152 / (one["ms_per_step"] * 1e-3)) <= 1e-6 * one["value"]
+    r2, two = _bench("--gpus", "2", *common, env={"BAZ_BENCH_SHARE_DEVICES": "1"})
+    assert r2.returncode == 0 and two is not None, r2.stderr[-2000:]
+    assert two["scaling"] == "strong" and two["n_gpus"] == 2
+    ranks = two["config"]["ranks"]
+    s0, s1 = set(ranks[0]["streams"]), set(ranks[1]["streams"])
+    assert not (s0 & s1) and sorted(s0 | s1) == list(range(64))          # disjoint and complete
+    assert s0 == set(range(0, 64, 2)) and s1 == set(range(1, 64, 2))     # s mod 2
+    assert all(r["items_per_step"] == 1048576 for r in ranks)            # half the items per rank ...
+    assert two["config"]["items_per_step_all_gpus"] == 2097152           # ... the same job
+    assert 0.5 * one["value"] <= two["value"] <= 1.5 * one["value"], (one["value"], two["value"])   # one shared device
+
+
+def test_bench_strong_scaling_needs_a_gpu_count_that_divides_64():
+    e = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--scaling", "strong", "--steps", "1"],
+                       capture_output=True, text=True, timeout=240, cwd=ROOT, env=e)
+    assert r.returncode != 0 and "must divide" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(300)
 def test_bench_refuses_more_ranks_than_devices(gpu_device):
     import torch
