@@ -132,6 +132,8 @@ struct baz_music_ctx {
     bool i8_ok = false;            // image built (finite table, scale representable, size within I8_IMAGE_LIMIT)
     int i8_on = 1;                 // BAZ_MUSIC_EXACT=1: every value on the fp64 matrix core (A/B; the round-3 scan)
     int i8_abl = 0;                // lab (BAZ_MUSIC_I8_ABL): ablation mask of scan_i8_kernel (timing only)
+    uint32_t num_cus = 256;        // compute units of the device (launch geometry of scan_i8_kernel)
+    int i8_wgs_per_cu[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};   // [NMAX > 2][SPEC][VEC4]: resident workgroups per CU (occupancy API, on first use)
     unsigned long long* dI8Stat = nullptr;   // [0] wave tiles that ran the refined form, [1] wave tiles walked, [2], [3] VAL margins
     int peak_mode = 0;      // 0: the reference's n strongest bins; 1 (opt-in extension): n strongest local maxima
     float* dPeakSpec = nullptr;   // internal spectrum when peak mode runs without the spectrum port
@@ -378,13 +380,18 @@ bool build_i8_image(const std::vector<double>& F, uint32_t m, uint32_t res, uint
     if (!(fmax > 0.0)) return false;
     int ex = 0;
     (void)std::frexp(fmax / I8_QMAX, &ex);          // fmax / QMAX = f 2^ex, f in [0.5, 1)  ->  fmax / 2^ex < QMAX
-    if (ex < -400 || ex > 400) return false;
+    // (float) wt[3] = Fscale 2^-36 must scale the bulk form's integer V in [1, 2^48) without leaving the normal float range
+    if (ex < -88 || ex > 100) return false;
     const double fscale = std::ldexp(1.0, ex);
     const double sq = std::ldexp(1.0, 8 * ND - 2), sf = sq / fscale;
     for (int l = 0; l < ND; ++l) ip.wt[l] = std::ldexp(fscale, -12 - 8 * l);
     ip.sq = sq;
-    ip.e_bound = (double)mm * fscale * (double)NS * 1.01 * std::ldexp(1.0, 2 - 8 * NS);
+    // digits cut off + levels dropped + the low byte of the level-4 sum (scan_i8_kernels.hip.h, "Error bound")
+    ip.e_bound = (double)mm * fscale * (double)NS * 1.01 * std::ldexp(1.0, 2 - 8 * NS) + fscale * std::ldexp(1.0, -12 - 8 * (NS - 2));
     ip.t_acc = ip.e_bound * (1.0 + 1.0 / I8_EPS);
+    ip.ws_f = (float)ip.wt[NS - 2];
+    ip.t_acc_f = (float)ip.t_acc;
+    if ((double)ip.t_acc_f < ip.t_acc) ip.t_acc_f = std::nextafterf(ip.t_acc_f, INFINITY);
     // (VAL) the refined form against the fp64 form it is compared with: its own digits (7.07 2^-54 MM Fscale) plus the fp64
     // form's accumulation error, <= MM 2^-53 sum_e |q_e F_e| <= MM^2 2^-53 Fscale in the worst case
     ip.e_refined = (double)mm * fscale * std::ldexp(1.0, -54) * (7.07 + 2.0 * (double)mm);
@@ -615,6 +622,30 @@ ScanGeom scan_geometry(uint32_t batch, uint32_t nsteps, uint32_t nclass, int for
     return G;
 }
 
+// Bin ranges per item of scan_i8_kernel: its workgroups (4 waves x 16 items, one range of 64-bin steps) should fill the
+// slots the chip holds at once -- `slots` = CUs x resident workgroups per CU -- a whole number of times: 16,384 config-3 items
+// are 256 groups; 8 ranges made 2,048 workgroups for 768 slots, 2.67 rounds of which the last ran a third empty, where 3 ranges
+// fill every slot exactly once (and restart the top-n lists 3 times instead of 8).  Up to 8 rounds are tried; the fewest
+// rounds within 3 % of the best filling win.  Ranges of fewer than 4 steps are not made.
+constexpr uint32_t I8_MAX_NSPLIT = 16;
+uint32_t i8_nsplit(uint32_t batch, uint32_t nsteps, uint32_t slots, int force_nsplit)
+{
+    const uint32_t groups = std::max<uint32_t>(1u, (batch + 63) / 64);
+    const uint32_t cap = std::max<uint32_t>(1u, std::min<uint32_t>(I8_MAX_NSPLIT, nsteps / 4));
+    if (force_nsplit > 0) return std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)force_nsplit, std::min<uint32_t>(nsteps, 64u)));
+    uint32_t best = 1;
+    double best_fill = 0.0;
+    for (uint32_t r = 1; r <= 8; ++r) {
+        const uint32_t ns = std::max<uint32_t>(1u, std::min<uint32_t>(cap, (uint32_t)(((uint64_t)r * slots) / groups)));
+        const uint64_t blocks = (uint64_t)groups * ns;
+        const uint64_t rounds = (blocks + slots - 1) / slots;
+        const double fill = (double)blocks / (double)(rounds * slots);
+        if (fill > best_fill * 1.03) { best_fill = fill; best = ns; }
+        if (ns == cap) break;
+    }
+    return best;
+}
+
 int ensure_candidates(baz_music_ctx* c, size_t entries)
 {
     if (entries <= c->cand_cap) return BAZ_MUSIC_OK;
@@ -686,7 +717,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             return BAZ_MUSIC_OK;
         }
     }
-    const ScanGeom G = scan_geometry(batch, c->fb_steps, c->nclass, c->force_nsplit, c->m);
+    ScanGeom G = scan_geometry(batch, c->fb_steps, c->nclass, c->force_nsplit, c->m);
     c->last_nsplit = G.nsplit;
     double* cand = c->dCand;
     if ((size_t)batch * G.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;   // reserve_candidates() sized it
@@ -705,6 +736,21 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             rf.below = c->refine_below;
             rf.count = c->dRefined + c->stat_parity;
             rf.A2 = nullptr;
+            // its own bin ranges: whole rounds of the resident workgroup slots (i8_nsplit)
+            int& per_cu = c->i8_wgs_per_cu[NMAX > 2 ? 1 : 0][spec ? 1 : 0][vec4 ? 1 : 0];
+            if (per_cu == 0) {
+                int occ = 0;
+                hipError_t oe;
+                if (spec && vec4) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_i8_kernel<M, NMAX, true, true>, 256, 0);
+                else if (spec) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_i8_kernel<M, NMAX, true, false>, 256, 0);
+                else oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_i8_kernel<M, NMAX, false, false>, 256, 0);
+                per_cu = (oe == hipSuccess && occ > 0) ? occ : 2;
+                (void)hipGetLastError();
+            }
+            G.nsplit = i8_nsplit(batch, c->fb_steps, c->num_cus * (uint32_t)per_cu, c->force_nsplit);
+            G.blocks = (G.groups / 4) * G.nsplit;
+            c->last_nsplit = G.nsplit;
+            if ((size_t)batch * G.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;
 #define BAZ_I8_LAUNCH(SPEC, VEC4)                                                                                       \
     hipLaunchKernelGGL((scan_i8_kernel<M, NMAX, SPEC, VEC4>), dim3(G.blocks), dim3(256), 0, c->stream, dQ, c->dIB,      \
                        c->dIB + i8_image_bytes5(c->m, c->fb_steps) / 16, c->dFB + c->fb_step_elems, d_spec, cand, batch, c->res, qstride, G.nsplit, c->keep_mask, c->n, rf, \
@@ -718,11 +764,11 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
                        qstride, G.nsplit, c->keep_mask, c->n, rf, c->i8, c->dI8Stat, nullptr)
                     switch (c->i8_abl) {
                         case 1: BAZ_I8_ABL(1); break;      // no spectrum stores
-                        case 2: BAZ_I8_ABL(2); break;      // no level combination
-                        case 3: BAZ_I8_ABL(3); break;
                         case 4: BAZ_I8_ABL(4); break;      // no MFMAs
-                        case 6: BAZ_I8_ABL(6); break;
-                        default: BAZ_I8_ABL(7); break;     // staging, LDS reads, barriers, gate only
+                        case 5: BAZ_I8_ABL(5); break;
+                        case 8: BAZ_I8_ABL(8); break;      // no staging loads, waits, barriers
+                        case 9: BAZ_I8_ABL(9); break;      // ... and no stores: the tiles' arithmetic alone
+                        default: BAZ_I8_ABL(13); break;    // LDS reads and the per-value vector work alone
                     }
 #undef BAZ_I8_ABL
                     HIP_TRY(c, hipGetLastError());
@@ -830,6 +876,7 @@ size_t cand_entries(const baz_music_ctx* c, uint32_t nb)
 {
     size_t per_item = scan_geometry(nb, c->fb_steps, c->nclass, c->force_nsplit, c->m).nsplit;
     if (c->m <= 8 && c->dCS) per_item = std::max<size_t>(per_item, coarse_geometry(c, nb).nsplit);
+    if (c->dIB) per_item = std::max<size_t>(per_item, c->force_nsplit > 0 ? (size_t)std::min<uint32_t>((uint32_t)c->force_nsplit, 64u) : I8_MAX_NSPLIT);
     return (size_t)nb * per_item * topn_list_len(c->n);
 }
 
@@ -843,9 +890,12 @@ size_t cand_entries_upto(const baz_music_ctx* c, uint32_t batch)
     const size_t cap_split = std::min<size_t>(64u, std::max<uint32_t>(1u, c->fb_steps));
     const size_t worst = std::min<size_t>((size_t)batch * cap_split, 16u * want_tasks + (size_t)batch);
     const size_t forced = c->force_nsplit > 0 ? (size_t)batch * std::min<size_t>((size_t)c->force_nsplit, cap_split) : 0;
-    // the coarse-gated scan: nsplit = ceil(COARSE_WANT_BLOCKS / ceil(nb / 128)) <= 16  ->  nb * nsplit <= 128 * WANT + nb
-    const size_t coarse = (c->m <= 8) ? std::min<size_t>((size_t)batch * 16u, 128u * COARSE_WANT_BLOCKS + (size_t)batch) : 0;
-    return std::max(std::max(std::max(worst, forced), coarse), (size_t)batch) * topn_list_len(c->n);
+    // the coarse-gated scan: nsplit = ceil(COARSE_WANT_BLOCKS / ceil(nb / (64 rg))) <= 16, rg <= 4 row groups per wave
+    // ->  nb * nsplit <= 256 * WANT + nb
+    const size_t coarse = (c->m <= 8) ? std::min<size_t>((size_t)batch * 16u, 256u * COARSE_WANT_BLOCKS + (size_t)batch) : 0;
+    // the int8 scan: nsplit <= r slots / ceil(nb / 64) with r <= 8 rounds of <= 4 x 256-CU slots, and <= I8_MAX_NSPLIT
+    const size_t i8 = c->dIB ? std::min<size_t>((size_t)batch * I8_MAX_NSPLIT, (size_t)64u * 8u * 4u * c->num_cus + (size_t)batch) : 0;
+    return std::max(std::max(std::max(std::max(worst, forced), coarse), i8), (size_t)batch) * topn_list_len(c->n);
 }
 
 int reserve_candidates(baz_music_ctx* c, uint32_t batch)
@@ -1568,6 +1618,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
             // 6 (the occupancy limit) / 8 per CU, the fewest concurrent input streams read fastest -- 0.370 vs 0.396 ms per
             // 262,144 items inside the pipeline (profiles/r02_cov_grid.txt); more waves only queue more requests.
             c->cov4_resident_blocks = (uint32_t)std::max(1, prop.multiProcessorCount);
+            c->num_cus = (uint32_t)std::max(1, prop.multiProcessorCount);
             if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COV_BLOCKS_PER_CU"))    // lab: grid of the covariance kernel
                 if (atoi(v) > 0) c->cov4_resident_blocks = (uint32_t)atoi(v) * (uint32_t)std::max(1, prop.multiProcessorCount);
         }

@@ -24,8 +24,19 @@
 //                                                                                          ->  <= MM Fscale 2^-38 1.006
 //     levels dropped    pairs (s, t) of the five digits with s + t >= 5: <= MM 128^2 4 256^3 1.005 of the integer product
 //                                                                                          ->  <= MM Fscale 4 2^-38 1.005
-//     E5 = MM Fscale 5 1.01 2^-38          (m = 8: 1.2e-9 Fscale; m = 16: 4.7e-9 Fscale;  ||a||^2 = m for the helper's tables)
+//     level 4 cut       the bulk form keeps floor(A_4 / 256) of the level-4 sum, folded into the level-3 accumulator (below):
+//                                                                                          ->  <= Fscale 2^-36
+//     E5 = MM Fscale 5 1.01 2^-38 + Fscale 2^-36   (m = 8: 1.2e-9 Fscale; m = 16: 4.7e-9 Fscale;  ||a||^2 = m for the helper's tables)
 // A value is within eps = 7.5e-7 of the true one when d5 > T = E5 (1 + 1 / eps).
+//
+// Bulk form per value (round 4, third form: the vector unit, not the matrix core, bounds this kernel -- 109 vector
+// instructions per tile against 15 MFMAs in the second form, profiles/r04_i8_scan_v2_pmc.txt):  V = (A_0 256 + A_1) 65536 +
+// (A_2 256 + A_3 + floor(A_4 / 256)), an integer below 2^48 built from two int32 words, two conversions and one fp64 FMA;
+// d5 = V wt[3] exactly; (float) V, one multiplication by the power of two (float) wt[3], ONE comparison against the row's
+// threshold max(top-n gate, T), one reciprocal.  Everything else -- the seven-digit form (which adds the cut-off low byte of
+// A_4 back: d7 = d5 + (A_4 mod 256) wt[4] + A_5 wt[5] + A_6 wt[6]), bins outside the table (zero digits: V = 0 is under every
+// threshold), items that are not projectors (zero digits), the literal form near nulls, the key network -- happens behind
+// that one wave-uniform branch.
 //
 // Refined form.  A 16 x 16 tile in which some |d5| <= T (the bottom of the nulls: 0.5 % of the values of a 20-dB scene) adds
 // the levels 5 and 6 of ALL SEVEN digits -- 13 more MFMAs on top of the five accumulators it still holds; digits 5, 6 of q
@@ -76,6 +87,8 @@ struct I8Params {
     double t_acc;         // T = E5 (1 + 1 / eps): at or below it a value takes the refined form
     double e_bound;       // E5 (VAL only)
     double e_refined;     // allowance of the refined form against the fp64 form (VAL only)
+    float ws_f;           // (float) wt[3], a power of two: |d5| as float = |(float) V| ws_f, exactly
+    float t_acc_f;        // the smallest float >= T: |d5| <= T  =>  (float)|d5| <= t_acc_f
 };
 
 // two adjacent levels fit one int32 (a_l 256 + a_(l+1)) while (l + 1) MM 2^22 + (l + 2) MM 2^14 < 2^31
@@ -111,8 +124,13 @@ __device__ __noinline__ v4f64 exact16(const double* __restrict__ Qs, const doubl
     return acc;
 }
 
-// Order of the bulk form's 15 digit pairs (s = digit of q, l = level = s + digit of F): the levels go round so that two
-// MFMAs on the same accumulator are as far apart as the triangle allows (a dependent MFMA waits for its predecessor's passes).
+// Order of the bulk form's 15 digit pairs (s = digit of q, l = level = s + digit of F).
+// One block of 64 terms (m <= 8): the level-4 pairs go first, spread between the first pairs of the other levels, because the
+// level-3 accumulator STARTS from floor(A_4 / 256) (its C operand: four shifts per tile instead of a shift and an addition
+// per value); two MFMAs on one accumulator are kept apart (a dependent MFMA waits for its predecessor's passes).
+constexpr int i8_fold_s(int i) { constexpr int t[15] = {0, 1, 0, 2, 0, 3, 1, 4, 0, 1, 0, 2, 1, 2, 3}; return t[i]; }
+constexpr int i8_fold_l(int i) { constexpr int t[15] = {4, 4, 0, 4, 1, 4, 1, 4, 2, 2, 3, 2, 3, 3, 3}; return t[i]; }
+// More blocks (m >= 9): the levels go round, level 4's low byte is dropped by one shift and one addition per value.
 constexpr int i8_order_s(int i) { return i < 5 ? 0 : (i < 9 ? 1 : (i < 12 ? 2 : (i < 14 ? 3 : 4))); }
 constexpr int i8_order_l(int i) { return i < 5 ? 4 - i : (i < 9 ? 9 - i : (i < 12 ? 13 - i : (i < 14 ? 16 - i : 4))); }
 
@@ -120,7 +138,8 @@ constexpr int i8_order_l(int i) { return i < 5 ? 4 - i : (i < 9 ? 9 - i : (i < 1
 // margin[0] / margin[1] = the worst |d5 - d| / E5 and |d7 - d| / allowance over all (item, bin) of items that take the integer
 // forms (float bits, atomicMax); outputs are the fp64 form's.
 // stat (may be nullptr): [0] += wave tiles (16 items x 16 bins) that ran the refined form, [1] += wave tiles walked.
-// ABL (lab builds only): 1 no spectrum stores, 2 no level combination (one conversion per value), 4 no MFMAs -- timing only.
+// ABL (lab builds only): 1 no spectrum stores, 4 no MFMAs, 8 no staging loads, waits or barriers (the tiles read whatever
+// the stage holds) -- timing only.
 template <int M, int NMAX, bool SPEC, bool VEC4, bool VAL = false, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restrict__ Qs, const uint4* __restrict__ IB,
                                                          const uint4* __restrict__ IB2, const double2* __restrict__ FB,
@@ -262,6 +281,15 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
 
     const uint32_t nobin = ~keep_mask;
     const int nn = (int)M - (int)n;
+    constexpr bool FOLD = (NKB == 1);                  // level 3 starts from floor(A_4 / 256) (else: one shift + add per value)
+    constexpr bool PAIR23 = i8_pair_ok(MM, 2);         // A_2 256 + A_3 (+ A_4 / 256) fits an int32 (m <= 13)
+    const double ws_d = ip.wt[NS - 2];                 // weight of the bulk form's integer V (level 3)
+    const float ws_f = ip.ws_f;
+    // the row's threshold of the ONE comparison per value: under it the value may enter the row's list (top-n gate), or
+    // needs the seven-digit form (T), or lies outside the table / belongs to an item without digits (V = 0)
+    float thr_f[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) thr_f[r] = __builtin_inff();
     for (uint32_t st = st_begin; st < st_end; ++st) {
         const uint32_t bin = st * 64 + 4 * (uint32_t)c;          // this lane's first bin of the step (tile t: bin + t)
         const bool tail_step = st * 64 + 64 > res;               // wave-uniform: the step reaches beyond the table
@@ -269,149 +297,180 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
         for (int p = 0; p < PPS; ++p) {
             const bool last_p = (p == PPS - 1);
             const bool more = !last_p || (st + 1 < st_end);      // wave-uniform
-            if (more) stage_load(last_p ? st + 1 : st, last_p ? 0 : p + 1, buf ^ 1);
+            if constexpr (!(ABL & 8)) {
+                if (more) stage_load(last_p ? st + 1 : st, last_p ? 0 : p + 1, buf ^ 1);
+            }
             if (p == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(sv[r]));      // (see scan_mfma_kernel: the store data stays put)
             }
 
-            // the phase's tiles, one at a time: 15 NKB int8 MFMAs, the levels of every value combined in fp64, and
-            // scan_mfma_kernel's epilogue for the tile's 4 values per lane (gate, literal form near nulls, keys, reciprocals)
             const v4i32* __restrict__ Bp = reinterpret_cast<const v4i32*>(&stage[buf][0]) + lane;
 #pragma unroll
             for (int tl = 0; tl < TPP; ++tl) {
                 const int t = p * TPP + tl;
+                // ---- the tile's 15 NKB int8 MFMAs ------------------------------------------------------------------------
                 v4i32 L[NS];
-#pragma unroll
-                for (int l = 0; l < NS; ++l) L[l] = (v4i32){0, 0, 0, 0};
-#pragma unroll
-                for (int kb = 0; kb < NKB; ++kb) {
+                if constexpr (FOLD) {
                     v4i32 b[NS];
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) b[s] = Bp[((tl * NKB + kb) * NS + s) * 64];
-                    if constexpr (ABL & 4) {
+                    for (int s = 0; s < NS; ++s) b[s] = Bp[(tl * NS + s) * 64];
+                    bool started[NS] = {false, false, false, false, false};
 #pragma unroll
-                        for (int l = 0; l < NS; ++l) L[l] += b[l] ^ A[kb][l];
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 15; ++i) {
-                            const int s = i8_order_s(i), l = i8_order_l(i);
-                            L[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][s], b[l - s], L[l], 0, 0, 0);
-                        }
-                    }
-                }
-                v4f64 d;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if constexpr (ABL & 2) d[r] = (double)(L[0][r] + L[1][r] + L[2][r] + L[3][r] + L[4][r]) * ip.wt[2];
-                    else {
-                        const int a[NS] = {L[0][r], L[1][r], L[2][r], L[3][r], L[4][r]};
-                        d[r] = I8Comb<MM, 0>::run(a, ip.wt);
-                    }
-                }
-                [[maybe_unused]] const v4f64 d5 = d;
-                // Values at or below T: two more digits of both operands (levels 5 and 6 on top of the five accumulated ones:
-                // 13 NKB MFMAs), digits 5, 6 of q from this lane's LDS slot, of F from the image in L2.
-                bool lowt = false;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) lowt |= !(fabs(d[r]) > tacc_d);
-                if (VAL || __any(lowt)) {
-                    ++fell;
-                    v4i32 L5 = {0, 0, 0, 0}, L6 = {0, 0, 0, 0};
-                    const v4i32* __restrict__ B2 = reinterpret_cast<const v4i32*>(IB2) + ((size_t)st * 4 + (size_t)t) * TU2 + lane;
-#pragma unroll
-                    for (int kb = 0; kb < NKB; ++kb) {
-                        const v4i32 b5 = B2[(kb * 2 + 0) * 64], b6 = B2[(kb * 2 + 1) * 64];
-                        const v4i32 a5 = a56[wave][kb][0][lane], a6 = a56[wave][kb][1][lane];
-                        v4i32 b[NS];
-#pragma unroll
-                        for (int s = 0; s < NS; ++s) b[s] = Bp[((tl * NKB + kb) * NS + s) * 64];
-                        L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][0], b5, L5, 0, 0, 0);
-                        L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][0], b6, L6, 0, 0, 0);
-                        L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][1], b[4], L5, 0, 0, 0);
-                        L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][1], b5, L6, 0, 0, 0);
-                        L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][2], b[3], L5, 0, 0, 0);
-                        L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][2], b[4], L6, 0, 0, 0);
-                        L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][3], b[2], L5, 0, 0, 0);
-                        L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][3], b[3], L6, 0, 0, 0);
-                        L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][4], b[1], L5, 0, 0, 0);
-                        L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][4], b[2], L6, 0, 0, 0);
-                        L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a5, b[0], L5, 0, 0, 0);
-                        L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a5, b[1], L6, 0, 0, 0);
-                        L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a6, b[0], L6, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        // the two level sums are exact (small integers times powers of two); ONE rounding, of the final sum
-                        const double d7 = d[r] + __builtin_fma((double)L5[r], ip.wt[5], (double)L6[r] * ip.wt[6]);
-                        // Per VALUE: only a d at or below T is replaced, so what an (item, bin) pair gets never depends on which
-                        // items share its wave or on how a batch was cut (the rule of literal_tile()).
-                        const bool take = VAL || !(fabs(d[r]) > tacc_d);
-                        d[r] = take ? d7 : d[r];
-                    }
-                }
-                // items whose coefficients are not a projector's (non-finite or garbage covariance): scan_mfma_kernel's fp64
-                // form for their rows, bit for bit (a wave-uniform branch, taken by waves that hold such an item)
-                if (VAL || any_insane) {
-                    const v4f64 ex = exact16<M>(Qs, FB, itn, g, lane, qstride, st, t);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if constexpr (VAL) {
-                            const float r5 = (float)(fabs(d5[r] - ex[r]) / ip.e_bound);
-                            const float r7 = (float)(fabs(d[r] - ex[r]) / (ip.e_refined + 0x1p-50 * fabs(ex[r])));
-                            const bool counts = sane_r[r] && row_ok[r] && bin + t < res;        // (NaN never counts)
-                            if (counts && r5 > worst5) worst5 = r5;
-                            if (counts && r7 > worst7) worst7 = r7;
-                        }
-                        d[r] = (VAL || !sane_r[r]) ? ex[r] : d[r];
-                    }
-                }
-                // bins outside the table (last step of a row): zero digits gave d = 0; they must never be selected
-                const bool inside = bin + t < res;
-                if (tail_step) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) d[r] = inside ? d[r] : 1e300;
-                }
-                // Top-n gate and near-null vote of scan_mfma_kernel, per tile
-                bool hit = false, low = false;
-                if constexpr (SPEC) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float fd = fabsf((float)d[r]);
-                        hit |= (fd <= gate_f[r]);
-                        low |= (fd <= below_f);
-                        sv[r][t] = __builtin_amdgcn_rcpf(fd);
+                    for (int i = 0; i < 15; ++i) {
+                        const int sq_ = i8_fold_s(i), l = i8_fold_l(i);
+                        v4i32 cin = {0, 0, 0, 0};
+                        if (started[l]) cin = L[l];
+                        else if (l == 3) cin = (v4i32){L[4][0] >> 8, L[4][1] >> 8, L[4][2] >> 8, L[4][3] >> 8};   // (all level-4 pairs precede)
+                        if constexpr (ABL & 4) L[l] = cin + (b[l - sq_] ^ A[0][sq_]);
+                        else L[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0][sq_], b[l - sq_], cin, 0, 0, 0);
+                        started[l] = true;
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        hit |= (fabs(d[r]) <= gate_d[r]);
-                        low |= (fabs(d[r]) <= below_d);
-                    }
-                }
-                if (__any(hit)) {
-                    if (refine_on && __any(low)) {          // near-null values: the reference's literal form, per value
-                        const v4f64 lit = literal16<M>(rf.Gs, rf.TB, itn, g, qstride, nn, bin + t);
+                    for (int l = 0; l < NS; ++l) L[l] = (v4i32){0, 0, 0, 0};
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const bool redo = (fabs(d[r]) <= rf.below) && inside;
-                            d[r] = redo ? lit[r] : d[r];
-                            refined += (redo && row_ok[r]) ? 1u : 0u;
-                            if constexpr (SPEC) sv[r][t] = strength_f32(fabs(d[r]));
+                    for (int kb = 0; kb < NKB; ++kb) {
+                        v4i32 b[NS];
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) b[s] = Bp[((tl * NKB + kb) * NS + s) * 64];
+#pragma unroll
+                        for (int i = 0; i < 15; ++i) {
+                            const int sq_ = i8_order_s(i), l = i8_order_l(i);
+                            if constexpr (ABL & 4) L[l] += b[l - sq_] ^ A[kb][sq_];
+                            else L[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][sq_], b[l - sq_], L[l], 0, 0, 0);
                         }
                     }
+                }
+                // ---- bulk form: V from two (three) int32 words, one comparison, one reciprocal per value -------------------
+                v4f64 vd;
+                bool under = false;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        key_insert_new<NMAX>(key[r], make_key(d[r], inside ? bin + t : nobin, keep_mask));
-                        const uint64_t kb = __builtin_bit_cast(uint64_t, key[r][NMAX - 1]) | (uint64_t)(~keep_mask);
-                        gate_d[r] = fmax(__builtin_bit_cast(double, kb), below_d);
-                        gate_f[r] = (float)gate_d[r];
+                for (int r = 0; r < 4; ++r) {
+                    const int l3 = FOLD ? L[3][r] : L[3][r] + (L[4][r] >> 8);
+                    const int hw = L[0][r] * 256 + L[1][r];
+                    if constexpr (PAIR23) vd[r] = __builtin_fma((double)hw, 65536.0, (double)(L[2][r] * 256 + l3));
+                    else vd[r] = __builtin_fma(__builtin_fma((double)hw, 256.0, (double)L[2][r]), 256.0, (double)l3);
+                    const float fd = fabsf((float)vd[r]) * ws_f;
+                    under |= (fd <= thr_f[r]);
+                    if constexpr (SPEC) sv[r][t] = __builtin_amdgcn_rcpf(fd);
+                }
+                if (VAL || __any(under)) {
+                    // ======== everything that is not the bulk of the values (wave-uniform branch) ========================
+                    v4f64 d;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d[r] = vd[r] * ws_d;                // d5, exactly
+                    [[maybe_unused]] const v4f64 d5 = d;
+                    // Values at or below T: two more digits of both operands (levels 5 and 6 on top of the accumulated ones:
+                    // 13 NKB MFMAs) and the low byte of the level-4 sum; digits 5, 6 of q from this lane's LDS slot, of F from
+                    // the image in L2.
+                    bool lowt = false;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lowt |= !(fabs(d[r]) > tacc_d);
+                    if (VAL || __any(lowt)) {
+                        ++fell;
+                        v4i32 L5 = {0, 0, 0, 0}, L6 = {0, 0, 0, 0};
+                        const v4i32* __restrict__ B2 = reinterpret_cast<const v4i32*>(IB2) + ((size_t)st * 4 + (size_t)t) * TU2 + lane;
+#pragma unroll
+                        for (int kb = 0; kb < NKB; ++kb) {
+                            const v4i32 b5 = B2[(kb * 2 + 0) * 64], b6 = B2[(kb * 2 + 1) * 64];
+                            const v4i32 a5 = a56[wave][kb][0][lane], a6 = a56[wave][kb][1][lane];
+                            v4i32 b[NS];
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) b[s] = Bp[((tl * NKB + kb) * NS + s) * 64];
+                            L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][0], b5, L5, 0, 0, 0);
+                            L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][0], b6, L6, 0, 0, 0);
+                            L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][1], b[4], L5, 0, 0, 0);
+                            L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][1], b5, L6, 0, 0, 0);
+                            L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][2], b[3], L5, 0, 0, 0);
+                            L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][2], b[4], L6, 0, 0, 0);
+                            L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][3], b[2], L5, 0, 0, 0);
+                            L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][3], b[3], L6, 0, 0, 0);
+                            L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][4], b[1], L5, 0, 0, 0);
+                            L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][4], b[2], L6, 0, 0, 0);
+                            L5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a5, b[0], L5, 0, 0, 0);
+                            L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a5, b[1], L6, 0, 0, 0);
+                            L6 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a6, b[0], L6, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            // the level sums are exact (small integers times powers of two); ONE rounding, of the final sum
+                            const double low = __builtin_fma((double)(L[4][r] & 255), ip.wt[4],
+                                                             __builtin_fma((double)L5[r], ip.wt[5], (double)L6[r] * ip.wt[6]));
+                            const double d7 = d[r] + low;
+                            // Per VALUE: only a d at or below T is replaced, so what an (item, bin) pair gets never depends on which
+                            // items share its wave or on how a batch was cut (the rule of literal_tile()).
+                            const bool take = VAL || !(fabs(d[r]) > tacc_d);
+                            d[r] = take ? d7 : d[r];
+                        }
+                    }
+                    // items whose coefficients are not a projector's (non-finite or garbage covariance): scan_mfma_kernel's fp64
+                    // form for their rows, bit for bit (a wave-uniform branch, taken by waves that hold such an item)
+                    if (VAL || any_insane) {
+                        const v4f64 ex = exact16<M>(Qs, FB, itn, g, lane, qstride, st, t);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if constexpr (VAL) {
+                                const float r5 = (float)(fabs(d5[r] - ex[r]) / ip.e_bound);
+                                const float r7 = (float)(fabs(d[r] - ex[r]) / (ip.e_refined + 0x1p-50 * fabs(ex[r])));
+                                const bool counts = sane_r[r] && row_ok[r] && bin + t < res;        // (NaN never counts)
+                                if (counts && r5 > worst5) worst5 = r5;
+                                if (counts && r7 > worst7) worst7 = r7;
+                            }
+                            d[r] = (VAL || !sane_r[r]) ? ex[r] : d[r];
+                        }
+                    }
+                    // bins outside the table (last step of a row): zero digits gave d = 0; they must never be selected
+                    const bool inside = bin + t < res;
+                    if (tail_step) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) d[r] = inside ? d[r] : 1e300;
+                    }
+                    // Top-n gate and near-null vote of scan_mfma_kernel, per tile
+                    bool hit = false, low = false;
+                    if constexpr (SPEC) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float fd = fabsf((float)d[r]);
+                            hit |= (fd <= gate_f[r]);
+                            low |= (fd <= below_f);
+                            sv[r][t] = __builtin_amdgcn_rcpf(fd);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            hit |= (fabs(d[r]) <= gate_d[r]);
+                            low |= (fabs(d[r]) <= below_d);
+                        }
+                    }
+                    if (__any(hit)) {
+                        if (refine_on && __any(low)) {          // near-null values: the reference's literal form, per value
+                            const v4f64 lit = literal16<M>(rf.Gs, rf.TB, itn, g, qstride, nn, bin + t);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const bool redo = (fabs(d[r]) <= rf.below) && inside;
+                                d[r] = redo ? lit[r] : d[r];
+                                refined += (redo && row_ok[r]) ? 1u : 0u;
+                                if constexpr (SPEC) sv[r][t] = strength_f32(fabs(d[r]));
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            key_insert_new<NMAX>(key[r], make_key(d[r], inside ? bin + t : nobin, keep_mask));
+                            const uint64_t kb = __builtin_bit_cast(uint64_t, key[r][NMAX - 1]) | (uint64_t)(~keep_mask);
+                            gate_d[r] = fmax(__builtin_bit_cast(double, kb), below_d);
+                            gate_f[r] = (float)gate_d[r];
+                            // the bulk path's threshold: at least the gate (rounded up where the gate is kept in fp64), at least T
+                            float gu = gate_f[r];
+                            if constexpr (!SPEC) gu = ((double)gu < gate_d[r]) ? __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, gu) + 1u) : gu;   // (gu >= 0, finite here)
+                            thr_f[r] = fmaxf(gu, ip.t_acc_f);
+                        }
                     }
                 }
             }
 
             // the next phase's operands have landed (and the PREVIOUS step's stores are done) ...
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // ... then this step's spectrum stores, then the barrier
             if (last_p) {
                 if constexpr (SPEC && !(ABL & 1)) {
@@ -441,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
                     for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(sv[r]));
                 }
             }
-            __syncthreads();
+            if constexpr (!(ABL & 8)) __syncthreads();
             buf ^= 1;
         }
     }

@@ -13,9 +13,9 @@
  * Arithmetic: out[o] = sum_k in[ii_o + k] * taps[imu_o][7-k] (float accumulation), imu_o = rint((float)mu_o * 128).
  * The 8-tap x 129-phase table belongs to gnuradio-filter's MMSE interpolator, which gr-baz does not vendor: a fresh
  * context starts from the table regenerated from the library's published criterion (closed-form least squares,
- * gr_baz_amd/csrc/baz_resamp_hip.hip: build_taps, rounded to the six significant digits the library's generator prints:
- * the rows of the published header known here, mu = 1/128 .. 4/128 and 64/128, come out digit for digit) -- PARITY
- * UNPINNED for that default in the strict sense, as the published file itself is not available offline --
+ * gr_baz_amd/csrc/baz_resamp_hip.hip: build_taps, rounded to the six significant digits the library's generator prints)
+ * -- PARITY UNPINNED for that default: the library's header is not available offline, and the default may differ from it
+ * by a few 1e-6 per tap (tests/test_resamp.py) --
  * and baz_resamp_set_taps() installs the host's own table, which the host block does wherever it is compiled against
  * a real gnuradio-filter: bit-exact with whatever gnuradio-filter the host has.  The reference's x87 `long double` phase recurrence mu <- frac(mu + mu_inc),
  * ii <- ii + floor(mu + mu_inc) is evaluated in closed form, P_o = mu_0 + o * mu_inc in 64.64-bit fixed point

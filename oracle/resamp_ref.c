@@ -18,13 +18,14 @@
  *         integral_{-B}^{B} | sum_j h_j e^{-i 2 pi f j} - e^{-i 2 pi f (4 - mu)} |^2 df,   B = 0.25,
  *     numerically (praxis) and prints 6 significant digits.  That problem is linear least squares with
  *     the closed form  A h = b,  A_jl = 2B sinc(2B (j-l)),  b_j = 2B sinc(2B (j - (4 - mu))), used here.
- *     The published header holds the generator's printout ("%12.5e") as float literals, so the table here is
- *     the closed form ROUNDED TO SIX SIGNIFICANT DECIMAL DIGITS and then to float.  Rows of that header as far as
- *     they are known here without a copy of it (mu = 1/128 .. 5/128 and 64/128, written down from memory in
- *     tests/test_resamp.py) are reproduced digit for digit, 48 of 48 entries -- which a closed form could not do
- *     for misremembered digits, nor a numerical minimiser's residue survive.  PARITY STILL UNPINNED in the strict
- *     sense: no golden vectors exist in the reference and the file itself is not available offline; a host that has
- *     gnuradio-filter installs ITS table through baz_resamp_set_taps() (include/baz_resamp_hip.h).
+ *     The header holds the generator's printout ("%12.5e") as float literals, so the table here is the closed form
+ *     ROUNDED TO SIX SIGNIFICANT DECIMAL DIGITS and then to float.  PARITY UNPINNED: the reference holds no golden
+ *     vectors for this path and the header is not available offline; two recollections of its rows 1 and 3 exist and
+ *     disagree in the outermost tap by 9.5e-7 / 2.8e-6 (tests/test_resamp.py keeps both as candidates and asserts
+ *     neither) -- so the default table may differ from the real one by a few 1e-6 per tap.  A host that has
+ *     gnuradio-filter installs ITS table through baz_resamp_set_taps() (include/baz_resamp_hip.h) and is then exact;
+ *     scripts/dump_gr_mmse_taps.py turns such a host into the fixture tests/golden/mmse_taps_gr37.npz, against which
+ *     the default is then compared bit for bit (test_default_table_equals_gnuradio_filters_bit_for_bit).
  */
 #define _POSIX_C_SOURCE 200809L
 #include <locale.h>

@@ -1,6 +1,6 @@
 """Lab (GPU box, lab build of the library): where the int8 scan's time goes.  BASELINE configs[2] (m8, N4096, res36000; 16,384
 items) and configs[4]'s MUSIC stage (m16, N4096, res3600; 16,384 items), spectrum port wired, with parts of the bulk loop
-compiled out (BAZ_MUSIC_I8_ABL: 1 no spectrum stores, 2 no level combination, 4 no MFMAs; timing only, results are wrong)."""
+compiled out (BAZ_MUSIC_I8_ABL: 1 no spectrum stores, 4 no MFMAs, 8 no staging loads / waits / barriers; timing only, results are wrong)."""
 import os
 import sys
 
@@ -11,8 +11,8 @@ from gr_baz_amd import capi, synth
 from gr_baz_amd.baz.music_doa_helper import calculate_antenna_array_response
 
 dev = torch.device("cuda:0")
-NAMES = {0: "product", 1: "no stores", 2: "no level combination", 3: "no stores, no combination", 4: "no MFMAs",
-         6: "no MFMAs, no combination", 7: "staging + LDS reads + gate only"}
+NAMES = {0: "product", 1: "no stores", 4: "no MFMAs", 5: "no MFMAs, no stores", 8: "no staging / waits / barriers",
+         9: "no staging / waits / barriers, no stores", 13: "LDS reads + per-value vector work only"}
 for M, NE, N, RES, B in ((8, 2, 4096, 36000, 16384), (16, 2, 4096, 3600, 16384)):
     arr = synth.array_geometry(M)
     table = np.array(calculate_antenna_array_response([[0.5 * x, 0.5 * y] for x, y in arr], RES, 1.0)).astype(np.complex64)
@@ -20,7 +20,7 @@ for M, NE, N, RES, B in ((8, 2, 4096, 36000, 16384), (16, 2, 4096, 3600, 16384))
     ang = torch.zeros(B, NE, dtype=torch.float32, device=dev)
     lvl = torch.zeros_like(ang)
     spec = torch.zeros(B, RES, dtype=torch.float32, device=dev)
-    for abl in (0, 1, 2, 3, 4, 6, 7):
+    for abl in (0, 1, 4, 5, 8, 9, 13):
         os.environ["BAZ_MUSIC_I8_ABL"] = str(abl)
         with capi.Context(M, NE, N, RES, table, lab=True) as ctx:
             ctx.reserve(B)

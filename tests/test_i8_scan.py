@@ -102,7 +102,7 @@ def test_digit_images_equal_the_numpy_restatement(m, res):
         assert np.array_equal(Fd[s], ref[s]), "digit %d of the image differs" % s
     assert np.abs(Fd[0]).max() <= 65 and all(np.abs(Fd[s]).max() <= 128 for s in range(1, ND))
     # the parameters are the documented formulas
-    E5 = m * m * fs * NS * 1.01 * 2.0 ** (2 - 8 * NS)
+    E5 = m * m * fs * NS * 1.01 * 2.0 ** (2 - 8 * NS) + fs * 2.0 ** (-12 - 8 * (NS - 2))    # (+ the low byte of the level-4 sum)
     assert par["sq"] == sq and par["e_bound"] == E5 and par["t_acc"] == E5 * (1.0 + 1.0 / EPS)
     assert np.array_equal(par["wt"], [fs * 2.0 ** (-12 - 8 * l) for l in range(ND)])
     assert par["e_refined"] == m * m * fs * 2.0 ** -54 * (7.07 + 2.0 * m * m)
@@ -110,13 +110,18 @@ def test_digit_images_equal_the_numpy_restatement(m, res):
 
 def _integer_forms(qd, Fd, wt):
     """(d5, d7) exactly as the kernel evaluates them: level sums of digit products (int64 here, int32 there: asserted to fit),
-    levels < 5 of the five leading digits for the bulk form, levels 5 and 6 of all seven digits on top for the refined one."""
+    levels < 5 of the five leading digits for the bulk form -- of the level-4 sum only floor(A_4 / 256), folded into level 3 --,
+    the low byte of A_4 and levels 5 and 6 of all seven digits on top for the refined one."""
     d5 = np.zeros((qd[0].shape[0], Fd[0].shape[0]))
+    tail = np.zeros_like(d5)
     for l in range(NS):
         A = sum(qd[s] @ Fd[l - s].T for s in range(l + 1))
         assert np.abs(A).max() < 2 ** 31 // 256
-        d5 += A.astype(np.float64) * wt[l]               # (every term an integer times a power of two: exact in fp64)
-    tail = np.zeros_like(d5)
+        if l == NS - 1:
+            d5 += (A >> 8).astype(np.float64) * wt[l - 1]          # (arithmetic shift = floor)
+            tail += (A & 255).astype(np.float64) * wt[l]
+        else:
+            d5 += A.astype(np.float64) * wt[l]           # (every term an integer times a power of two: exact in fp64)
     for l in (5, 6):
         A = sum(qd[s] @ Fd[l - s].T for s in range(l + 1))
         assert np.abs(A).max() < 2 ** 31

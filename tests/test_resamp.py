@@ -15,8 +15,18 @@ import pytest
 from conftest import GOLDEN_DIR, ROOT
 from oracle import resamp_ref as rr
 
-ANCHOR_ROW_MU_1_128 = np.array([-1.54700e-04, 8.53777e-04, -2.76968e-03, 7.89295e-03, 9.98534e-01, -5.41054e-03,
-                                1.24642e-03, -1.98993e-04])   # the published gnuradio-filter row for mu = 1/128
+# Rows of gnuradio-filter's interpolator_taps.h AS RECOLLECTED -- there is no copy of that header in this image, and two
+# recollections of the outermost tap of rows 1 and 3 exist (round 2 wrote -1.98047e-04 / -5.94874e-04, round 3
+# -1.98993e-04 / -5.92100e-04, the values of the closed form; the reviewers' memory is the former).  Neither is a fixture:
+# they are kept as CANDIDATES, and nothing below asserts equality with either.  The only pin that counts is the real table
+# (tests/golden/mmse_taps_gr37.npz, produced on a GNU Radio host by scripts/dump_gr_mmse_taps.py; absent here).
+CANDIDATE_ROWS = {
+    1: [np.array([-1.54700e-04, 8.53777e-04, -2.76968e-03, 7.89295e-03, 9.98534e-01, -5.41054e-03, 1.24642e-03, -1.98047e-04]),
+        np.array([-1.54700e-04, 8.53777e-04, -2.76968e-03, 7.89295e-03, 9.98534e-01, -5.41054e-03, 1.24642e-03, -1.98993e-04])],
+    3: [np.array([-4.64053e-04, 2.56486e-03, -8.34364e-03, 2.39714e-02, 9.95074e-01, -1.59305e-02, 3.69852e-03, -5.94874e-04]),
+        np.array([-4.64053e-04, 2.56486e-03, -8.34364e-03, 2.39714e-02, 9.95074e-01, -1.59305e-02, 3.69852e-03, -5.92100e-04])],
+}
+REAL_TABLE = os.path.join(GOLDEN_DIR, "mmse_taps_gr37.npz")
 
 
 def resamp_golden():
@@ -55,30 +65,17 @@ def make(cls, g, **kw):
 
 
 # ------------------------------------------------------------------ CPU: the oracle
-# Rows of the published table (gnuradio-filter's interpolator_taps.h: mu = 1/128 .. 5/128 and the mid row 64/128), written
-# down from memory of that file -- there is no copy of it in this image -- and therefore cross-checked here rather than
-# trusted: all 48 entries equal the closed form at the table's print precision ("%12.5e", six significant digits), which
-# an independent computation would not do for misremembered digits.  (An earlier round's note had -1.98047e-04 and
-# -5.94874e-04 in the outermost tap of rows 1 and 3 and read the 1e-6 gaps as the residue of GNU Radio's minimiser;
-# rows 2, 4, 5 and 64 show no such residue in any tap, and those two digits were the recollection's, not the table's.)
-# The table of the restatement and of the engine is therefore the closed form rounded the way the generator prints, and
-# then to float the way the compiler reads the header: equal to the rows below bit for bit.
-PUBLISHED_ROWS = {
-    1: ANCHOR_ROW_MU_1_128,
-    2: np.array([-3.09412e-04, 1.70888e-03, -5.55134e-03, 1.58840e-02, 9.96891e-01, -1.07209e-02, 2.47942e-03, -3.96391e-04]),
-    3: np.array([-4.64053e-04, 2.56486e-03, -8.34364e-03, 2.39714e-02, 9.95074e-01, -1.59305e-02, 3.69852e-03, -5.92100e-04]),
-    4: np.array([-6.18544e-04, 3.42130e-03, -1.11453e-02, 3.21531e-02, 9.93082e-01, -2.10389e-02, 4.90322e-03, -7.86031e-04]),
-    5: np.array([-7.72802e-04, 4.27773e-03, -1.39548e-02, 4.04274e-02, 9.90917e-01, -2.60456e-02, 6.09305e-03, -9.78093e-04]),
-    64: np.array([-6.77751e-03, 3.94578e-02, -1.42658e-01, 6.09836e-01, 6.09836e-01, -1.42658e-01, 3.94578e-02, -6.77751e-03]),
-}
-
-
-def test_tap_table_reproduces_the_published_row_and_its_structure():
+def test_tap_table_structure_and_closed_form():
+    """The DEFAULT table is the closed-form MMSE design (oracle/resamp_ref.c) rounded to six significant digits and then to
+    float -- PARITY UNPINNED against gnuradio-filter's own header.  Asserted here: its structure, that it is what the closed
+    form gives, and that every recollected candidate row lies within 3e-6 of it (the size of the disagreement between the
+    candidates themselves: 9.5e-7 and 2.8e-6) -- which bounds what a wrong default could cost (outputs within ~1e-6 of the
+    signal scale), and proves nothing more."""
     t = rr.taps()
     assert t.shape == (129, 8)
-    for i, row in PUBLISHED_ROWS.items():
-        assert np.array_equal(t[i], row.astype(np.float32)), i        # the float the compiler makes of the printed literal
-        assert np.array_equal(t[128 - i], row.astype(np.float32)[::-1]), i
+    for i, cands in CANDIDATE_ROWS.items():
+        for row in cands:
+            assert np.max(np.abs(t[i].astype(np.float64) - row)) <= 3e-6, (i, row)
     # every entry is a six-digit decimal: printing it the generator's way and reading it back changes nothing
     assert np.array_equal(np.array([[float("%.5e" % v) for v in r] for r in t.astype(np.float64)]).astype(np.float32), t)
     assert np.array_equal(t[::-1, ::-1], t)                            # taps(1 - mu) = reversed taps(mu)
@@ -90,6 +87,18 @@ def test_tap_table_reproduces_the_published_row_and_its_structure():
         f = 0.05
         got = np.sum(np.exp(2j * np.pi * f * n) * t[i][::-1])
         assert abs(got - np.exp(2j * np.pi * f * (3 + i / 128.0))) < 2e-4
+
+
+@pytest.mark.skipif(not os.path.exists(REAL_TABLE), reason="no gnuradio-filter table fixture (scripts/dump_gr_mmse_taps.py makes it on a GNU Radio host)")
+def test_default_table_equals_gnuradio_filters_bit_for_bit():
+    """The day someone runs scripts/dump_gr_mmse_taps.py on a GNU Radio host and commits its output, the resampler becomes
+    pinned -- or this fails loudly and the default table must be replaced by the fixture's."""
+    z = np.load(REAL_TABLE, allow_pickle=False)
+    real = z["taps"]
+    assert real.shape == (129, 8) and real.dtype == np.float32
+    assert np.array_equal(rr.taps().view(np.uint32), real.view(np.uint32)), \
+        "default MMSE table differs from gnuradio-filter's in %d entries (worst %.3e)" % (
+            int((rr.taps() != real).sum()), float(np.abs(rr.taps().astype(np.float64) - real).max()))
 
 
 @pytest.mark.parametrize("name", resamp_golden())
@@ -213,7 +222,7 @@ def test_hip_tap_table_equals_the_oracle_table(gpu_device):
     from gr_baz_amd import resamp
     with resamp.Resampler(0.0, 1.0) as blk:
         t = blk.taps()
-    assert np.array_equal(t.view(np.uint32), rr.taps().view(np.uint32)) and np.array_equal(t[1], ANCHOR_ROW_MU_1_128.astype(np.float32))
+    assert np.array_equal(t.view(np.uint32), rr.taps().view(np.uint32))
 
 
 @pytest.mark.gpu
