@@ -78,6 +78,21 @@ def build_hip(force=False, verbose=False):
     return HIP_LIB
 
 
+QUICK_LIB = os.path.join(CSRC, "libbaz_music_hip_quick.so")   # lab iterations only: -DBAZ_MUSIC_LAB -DBAZ_MUSIC_QUICK (m = 4, 8, 16)
+
+
+def build_quick(verbose=False):
+    """Lab iterations on one kernel: the LAB form of the MUSIC library restricted to m = 4, 8, 16 (a fraction of the compile
+    time).  Loaded by capi.lib(lab=True) when BAZ_MUSIC_LAB_LIB=quick; never built by build_all(), never shipped."""
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-DBAZ_MUSIC_LAB", "-DBAZ_MUSIC_QUICK", "-I", INCLUDE, "-o", QUICK_LIB + ".tmp",
+                                      os.path.join(CSRC, "baz_music_hip.hip")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=CSRC)
+    os.replace(QUICK_LIB + ".tmp", QUICK_LIB)
+    return QUICK_LIB
+
+
 def pybind_module_path():
     ext = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
     return os.path.join(HOST, "_baz_music" + ext)
@@ -119,5 +134,8 @@ def build_all(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv, verbose=True)
-    print("built:", HIP_LIB)
+    if "--quick" in sys.argv:
+        print("built:", build_quick(verbose=True))
+    else:
+        build_all(force="--force" in sys.argv, verbose=True)
+        print("built:", HIP_LIB)

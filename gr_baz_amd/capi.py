@@ -57,9 +57,12 @@ def lib(lab=False):
     global _lib, _lab_lib
     if lab:
         if _lab_lib is None:
-            if not os.path.exists(LAB_LIB_PATH):
-                raise ImportError("gr_baz_amd: %s is missing - run `python -m gr_baz_amd.build`" % LAB_LIB_PATH)
-            _lab_lib = _bind(ctypes.CDLL(LAB_LIB_PATH))
+            path = LAB_LIB_PATH
+            if os.environ.get("BAZ_MUSIC_LAB_LIB") == "quick":      # tests/lab iterations: python -m gr_baz_amd.build --quick
+                path = os.path.join(os.path.dirname(LAB_LIB_PATH), "libbaz_music_hip_quick.so")
+            if not os.path.exists(path):
+                raise ImportError("gr_baz_amd: %s is missing - run `python -m gr_baz_amd.build`" % path)
+            _lab_lib = _bind(ctypes.CDLL(path))
         return _lab_lib
     if _lib is not None:
         return _lib
@@ -257,11 +260,11 @@ class Context:
         return bool(self._L.baz_music_uses_i8_scan(self._h))
 
     def debug_i8_margin(self, d_in, batch):
-        """(worst |d5 - d| / E5, worst |d7 - d| / allowance) of the int8 scan's bulk and refined forms over every (item, bin)
-        of the batch, against the fp64 form (the bounds hold below 1)."""
-        w = (ctypes.c_float * 2)(0.0, 0.0)
+        """(worst |d5 - d| / E5, worst |d7 - d| / allowance, worst |d4 - d| / E4) of the int8 scan's five-, seven- and
+        four-digit forms over every (item, bin) of the batch, against the fp64 form (the bounds hold below 1)."""
+        w = (ctypes.c_float * 3)(0.0, 0.0, 0.0)
         self._chk(self._L.baz_music_debug_i8_margin(self._h, _vp(d_in), int(batch), w), "baz_music_debug_i8_margin")
-        return float(w[0]), float(w[1])
+        return float(w[0]), float(w[1]), float(w[2])
 
     def debug_i8_stats(self):
         """(wave tiles -- 16 items x 16 bins -- that ran the refined form, wave tiles walked) of the int8 scan since the last read; resets."""
@@ -340,7 +343,7 @@ def debug_i8_image(m, resolution, table):
     lib().baz_music_debug_i8_image(int(m), int(resolution), tp, img.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n,
                                    par.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
     return img, {"wt": par[:7].copy(), "sq": par[7], "t_acc": par[8], "e_bound": par[9], "e_refined": par[10],
-                 "ns": int(par[11]), "nd": int(par[12])}
+                 "ns": int(par[11]), "nd": int(par[12]), "e4_bound": par[13], "t4": par[14]}
 
 
 def q_stride(batch):

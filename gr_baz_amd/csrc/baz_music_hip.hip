@@ -134,7 +134,7 @@ struct baz_music_ctx {
     int i8_abl = 0;                // lab (BAZ_MUSIC_I8_ABL): ablation mask of scan_i8_kernel (timing only)
     uint32_t num_cus = 256;        // compute units of the device (launch geometry of scan_i8_kernel)
     int i8_wgs_per_cu[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};   // [NMAX > 2][SPEC][VEC4]: resident workgroups per CU (occupancy API, on first use)
-    unsigned long long* dI8Stat = nullptr;   // [0] wave tiles that ran the refined form, [1] wave tiles walked, [2], [3] VAL margins
+    unsigned long long* dI8Stat = nullptr;   // [0] wave tiles that ran the refined form, [1] wave tiles walked, [2] .. [4] VAL margins
     int peak_mode = 0;      // 0: the reference's n strongest bins; 1 (opt-in extension): n strongest local maxima
     float* dPeakSpec = nullptr;   // internal spectrum when peak mode runs without the spectrum port
     size_t peak_spec_cap = 0;     // floats
@@ -389,6 +389,11 @@ bool build_i8_image(const std::vector<double>& F, uint32_t m, uint32_t res, uint
     // digits cut off + levels dropped + the low byte of the level-4 sum (scan_i8_kernels.hip.h, "Error bound")
     ip.e_bound = (double)mm * fscale * (double)NS * 1.01 * std::ldexp(1.0, 2 - 8 * NS) + fscale * std::ldexp(1.0, -12 - 8 * (NS - 2));
     ip.t_acc = ip.e_bound * (1.0 + 1.0 / I8_EPS);
+    // first tier: four leading digits, levels 0 .. 3
+    ip.e4_bound = (double)mm * fscale * (double)(NS - 1) * 1.01 * std::ldexp(1.0, 2 - 8 * (NS - 1));
+    const double t4 = ip.e4_bound * (1.0 + 1.0 / I8_EPS);
+    ip.t4_f = (float)t4;
+    if ((double)ip.t4_f < t4) ip.t4_f = std::nextafterf(ip.t4_f, INFINITY);
     ip.ws_f = (float)ip.wt[NS - 2];
     ip.t_acc_f = (float)ip.t_acc;
     if ((double)ip.t_acc_f < ip.t_acc) ip.t_acc_f = std::nextafterf(ip.t_acc_f, INFINITY);
@@ -518,11 +523,15 @@ int launch_cov_t(baz_music_ctx* c, const float* d_in, uint32_t batch, double2* d
     return BAZ_MUSIC_OK;
 }
 
+#ifdef BAZ_MUSIC_QUICK      // lab: a library that only knows m = 4, 8, 16 (a sixth of the compile time; tests/lab iterations)
+#define BAZ_M_CASES(CALL) case 4: return CALL(4); case 8: return CALL(8); case 16: return CALL(16);
+#else
 #define BAZ_M_CASES(CALL)                                                                          \
     case 2: return CALL(2); case 3: return CALL(3); case 4: return CALL(4); case 5: return CALL(5); \
     case 6: return CALL(6); case 7: return CALL(7); case 8: return CALL(8); case 9: return CALL(9); \
     case 10: return CALL(10); case 11: return CALL(11); case 12: return CALL(12); case 13: return CALL(13); \
     case 14: return CALL(14); case 15: return CALL(15); case 16: return CALL(16);
+#endif
 
 int launch_cov(baz_music_ctx* c, const float* d_in, uint32_t batch, double2* dR)
 {
@@ -765,10 +774,27 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
                     switch (c->i8_abl) {
                         case 1: BAZ_I8_ABL(1); break;      // no spectrum stores
                         case 4: BAZ_I8_ABL(4); break;      // no MFMAs
+                        case 16: BAZ_I8_ABL(16); break;    // stores in flight across the next step's wait (scrap loads, vmcnt(4))
+                        case 17: BAZ_I8_ABL(17); break;    // ... without the stores
                         case 5: BAZ_I8_ABL(5); break;
-                        case 8: BAZ_I8_ABL(8); break;      // no staging loads, waits, barriers
+                        case 8: BAZ_I8_ABL(8); break;      // only the first phase staged: no staging loads, waits, barriers
                         case 9: BAZ_I8_ABL(9); break;      // ... and no stores: the tiles' arithmetic alone
-                        default: BAZ_I8_ABL(13); break;    // LDS reads and the per-value vector work alone
+                        case 32: BAZ_I8_ABL(32); break;    // staging, barriers and stores alone
+                        case 40: BAZ_I8_ABL(40); break;    // stores alone
+                        case 64: BAZ_I8_ABL(64); break;    // plain stores
+                        case 1024: BAZ_I8_ABL(1024); break; // staggered workgroup starts
+                        case 8192: BAZ_I8_ABL(8192); break; // s_memtime around wait / stores / barrier (baz_music_debug_i8_times)
+                        case 8193: BAZ_I8_ABL(8193); break;
+                        case 2048: BAZ_I8_ABL(2048); break; // rows 256-B aligned (row stride rounded down to 64 bins)
+                        case 2088: BAZ_I8_ABL(2088); break; // ... stores alone
+                        case 4096: BAZ_I8_ABL(4096); break; // every step stores to the row's first piece (no new HBM lines)
+                        case 4104: BAZ_I8_ABL(4104); break; // ... without staging / waits / barriers
+                        case 4136: BAZ_I8_ABL(4136); break; // ... stores alone
+                        case 137: BAZ_I8_ABL(137); break;  // 9 + 128: operands + MFMAs only
+                        case 265: BAZ_I8_ABL(265); break;  // 9 + 256: operands + per-value work only
+                        case 393: BAZ_I8_ABL(393); break;  // 9 + 128 + 256: LDS reads only
+                        case 521: BAZ_I8_ABL(521); break;  // 9 + 512: ten MFMAs
+                        default: BAZ_I8_ABL(96); break;    // staging, barriers, plain stores
                     }
 #undef BAZ_I8_ABL
                     HIP_TRY(c, hipGetLastError());
@@ -1609,8 +1635,8 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8_ABL")) c->i8_abl = atoi(v);                  // lab
         if (m >= 6 && n <= 4 && i8_image_bytes(m, c->fb_steps) <= I8_IMAGE_LIMIT) {
             if (hipMalloc((void**)&c->dIB, i8_image_bytes(m, c->fb_steps)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
-            if (hipMalloc((void**)&c->dI8Stat, 4 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
-            if (hipMemset(c->dI8Stat, 0, 4 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
+            if (hipMalloc((void**)&c->dI8Stat, 8 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+            if (hipMemset(c->dI8Stat, 0, 8 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         }
         if (short_form_applies(m, n) && hipMalloc((void**)&c->dA2p, (size_t)(c->fb_steps + 2) * 64 * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         {
@@ -2087,8 +2113,8 @@ int64_t baz_music_debug_coarse_fired(baz_music_ctx* c)
 }
 
 // Validation of the int8 scan's a-priori bounds on this hardware (scan_i8_kernels.hip.h, VAL): covariance + EVD of the batch,
-// then EVERY (item, bin) in the bulk, the refined and the fp64 form; worst[0] = max |d5 - d| / E5, worst[1] = max |d7 - d| /
-// allowance over the items that take the integer forms.
+// then EVERY (item, bin) in the four-, five-, seven-digit and the fp64 form; worst[0] = max |d5 - d| / E5, worst[1] = max |d7 - d| /
+// allowance, worst[2] = max |d4 - d| / E4 over the items that take the integer forms.
 int baz_music_debug_i8_margin(baz_music_ctx* c, const void* d_in, uint32_t batch, float* worst)
 {
     if (!c || !d_in || !worst || batch == 0) return BAZ_MUSIC_E_INVALID;
@@ -2106,7 +2132,7 @@ int baz_music_debug_i8_margin(baz_music_ctx* c, const void* d_in, uint32_t batch
     if (!r) r = launch_evd(c, c->dR, batch, c->dQ, qstride, c->dG);
     c->i8_on = on;
     if (r) return r;
-    HIP_TRY(c, hipMemsetAsync(c->dI8Stat + 2, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dI8Stat + 2, 0, 3 * sizeof(unsigned long long), c->stream));
     ScanRefine rf;
     rf.Gs = nullptr; rf.TB = c->dTB + c->tb_step_elems; rf.below = 0.0; rf.count = nullptr; rf.A2 = nullptr;
     const uint32_t blocks = (batch + 63) / 64;
@@ -2121,10 +2147,10 @@ int baz_music_debug_i8_margin(baz_music_ctx* c, const void* d_in, uint32_t batch
     }
 #undef BAZ_VAL8
     HIP_TRY(c, hipGetLastError());
-    unsigned long long packed[2] = {0, 0};
+    unsigned long long packed[3] = {0, 0, 0};
     HIP_TRY(c, hipMemcpyAsync(packed, c->dI8Stat + 2, sizeof(packed), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         const unsigned int bits = (unsigned int)packed[k];
         std::memcpy(worst + k, &bits, sizeof(float));
     }
@@ -2148,13 +2174,30 @@ int baz_music_debug_i8_stats(baz_music_ctx* c, uint64_t* refined_tiles, uint64_t
     return BAZ_MUSIC_OK;
 }
 
+#ifdef BAZ_MUSIC_LAB
+// lab: the s_memtime sums of scan_i8_kernel's ABL 8192 instrumentation since the last read (wait, stores, barrier, whole loop; per wave, summed)
+extern "C" __attribute__((visibility("default"))) int baz_music_debug_i8_times(baz_music_ctx* c, uint64_t out[4])
+{
+    if (!c || !c->dI8Stat) return BAZ_MUSIC_E_UNSUPPORTED;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    DeviceGuard guard(c->device);
+    unsigned long long v[4] = {0, 0, 0, 0};
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(v, c->dI8Stat + 4, sizeof(v), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemset(c->dI8Stat + 4, 0, sizeof(v)));
+    for (int i = 0; i < 4; ++i) out[i] = v[i];
+    return BAZ_MUSIC_OK;
+}
+#endif
+
 // 1 when this context's scan runs on the int8 matrix core (6 <= m <= 16, n <= 4, a table whose digit image exists, not
 // BAZ_MUSIC_EXACT=1), else 0.
 int baz_music_uses_i8_scan(const baz_music_ctx* c) { return (c && !c->wide && i8_active(c)) ? 1 : 0; }
 
 // HOST-ONLY tap (no device needed): the digit images and parameters build_i8_image() produces for a table.  Returns the
 // images' size in bytes (also when `out` is NULL or too small: nothing is written then), 0 when the table has no image.
-// params[0 .. 6] = level weights, [7] = 2^54, [8] = T, [9] = E5, [10] = allowance of the refined form, [11] = 5, [12] = 7.
+// params[0 .. 6] = level weights, [7] = 2^54, [8] = T, [9] = E5, [10] = allowance of the refined form, [11] = 5, [12] = 7,
+// [13] = E4, [14] = T4 (as the float the kernel compares with).
 size_t baz_music_debug_i8_image(uint32_t m, uint32_t resolution, const float* table_ri, uint8_t* out, size_t out_bytes,
                                 double* params)
 {
@@ -2168,6 +2211,7 @@ size_t baz_music_debug_i8_image(uint32_t m, uint32_t resolution, const float* ta
         for (int l = 0; l < I8_ND; ++l) params[l] = ip.wt[l];
         params[7] = ip.sq; params[8] = ip.t_acc; params[9] = ip.e_bound; params[10] = ip.e_refined;
         params[11] = (double)I8_NS; params[12] = (double)I8_ND;
+        params[13] = ip.e4_bound; params[14] = (double)ip.t4_f;
     }
     if (out && out_bytes >= img.size()) std::memcpy(out, img.data(), img.size());
     return img.size();

@@ -37,7 +37,8 @@
 // delivers c - thr, three v_min and one compare per 64 values decide the tile.  After an exact tile the new
 // thresholds are shared over the 16 lanes of an item row (4 DPP row rotations on f32).  D never drops below
 // `refine_below`, so near-null values (literal-form refinement, music_kernels.hip.h) are always candidates.
-// NaN q (non-finite covariance): c - thr is NaN, no tile fires, the lists stay empty = (0, 0) pairs like the full scan.
+// NaN q (non-finite covariance): the row's allowance es is +inf (`sane` below), so every tile of the row's wave fires and the
+// exact form decides: NaN never enters a list, the lists stay empty = (0, 0) pairs like the full scan.
 //
 // Layouts.  f16 MFMA C/D: col = lane & 15, row = 4 (lane >> 4) + reg;  f64 MFMA: row = (lane >> 4) + 4 reg.  The
 // coarse A operand therefore carries item pi(i) = (i >> 2) + 4 (i & 3) in row i: register r of lane (g, c) is item
@@ -380,14 +381,20 @@ __global__ __launch_bounds__(256, (RG <= 2 && M <= 4) ? 3 : 2) void scan_coarse_
             __syncthreads();
             buf ^= 1;
         }
-        // D <= (c_(n) + es) (1 + 2^-15), never below `refine_below`;  thr = D (1 + 2^-16) + es   (all in coarse units)
+        // With E = NG2 2^-16 (S + D):  D <= (c_(n) + es) / (1 - NG2 2^-16), never below `refine_below`;
+        // thr = D (1 + NG2 2^-16) + es   (all in coarse units).  Both factors follow from NG2 (round 3 had the constants of one
+        // group everywhere: for 6 .. 8 antennas, NG2 = 2, the first threshold was 1.4e-5 D tighter than the bound it claims)
+        // and are rounded up; one group (m <= 5) keeps round 3's values.
+        constexpr float DDF = NG2 <= 1 ? 1.0000306f : (float)((1.0 + 0x1p-20) / (1.0 - NG2 * 0x1p-16));
+        constexpr float THF = NG2 <= 1 ? 1.0000164f : (float)((1.0 + NG2 * 0x1p-16) * (1.0 + 0x1p-19));
+        static_assert((double)DDF * (1.0 - NG2 * 0x1p-16) >= 1.0 && (double)THF >= 1.0 + NG2 * 0x1p-16, "threshold factors must be upper bounds");
 #pragma unroll
         for (int q = 0; q < RG; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float cn = row_kth_smallest(__builtin_bit_cast(float, pm[q][r]), n);
-                const float Dd = fmaxf(fmaxf(cn + es[q][r], 0.0f) * 1.0000306f, below_s);
-                negthr[q][r] = -__builtin_fmaf(Dd, 1.0000164f, es[q][r]);
+                const float Dd = fmaxf(fmaxf(cn + es[q][r], 0.0f) * DDF, below_s);
+                negthr[q][r] = -__builtin_fmaf(Dd, THF, es[q][r]);
             }
     }
 

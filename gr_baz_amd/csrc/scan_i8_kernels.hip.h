@@ -29,7 +29,14 @@
 //     E5 = MM Fscale 5 1.01 2^-38 + Fscale 2^-36   (m = 8: 1.2e-9 Fscale; m = 16: 4.7e-9 Fscale;  ||a||^2 = m for the helper's tables)
 // A value is within eps = 7.5e-7 of the true one when d5 > T = E5 (1 + 1 / eps).
 //
-// Bulk form per value (round 4, third form: the vector unit, not the matrix core, bounds this kernel -- 109 vector
+// Two tiers (round 4, fourth form).  The matrix core and the vector unit do not overlap on this kernel (their times add:
+// profiles/r04_i8_scan_ablations.txt) and an int8 MFMA costs what ~5 vector instructions cost, so the 15 MFMAs were the
+// largest share of a tile.  FIRST the 10 pairs of the four leading digits with s + t < 4: d4 = (A_0 256 + A_1) 65536 + A_2 256 +
+// A_3 in units of wt[3], error <= E4 = MM Fscale 4 1.01 2^-30 (m = 8: 2.4e-7 Fscale), good to eps where |d4| > T4 = E4 (1 + 1 / eps)
+// = 0.32 Fscale: 95 % of the values of a two-emitter scene.  A tile in which some value is at or below max(T4, its row's top-n
+// gate) adds the 5 level-4 pairs and gives the values at or below T4 -- per value, as always -- the five-digit form d5 below.
+//
+// Bulk form per value (third form: the vector unit, not the matrix core, bounds this kernel -- 109 vector
 // instructions per tile against 15 MFMAs in the second form, profiles/r04_i8_scan_v2_pmc.txt):  V = (A_0 256 + A_1) 65536 +
 // (A_2 256 + A_3 + floor(A_4 / 256)), an integer below 2^48 built from two int32 words, two conversions and one fp64 FMA;
 // d5 = V wt[3] exactly; (float) V, one multiplication by the power of two (float) wt[3], ONE comparison against the row's
@@ -89,6 +96,8 @@ struct I8Params {
     double e_refined;     // allowance of the refined form against the fp64 form (VAL only)
     float ws_f;           // (float) wt[3], a power of two: |d5| as float = |(float) V| ws_f, exactly
     float t_acc_f;        // the smallest float >= T: |d5| <= T  =>  (float)|d5| <= t_acc_f
+    float t4_f;           // the smallest float >= T4 = E4 (1 + 1 / eps): a value keeps the four-digit form iff (float)|d4| > t4_f
+    double e4_bound;      // E4 (VAL only)
 };
 
 // two adjacent levels fit one int32 (a_l 256 + a_(l+1)) while (l + 1) MM 2^22 + (l + 2) MM 2^14 < 2^31
@@ -124,22 +133,21 @@ __device__ __noinline__ v4f64 exact16(const double* __restrict__ Qs, const doubl
     return acc;
 }
 
-// Order of the bulk form's 15 digit pairs (s = digit of q, l = level = s + digit of F).
-// One block of 64 terms (m <= 8): the level-4 pairs go first, spread between the first pairs of the other levels, because the
-// level-3 accumulator STARTS from floor(A_4 / 256) (its C operand: four shifts per tile instead of a shift and an addition
-// per value); two MFMAs on one accumulator are kept apart (a dependent MFMA waits for its predecessor's passes).
-constexpr int i8_fold_s(int i) { constexpr int t[15] = {0, 1, 0, 2, 0, 3, 1, 4, 0, 1, 0, 2, 1, 2, 3}; return t[i]; }
-constexpr int i8_fold_l(int i) { constexpr int t[15] = {4, 4, 0, 4, 1, 4, 1, 4, 2, 2, 3, 2, 3, 3, 3}; return t[i]; }
-// More blocks (m >= 9): the levels go round, level 4's low byte is dropped by one shift and one addition per value.
-constexpr int i8_order_s(int i) { return i < 5 ? 0 : (i < 9 ? 1 : (i < 12 ? 2 : (i < 14 ? 3 : 4))); }
-constexpr int i8_order_l(int i) { return i < 5 ? 4 - i : (i < 9 ? 9 - i : (i < 12 ? 13 - i : (i < 14 ? 16 - i : 4))); }
+// Order of the first tier's 10 digit pairs (s = digit of q, l = level = s + digit of F): the levels go round so that two
+// MFMAs on one accumulator are apart (a dependent MFMA waits for its predecessor's passes).  The second tier is the 5 pairs
+// of level 4, s = 0 .. 4.
+constexpr int i8_t1_s(int i) { constexpr int t[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}; return t[i]; }
+constexpr int i8_t1_l(int i) { constexpr int t[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3}; return t[i]; }
 
 // VAL: validation build (baz_music_debug_i8_margin): every tile runs the bulk AND the refined form, every step the fp64 form;
-// margin[0] / margin[1] = the worst |d5 - d| / E5 and |d7 - d| / allowance over all (item, bin) of items that take the integer
-// forms (float bits, atomicMax); outputs are the fp64 form's.
+// margin[0] / margin[1] / margin[2] = the worst |d5 - d| / E5, |d7 - d| / allowance and |d4 - d| / E4 over all (item, bin) of items
+// that take the integer forms (float bits, atomicMax); outputs are the fp64 form's.
 // stat (may be nullptr): [0] += wave tiles (16 items x 16 bins) that ran the refined form, [1] += wave tiles walked.
-// ABL (lab builds only): 1 no spectrum stores, 4 no MFMAs, 8 no staging loads, waits or barriers (the tiles read whatever
-// the stage holds) -- timing only.
+// ABL (lab builds only; timing, results are wrong): 1 no spectrum stores, 4 no MFMAs, 8 only the first phase is staged (no
+// further staging loads, waits or barriers: every phase reads the first one's operands),
+// 32 no tile arithmetic at all (staging, barriers and stores of a constant), 64 plain stores (no nt / sc bits), 128 no per-value
+// work (the accumulators are only kept alive), 256 no MFMAs and nothing in their place (accumulators = the staged operands),
+// 512 the 10 MFMAs of levels 0 .. 3 only.
 template <int M, int NMAX, bool SPEC, bool VEC4, bool VAL = false, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restrict__ Qs, const uint4* __restrict__ IB,
                                                          const uint4* __restrict__ IB2, const double2* __restrict__ FB,
@@ -159,8 +167,19 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
     constexpr int TU2 = i8_tile_units2(M);
     constexpr int CH = TPP * NKB * NS;                 // 1-KiB chunks per phase
     static_assert(M >= 6 && M <= 16, "6 <= m <= 16 (row classes below, run-time-m kernels above)");
-    __shared__ uint4 stage[2][CH * 64];
-    __shared__ v4i32 a56[4][NKB][ND - NS][64];         // digits 5, 6 of q, per wave and LANE (each lane reads back its own)
+    // ONE __shared__ object: with a second one hipcc (ROCm 7.2) can no longer tell the LDS-DMA writes of the NEXT phase from
+    // the ds_reads of this one and drains vmcnt(0) in front of every phase's first ds_read -- the staging loads it has just
+    // issued AND the spectrum stores issued before the barrier (seen in the second form's .s; it cost 0.2 ms of config 3's 0.8)
+    __shared__ uint4 lds_all[2 * CH * 64 + 4 * NKB * (ND - NS) * 64];
+    uint4 (*stage)[CH * 64] = reinterpret_cast<uint4 (*)[CH * 64]>(&lds_all[0]);
+    // digits 5, 6 of q, per wave and LANE (each lane reads back its own)
+    v4i32 (*a56)[NKB][ND - NS][64] = reinterpret_cast<v4i32 (*)[NKB][ND - NS][64]>(&lds_all[2 * CH * 64]);
+    // Spectrum stores and the tiles' arithmetic (profiles/r04_i8_scan_ablations.txt): the stores alone run at 5.3 TB/s (0.44 ms for
+    // config 3), the arithmetic alone takes 0.53 ms, together 0.73 -- a wave blocks at a store until the write path accepts it,
+    // and three waves per SIMD cover that as far as a closed queue of three customers does.  What did NOT change it, each built
+    // and measured: the stores in flight across the next step's wait (vmcnt(4) behind the staging loads; vmcnt retires in issue
+    // order -- hipcc's own counted waits rely on it), one store behind every tile of the next step from a second register set,
+    // workgroups started a fraction of a step apart, 256-B aligned rows, plain instead of nt / sc stores.
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -263,33 +282,70 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
 
     int buf = 0;
     v4f32 sv[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    float* __restrict__ spec_base = SPEC ? spec + (size_t)item0 * res : nullptr;
+    float* __restrict__ spec_base = SPEC ? spec + (size_t)item0 * ((ABL & 2048) ? (res & ~63u) : res) : nullptr;
     [[maybe_unused]] __amdgpu_buffer_rsrc_t spec_rsrc = __builtin_amdgcn_make_buffer_rsrc(spec_base, 0, 0x7FFFFFFF, 0x00020000);
     uint32_t soff[4];
     bool row_ok[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        soff[r] = ((uint32_t)(g + 4 * r) * res + 4u * (uint32_t)c) * 4u;
+        soff[r] = ((uint32_t)(g + 4 * r) * ((ABL & 2048) ? (res & ~63u) : res) + 4u * (uint32_t)c) * 4u;    // (2048, lab: rows 256-B aligned)
         row_ok[r] = (item0 + (uint32_t)(g + 4 * r)) < batch;
     }
     uint32_t refined = 0, fell = 0;
-    [[maybe_unused]] float worst5 = 0.0f, worst7 = 0.0f;
+    [[maybe_unused]] float worst5 = 0.0f, worst7 = 0.0f, worst4 = 0.0f;
 
+    if constexpr ((ABL & 1024) != 0) {      // lab: workgroups start up to ~one step apart (their spectrum stores no longer arrive in one burst)
+        const uint32_t frac = ((blockIdx.x * 0x9E3779B1u) >> 28) & 15u;          // 0 .. 15 sixteenths of ~8,000 cycles
+        for (uint32_t i = 0; i < frac; ++i) __builtin_amdgcn_s_sleep(8);        // 8 x 64 cycles
+    }
     if (st_begin < st_end) stage_load(st_begin, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const uint32_t nobin = ~keep_mask;
     const int nn = (int)M - (int)n;
-    constexpr bool FOLD = (NKB == 1);                  // level 3 starts from floor(A_4 / 256) (else: one shift + add per value)
     constexpr bool PAIR23 = i8_pair_ok(MM, 2);         // A_2 256 + A_3 (+ A_4 / 256) fits an int32 (m <= 13)
-    const double ws_d = ip.wt[NS - 2];                 // weight of the bulk form's integer V (level 3)
+    const double ws_d = ip.wt[NS - 2];                 // weight of the integer V of both bulk forms (level 3)
     const float ws_f = ip.ws_f;
-    // the row's threshold of the ONE comparison per value: under it the value may enter the row's list (top-n gate), or
-    // needs the seven-digit form (T), or lies outside the table / belongs to an item without digits (V = 0)
-    float thr_f[4];
+    const float t4_f = ip.t4_f;
+    // the row's thresholds of the ONE comparison per value and tier: at or under thr4 a four-digit value needs the second tier
+    // (T4) or may enter the row's list (top-n gate), or lies outside the table / belongs to an item without digits (V = 0);
+    // at or under thr5 a five-digit value needs the seven-digit form (T) or may enter the list
+    float thr4[4], thr5[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) thr_f[r] = __builtin_inff();
+    for (int r = 0; r < 4; ++r) thr4[r] = thr5[r] = __builtin_inff();
+    // this wave's 16 rows x 64 bins of step `sst`: a 16-B store per lane and row, 256 B contiguous per row
+    auto store_rows = [&](const uint32_t sst) __attribute__((always_inline)) {
+        const uint32_t sbin = sst * 64 + 4 * (uint32_t)c;
+        const bool stail = sst * 64 + 64 > res;
+        if constexpr (SPEC && !(ABL & 1)) {
+            const int step_off = (ABL & 4096) ? 0 : (int)(sst * 256u);       // (4096, lab: every step overwrites the row's first piece)
+            if constexpr (VEC4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (!stail) {                       // wave-uniform: whole step inside the row
+                        if (row_ok[r]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, (ABL & 64) ? 0 : (1 | 2 | 16));
+                    } else {
+                        if (row_ok[r] && sbin < res) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, (1 | 2 | 16));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const v4u32 u = __builtin_bit_cast(v4u32, sv[r]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (row_ok[r] && sbin + t < res)
+                            __builtin_amdgcn_raw_buffer_store_b32(u[t], spec_rsrc, (int)(soff[r] + 4u * t), step_off, (1 | 2 | 16));
+                }
+            }
+        } else if constexpr (SPEC) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(sv[r]));
+        }
+    };
+    [[maybe_unused]] long long t_wait = 0, t_store = 0, t_bar = 0;       // (8192, lab: s_memtime around the step end's three parts)
+    [[maybe_unused]] const long long t_loop0 = ((ABL & 8192) != 0) ? (long long)__builtin_readcyclecounter() : 0;
     for (uint32_t st = st_begin; st < st_end; ++st) {
         const uint32_t bin = st * 64 + 4 * (uint32_t)c;          // this lane's first bin of the step (tile t: bin + t)
         const bool tail_step = st * 64 + 64 > res;               // wave-uniform: the step reaches beyond the table
@@ -300,73 +356,104 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
             if constexpr (!(ABL & 8)) {
                 if (more) stage_load(last_p ? st + 1 : st, last_p ? 0 : p + 1, buf ^ 1);
             }
+            if constexpr (ABL & 32) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sv[r] = (v4f32){1.0f, 2.0f, 3.0f, (float)st};
+            }
             if (p == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(sv[r]));      // (see scan_mfma_kernel: the store data stays put)
             }
 
-            const v4i32* __restrict__ Bp = reinterpret_cast<const v4i32*>(&stage[buf][0]) + lane;
+            const v4i32* __restrict__ Bp = reinterpret_cast<const v4i32*>(&stage[(ABL & 8) ? 0 : buf][0]) + lane;
 #pragma unroll
-            for (int tl = 0; tl < TPP; ++tl) {
+            for (int tl = 0; tl < ((ABL & 32) ? 0 : TPP); ++tl) {
                 const int t = p * TPP + tl;
-                // ---- the tile's 15 NKB int8 MFMAs ------------------------------------------------------------------------
+                // ---- first tier: the 10 NKB MFMAs of the four leading digits, levels 0 .. 3 -------------------------------
                 v4i32 L[NS];
-                if constexpr (FOLD) {
-                    v4i32 b[NS];
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) b[s] = Bp[(tl * NS + s) * 64];
-                    bool started[NS] = {false, false, false, false, false};
+                for (int l = 0; l < NS; ++l) L[l] = (v4i32){0, 0, 0, 0};
+                v4i32 b0[NS - 1];                       // (one block of terms: the second tier reuses these registers)
 #pragma unroll
-                    for (int i = 0; i < 15; ++i) {
-                        const int sq_ = i8_fold_s(i), l = i8_fold_l(i);
-                        v4i32 cin = {0, 0, 0, 0};
-                        if (started[l]) cin = L[l];
-                        else if (l == 3) cin = (v4i32){L[4][0] >> 8, L[4][1] >> 8, L[4][2] >> 8, L[4][3] >> 8};   // (all level-4 pairs precede)
-                        if constexpr (ABL & 4) L[l] = cin + (b[l - sq_] ^ A[0][sq_]);
-                        else L[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0][sq_], b[l - sq_], cin, 0, 0, 0);
-                        started[l] = true;
+                for (int kb = 0; kb < NKB; ++kb) {
+                    v4i32 b[NS - 1];
+#pragma unroll
+                    for (int s = 0; s < NS - 1; ++s) b[s] = Bp[((tl * NKB + kb) * NS + s) * 64];
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) {
+                        const int sq_ = i8_t1_s(i), l = i8_t1_l(i);
+                        if constexpr (ABL & 4) L[l] += b[l - sq_] ^ A[kb][sq_];
+                        else L[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][sq_], b[l - sq_], L[l], 0, 0, 0);
                     }
-                } else {
+                    if constexpr (NKB == 1) {
 #pragma unroll
-                    for (int l = 0; l < NS; ++l) L[l] = (v4i32){0, 0, 0, 0};
-#pragma unroll
-                    for (int kb = 0; kb < NKB; ++kb) {
-                        v4i32 b[NS];
-#pragma unroll
-                        for (int s = 0; s < NS; ++s) b[s] = Bp[((tl * NKB + kb) * NS + s) * 64];
-#pragma unroll
-                        for (int i = 0; i < 15; ++i) {
-                            const int sq_ = i8_order_s(i), l = i8_order_l(i);
-                            if constexpr (ABL & 4) L[l] += b[l - sq_] ^ A[kb][sq_];
-                            else L[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][sq_], b[l - sq_], L[l], 0, 0, 0);
-                        }
+                        for (int s = 0; s < NS - 1; ++s) b0[s] = b[s];
                     }
                 }
-                // ---- bulk form: V from two (three) int32 words, one comparison, one reciprocal per value -------------------
+                // ---- four-digit form: V from two (three) int32 words, one comparison, one reciprocal per value ------------
                 v4f64 vd;
+                float fdv[4];
                 bool under = false;
+                if constexpr (ABL & 128) {
+#pragma unroll
+                    for (int l = 0; l < NS; ++l) asm volatile("" ::"v"(L[l]));
+                    vd = (v4f64){1.0, 1.0, 1.0, 1.0};
+                } else
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int l3 = FOLD ? L[3][r] : L[3][r] + (L[4][r] >> 8);
                     const int hw = L[0][r] * 256 + L[1][r];
-                    if constexpr (PAIR23) vd[r] = __builtin_fma((double)hw, 65536.0, (double)(L[2][r] * 256 + l3));
-                    else vd[r] = __builtin_fma(__builtin_fma((double)hw, 256.0, (double)L[2][r]), 256.0, (double)l3);
-                    const float fd = fabsf((float)vd[r]) * ws_f;
-                    under |= (fd <= thr_f[r]);
-                    if constexpr (SPEC) sv[r][t] = __builtin_amdgcn_rcpf(fd);
+                    if constexpr (PAIR23) vd[r] = __builtin_fma((double)hw, 65536.0, (double)(L[2][r] * 256 + L[3][r]));
+                    else vd[r] = __builtin_fma(__builtin_fma((double)hw, 256.0, (double)L[2][r]), 256.0, (double)L[3][r]);
+                    fdv[r] = fabsf((float)vd[r]) * ws_f;
+                    under |= (fdv[r] <= thr4[r]);
+                    if constexpr (SPEC) sv[r][t] = __builtin_amdgcn_rcpf(fdv[r]);
                 }
+                if (VAL || __any(under)) {
+                    // ======== second tier (wave-uniform branch): the 5 NKB MFMAs of level 4; the values at or below T4 take the
+                    // five-digit form d5 = d4 + floor(A_4 / 256) wt[3], per value ============================================
+                    [[maybe_unused]] const v4f64 d4 = {vd[0] * ws_d, vd[1] * ws_d, vd[2] * ws_d, vd[3] * ws_d};
+                    bool form4[4], need5 = false;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        form4[r] = !VAL && (fdv[r] > t4_f);                  // per VALUE: its own four-digit value decides
+                        need5 |= !form4[r];
+                    }
+                    if (VAL || __any(need5)) {          // (a tile that only holds candidates of the top-n lists skips the MFMAs)
+#pragma unroll
+                        for (int kb = 0; kb < NKB; ++kb) {
+                            v4i32 b[NS];
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) {
+                                if (NKB == 1 && s < NS - 1) b[s] = b0[s];
+                                else b[s] = Bp[((tl * NKB + kb) * NS + s) * 64];
+                            }
+#pragma unroll
+                            for (int sq_ = 0; sq_ < NS; ++sq_) L[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[kb][sq_], b[4 - sq_], L[4], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double v5 = vd[r] + (double)(L[4][r] >> 8);
+                            const float f5 = fabsf((float)v5) * ws_f;
+                            vd[r] = form4[r] ? vd[r] : v5;
+                            fdv[r] = form4[r] ? fdv[r] : f5;
+                            if constexpr (SPEC) sv[r][t] = __builtin_amdgcn_rcpf(fdv[r]);
+                        }
+                    }
+                    under = false;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) under |= (fdv[r] <= thr5[r]);
                 if (VAL || __any(under)) {
                     // ======== everything that is not the bulk of the values (wave-uniform branch) ========================
                     v4f64 d;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) d[r] = vd[r] * ws_d;                // d5, exactly
+                    for (int r = 0; r < 4; ++r) d[r] = vd[r] * ws_d;                // d4 or d5, exactly
                     [[maybe_unused]] const v4f64 d5 = d;
-                    // Values at or below T: two more digits of both operands (levels 5 and 6 on top of the accumulated ones:
-                    // 13 NKB MFMAs) and the low byte of the level-4 sum; digits 5, 6 of q from this lane's LDS slot, of F from
-                    // the image in L2.
+                    // Five-digit values at or below T: two more digits of both operands (levels 5 and 6 on top of the accumulated
+                    // ones: 13 NKB MFMAs) and the low byte of the level-4 sum; digits 5, 6 of q from this lane's LDS slot, of F
+                    // from the image in L2.
                     bool lowt = false;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) lowt |= !(fabs(d[r]) > tacc_d);
+                    for (int r = 0; r < 4; ++r) lowt |= !form4[r] && !(fabs(d[r]) > tacc_d);
                     if (VAL || __any(lowt)) {
                         ++fell;
                         v4i32 L5 = {0, 0, 0, 0}, L6 = {0, 0, 0, 0};
@@ -398,9 +485,9 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
                             const double low = __builtin_fma((double)(L[4][r] & 255), ip.wt[4],
                                                              __builtin_fma((double)L5[r], ip.wt[5], (double)L6[r] * ip.wt[6]));
                             const double d7 = d[r] + low;
-                            // Per VALUE: only a d at or below T is replaced, so what an (item, bin) pair gets never depends on which
-                            // items share its wave or on how a batch was cut (the rule of literal_tile()).
-                            const bool take = VAL || !(fabs(d[r]) > tacc_d);
+                            // Per VALUE: only a five-digit d at or below T is replaced, so what an (item, bin) pair gets never depends
+                            // on which items share its wave or on how a batch was cut (the rule of literal_tile()).
+                            const bool take = VAL || (!form4[r] && !(fabs(d[r]) > tacc_d));
                             d[r] = take ? d7 : d[r];
                         }
                     }
@@ -413,9 +500,11 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
                             if constexpr (VAL) {
                                 const float r5 = (float)(fabs(d5[r] - ex[r]) / ip.e_bound);
                                 const float r7 = (float)(fabs(d[r] - ex[r]) / (ip.e_refined + 0x1p-50 * fabs(ex[r])));
+                                const float r4 = (float)(fabs(d4[r] - ex[r]) / ip.e4_bound);
                                 const bool counts = sane_r[r] && row_ok[r] && bin + t < res;        // (NaN never counts)
                                 if (counts && r5 > worst5) worst5 = r5;
                                 if (counts && r7 > worst7) worst7 = r7;
+                                if (counts && r4 > worst4) worst4 = r4;
                             }
                             d[r] = (VAL || !sane_r[r]) ? ex[r] : d[r];
                         }
@@ -460,51 +549,48 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
                             const uint64_t kb = __builtin_bit_cast(uint64_t, key[r][NMAX - 1]) | (uint64_t)(~keep_mask);
                             gate_d[r] = fmax(__builtin_bit_cast(double, kb), below_d);
                             gate_f[r] = (float)gate_d[r];
-                            // the bulk path's threshold: at least the gate (rounded up where the gate is kept in fp64), at least T
+                            // the bulk paths' thresholds: at least the gate (rounded up where the gate is kept in fp64), at least T4 / T
                             float gu = gate_f[r];
                             if constexpr (!SPEC) gu = ((double)gu < gate_d[r]) ? __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, gu) + 1u) : gu;   // (gu >= 0, finite here)
-                            thr_f[r] = fmaxf(gu, ip.t_acc_f);
+                            thr4[r] = fmaxf(gu, t4_f);
+                            thr5[r] = fmaxf(gu, ip.t_acc_f);
                         }
                     }
+                }
                 }
             }
 
-            // the next phase's operands have landed (and the PREVIOUS step's stores are done) ...
-            if constexpr (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // ... then this step's spectrum stores, then the barrier
-            if (last_p) {
-                if constexpr (SPEC && !(ABL & 1)) {
-                    const int step_off = (int)(st * 256u);
-                    if constexpr (VEC4) {
-                        if (!tail_step) {                       // wave-uniform: whole step inside the row
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (row_ok[r]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, (1 | 2 | 16));
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (row_ok[r] && bin < res) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, (1 | 2 | 16));
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const v4u32 u = __builtin_bit_cast(v4u32, sv[r]);
-#pragma unroll
-                            for (int t = 0; t < 4; ++t)
-                                if (row_ok[r] && bin + t < res)
-                                    __builtin_amdgcn_raw_buffer_store_b32(u[t], spec_rsrc, (int)(soff[r] + 4u * t), step_off, (1 | 2 | 16));
-                        }
-                    }
-                } else if constexpr (SPEC) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(sv[r]));
-                }
+            [[maybe_unused]] long long tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0;
+            if constexpr ((ABL & 8192) != 0) tm0 = __builtin_readcyclecounter();
+            if constexpr (!(ABL & 8)) {
+                // the next phase's operands have landed (and the PREVIOUS step's stores are done) ...
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if constexpr (!(ABL & 8)) __syncthreads();
+            if constexpr ((ABL & 8192) != 0) tm1 = __builtin_readcyclecounter();
+            // ... then this step's spectrum stores, then the barrier
+            if (last_p) store_rows(st);                                  // ... then this step's spectrum stores, then the barrier
+            if constexpr ((ABL & 8192) != 0) tm2 = __builtin_readcyclecounter();
+            // (a raw barrier: __syncthreads() would put a vmcnt(0) in front of it -- the LDS-DMA writes are LDS writes to the
+            // compiler -- and wait for the stores just issued; this phase's ds_reads have been consumed by its MFMAs)
+            if constexpr (!(ABL & 8)) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if constexpr ((ABL & 8192) != 0) {
+                tm3 = __builtin_readcyclecounter();
+                t_wait += tm1 - tm0; t_store += tm2 - tm1; t_bar += tm3 - tm2;
+            }
             buf ^= 1;
         }
     }
-
+    if constexpr ((ABL & 8192) != 0) {
+        if (stat && lane == 0) {
+            atomicAdd(stat + 4, (unsigned long long)t_wait);
+            atomicAdd(stat + 5, (unsigned long long)t_store);
+            atomicAdd(stat + 6, (unsigned long long)t_bar);
+            atomicAdd(stat + 7, (unsigned long long)((long long)__builtin_readcyclecounter() - t_loop0));
+        }
+    }
     if (rf.count) {
 #pragma unroll
         for (int msk = 1; msk < 64; msk <<= 1) refined += __shfl_xor(refined, msk, 64);
@@ -516,15 +602,18 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
     }
     if constexpr (VAL) {
         unsigned int w5 = __builtin_bit_cast(unsigned int, worst5), w7 = __builtin_bit_cast(unsigned int, worst7);
+        unsigned int w4 = __builtin_bit_cast(unsigned int, worst4);
 #pragma unroll
         for (int msk = 1; msk < 64; msk <<= 1) {
-            const unsigned int o5 = __shfl_xor(w5, msk, 64), o7 = __shfl_xor(w7, msk, 64);
+            const unsigned int o5 = __shfl_xor(w5, msk, 64), o7 = __shfl_xor(w7, msk, 64), o4 = __shfl_xor(w4, msk, 64);
             w5 = o5 > w5 ? o5 : w5;
             w7 = o7 > w7 ? o7 : w7;
+            w4 = o4 > w4 ? o4 : w4;
         }
         if (lane == 0 && margin) {                                 // ratios >= 0: their bits order like the values
             atomicMax(margin, (unsigned long long)w5);
             atomicMax(margin + 1, (unsigned long long)w7);
+            atomicMax(margin + 2, (unsigned long long)w4);
         }
     }
 #pragma unroll

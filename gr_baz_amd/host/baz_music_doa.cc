@@ -108,12 +108,17 @@ baz_music_doa::baz_music_doa(unsigned int m, unsigned int n, unsigned int nsampl
      *                              a single item is still a valid call, and nothing is lost at the end of a stream: the
      *                              runtime preloads the H look-back items as zeros (buffer_add_reader(.., history - 1)),
      *                              output i is computed from input i + H, i.e. from real item i.
-     * The block uses the second: BAZ_MUSIC_INPUT_LOOKBACK = H (default 1024 items; 0 = none), output multiple 1,
+     * The block uses the second: BAZ_MUSIC_INPUT_LOOKBACK = H (0 = none; default 1024 items, fewer where items are large:
+     * H = 16 MiB / the larger of an input item and a spectrum row, between 8 and 1024 -- the doubly mapped circular buffers
+     * are 2 (H + 2) items and must fit /dev/shm: config 2 keeps 1024 (16.8 MB in, 29.5 MB spectrum), config 3 (144 KB rows)
+     * gets 116, 64 antennas x 256 columns (128 KiB items) 128 instead of a 268 MB buffer), output multiple 1,
      * set_min_output_buffer(2 H) so that the output side admits the same calls (a call takes at most half a buffer).
      * BAZ_MUSIC_OUTPUT_MULTIPLE (1), BAZ_MUSIC_MIN_OUTPUT_BUFFER, BAZ_MUSIC_MAX_NOUTPUT (0 = no cap) override.
      * What the runtime makes of them (call sizes per work()) is modelled in gr_shim/gnuradio/flowgraph_model.h;
      * INTEGRATION.md 5 has the memory these requests cost and the measured rates. */
-    const long lookback = env_long("BAZ_MUSIC_INPUT_LOOKBACK", 1024, 0, 1 << 20);
+    const size_t big_item = std::max<size_t>((size_t)nsamples * sizeof(gr_complex), (size_t)resolution * sizeof(float));
+    const long lookback_dflt = (long)std::max<size_t>(8, std::min<size_t>(1024, ((size_t)16 << 20) / big_item));
+    const long lookback = env_long("BAZ_MUSIC_INPUT_LOOKBACK", lookback_dflt, 0, 1 << 20);
     const long multiple = env_long("BAZ_MUSIC_OUTPUT_MULTIPLE", 1, 1, 1 << 20);
     const long min_buffer = env_long("BAZ_MUSIC_MIN_OUTPUT_BUFFER", std::max(2 * lookback, multiple > 1 ? 8 * multiple : 0L), 0, 1L << 30);
     const long cap = env_long("BAZ_MUSIC_MAX_NOUTPUT", 0, 0, 1L << 30);

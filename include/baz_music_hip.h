@@ -146,19 +146,21 @@ BAZ_MUSIC_API int baz_music_debug_coarse_margin(baz_music_ctx* ctx, const void* 
  *                          read (the counter resets); -1 unless the context was created under BAZ_MUSIC_COARSE_STATS=1. */
 BAZ_MUSIC_API int64_t baz_music_debug_coarse_fired(baz_music_ctx* ctx);
 /*   int8 scan   : from 6 to BAZ_MUSIC_FAST_M antennas (n <= 4) the scan evaluates d = a^H Q a on the int8 matrix core with both
- *                          operands cut into balanced base-256 digits -- integer accumulation, no rounding.  The bulk of the values
- *                          uses five digits and is kept only where the a-priori bound |d5 - d| <= E5 = m^2 Fscale 5.05 2^-38 makes
- *                          it accurate to 7.5e-7; a 16-item x 16-bin tile holding a smaller value adds two digits (error
- *                          <= m^2 Fscale 7.07 2^-54 + 2^-53 d: the accuracy class of the fp64 form); near-null values take the
- *                          reference's literal form as in the fp64 scan (gr_baz_amd/csrc/scan_i8_kernels.hip.h; BAZ_MUSIC_EXACT=1
- *                          at create keeps the fp64 scan).  `margin` runs covariance + EVD of the batch and then the bulk, the
- *                          refined and the fp64 form on every (item, bin): worst[0] = the largest observed |d5 - d| / E5 (the
- *                          bound holds while it stays below 1), worst[1] = the largest |d7 - d| / (its bound + the fp64 form's own
- *                          worst-case error).  `stats` returns and resets the wave tiles that ran the refined form / walked since
- *                          the last read.  `uses_i8_scan`: 1 when that scan is the one this context runs.  `i8_image` needs no
- *                          device: the digit images of a table (size returned; written when out_bytes suffices: five leading
- *                          digits, then digits 5 and 6) and params = {7 level weights, 2^54, T, E5, refined allowance, 5, 7}. */
-BAZ_MUSIC_API int baz_music_debug_i8_margin(baz_music_ctx* ctx, const void* d_in, uint32_t batch, float worst[2]);
+ *                          operands cut into balanced base-256 digits -- integer accumulation, no rounding.  Every value is
+ *                          first evaluated with four digits (error <= E4 = m^2 Fscale 4.04 2^-30) and keeps that form where it is
+ *                          accurate to 7.5e-7; the others take five digits (E5 = m^2 Fscale 5.05 2^-38 + Fscale 2^-36), and where
+ *                          even that is not accurate to 7.5e-7, seven (error <= m^2 Fscale 7.07 2^-54 + 2^-53 d: the accuracy class
+ *                          of the fp64 form) -- decided per value by that value alone; near-null values take the reference's
+ *                          literal form as in the fp64 scan (gr_baz_amd/csrc/scan_i8_kernels.hip.h; BAZ_MUSIC_EXACT=1 at create
+ *                          keeps the fp64 scan).  `margin` runs covariance + EVD of the batch and then every form on every
+ *                          (item, bin): worst[0] = the largest observed |d5 - d| / E5 (the bound holds while it stays below 1),
+ *                          worst[1] = the largest |d7 - d| / (its bound + the fp64 form's own worst-case error), worst[2] = the
+ *                          largest |d4 - d| / E4.  `stats` returns and resets the wave tiles that ran the seven-digit form /
+ *                          walked since the last read.  `uses_i8_scan`: 1 when that scan is the one this context runs.
+ *                          `i8_image` needs no device: the digit images of a table (size returned; written when out_bytes
+ *                          suffices: five leading digits, then digits 5 and 6) and params[16] = {7 level weights, 2^54, T, E5,
+ *                          refined allowance, 5, 7, E4, T4}. */
+BAZ_MUSIC_API int baz_music_debug_i8_margin(baz_music_ctx* ctx, const void* d_in, uint32_t batch, float worst[3]);
 BAZ_MUSIC_API int baz_music_debug_i8_stats(baz_music_ctx* ctx, uint64_t* refined_tiles, uint64_t* tiles);
 BAZ_MUSIC_API int baz_music_uses_i8_scan(const baz_music_ctx* ctx);
 BAZ_MUSIC_API size_t baz_music_debug_i8_image(uint32_t m, uint32_t resolution, const float* table_ri, uint8_t* out,

@@ -11,8 +11,14 @@ from gr_baz_amd import capi, synth
 from gr_baz_amd.baz.music_doa_helper import calculate_antenna_array_response
 
 dev = torch.device("cuda:0")
-NAMES = {0: "product", 1: "no stores", 4: "no MFMAs", 5: "no MFMAs, no stores", 8: "no staging / waits / barriers",
-         9: "no staging / waits / barriers, no stores", 13: "LDS reads + per-value vector work only"}
+NAMES = {0: "product", 1: "no stores", 4: "no MFMAs", 5: "no MFMAs, no stores", 8: "first phase staged only: no staging / waits / barriers",
+         9: "the same without stores: the tiles' arithmetic alone", 16: "stores in flight across the next wait (scrap loads, vmcnt(4))",
+         17: "the same without the stores", 32: "staging + barriers + stores, no arithmetic", 40: "stores alone", 64: "plain stores (no nt / sc)",
+         96: "staging + barriers + plain stores, no arithmetic", 1024: "workgroups start up to one step apart", 2048: "rows 256-B aligned (stride rounded down to 64 bins)",
+         2088: "stores alone, rows 256-B aligned", 4096: "every step stores to the row's first 256 B",
+         4104: "the same without staging / waits / barriers", 4136: "stores alone, to the row's first 256 B", 137: "arithmetic alone: LDS reads + MFMAs, no per-value work",
+         265: "arithmetic alone: LDS reads + per-value work, no MFMAs", 393: "arithmetic alone: LDS reads only", 521: "arithmetic alone with 10 MFMAs per tile"}
+ABLS = [int(v) for v in sys.argv[1:]] or [0, 1, 8, 9, 32, 40, 64, 96]
 for M, NE, N, RES, B in ((8, 2, 4096, 36000, 16384), (16, 2, 4096, 3600, 16384)):
     arr = synth.array_geometry(M)
     table = np.array(calculate_antenna_array_response([[0.5 * x, 0.5 * y] for x, y in arr], RES, 1.0)).astype(np.complex64)
@@ -20,7 +26,7 @@ for M, NE, N, RES, B in ((8, 2, 4096, 36000, 16384), (16, 2, 4096, 3600, 16384))
     ang = torch.zeros(B, NE, dtype=torch.float32, device=dev)
     lvl = torch.zeros_like(ang)
     spec = torch.zeros(B, RES, dtype=torch.float32, device=dev)
-    for abl in (0, 1, 4, 5, 8, 9, 13):
+    for abl in ABLS:
         os.environ["BAZ_MUSIC_I8_ABL"] = str(abl)
         with capi.Context(M, NE, N, RES, table, lab=True) as ctx:
             ctx.reserve(B)
@@ -34,6 +40,14 @@ for M, NE, N, RES, B in ((8, 2, 4096, 36000, 16384), (16, 2, 4096, 3600, 16384))
             ctx.sync()
             t, k = ctx.stage_ms(capi.STAGE_SCAN)
             ctx.profile(False)
-        print("m%d res%d %d items: scan %.3f ms  (%s)" % (M, RES, B, t / k, NAMES[abl]), flush=True)
+            extra = ""
+            if abl & 8192:
+                import ctypes
+                v = (ctypes.c_uint64 * 4)()
+                ctx._L.baz_music_debug_i8_times(ctx._h, v)
+                tot = max(1, v[3])
+                extra = " | per wave: wait %.1f %%, stores %.1f %%, barrier %.1f %% of the step loop (%.0f cycles per step and wave)" % (
+                    100.0 * v[0] / tot, 100.0 * v[1] / tot, 100.0 * v[2] / tot, v[3] / (15.0 * (B / 16.0) * ((RES + 63) // 64)))
+        print("m%d res%d %d items: scan %.3f ms  (%s)%s" % (M, RES, B, t / k, NAMES.get(abl, str(abl)), extra), flush=True)
     del x, spec
     torch.cuda.empty_cache()

@@ -106,6 +106,8 @@ def test_digit_images_equal_the_numpy_restatement(m, res):
     assert par["sq"] == sq and par["e_bound"] == E5 and par["t_acc"] == E5 * (1.0 + 1.0 / EPS)
     assert np.array_equal(par["wt"], [fs * 2.0 ** (-12 - 8 * l) for l in range(ND)])
     assert par["e_refined"] == m * m * fs * 2.0 ** -54 * (7.07 + 2.0 * m * m)
+    E4 = m * m * fs * (NS - 1) * 1.01 * 2.0 ** (2 - 8 * (NS - 1))
+    assert par["e4_bound"] == E4 and par["t4"] >= E4 * (1.0 + 1.0 / EPS) > par["t4"] * (1.0 - 2.0 ** -23)    # T4 as the next float up
 
 
 def _integer_forms(qd, Fd, wt):
@@ -114,7 +116,10 @@ def _integer_forms(qd, Fd, wt):
     the low byte of A_4 and levels 5 and 6 of all seven digits on top for the refined one."""
     d5 = np.zeros((qd[0].shape[0], Fd[0].shape[0]))
     tail = np.zeros_like(d5)
+    d4 = None
     for l in range(NS):
+        if l == NS - 1:
+            d4 = d5.copy()                               # the first tier: four leading digits, levels 0 .. 3
         A = sum(qd[s] @ Fd[l - s].T for s in range(l + 1))
         assert np.abs(A).max() < 2 ** 31 // 256
         if l == NS - 1:
@@ -126,7 +131,7 @@ def _integer_forms(qd, Fd, wt):
         A = sum(qd[s] @ Fd[l - s].T for s in range(l + 1))
         assert np.abs(A).max() < 2 ** 31
         tail += A.astype(np.float64) * wt[l]
-    return d5, d5 + tail
+    return d5, d5 + tail, d4
 
 
 @pytest.mark.parametrize("scale", [1.0, 3e-12, 7e11])
@@ -146,13 +151,17 @@ def test_integer_forms_from_the_images_stay_inside_their_bounds(m, scale):
     q = q_image(G @ G.conj().transpose(0, 2, 1))
     assert np.abs(q).max() <= 1.0 + 1e-12               # a projector's coefficients (what the kernel's sanity check admits)
     qd = digits(fixed(q, par["sq"]))
-    d5, d7 = _integer_forms(qd, Fd, par["wt"])
+    d5, d7, d4 = _integer_forms(qd, Fd, par["wt"])
     F = f_image(table)
     d = q.astype(np.longdouble) @ F.T.astype(np.longdouble)
     err5 = np.abs(d5 - d).astype(np.float64).max()
     assert err5 <= par["e_bound"], (err5, par["e_bound"])
     keep = d5 > par["t_acc"]
     assert keep.mean() > 0.9 and (np.abs(d5 - d)[keep] / d[keep]).max() <= EPS
+    err4 = np.abs(d4 - d).astype(np.float64).max()
+    assert err4 <= par["e4_bound"], (err4, par["e4_bound"])
+    keep4 = d4 > par["t4"]
+    assert keep4.mean() > 0.8 and (np.abs(d4 - d)[keep4] / d[keep4]).max() <= EPS
     fs = fscale_of(np.abs(F).max())
     allow7 = m * m * fs * 7.07 * 2.0 ** -54 + 2.0 ** -53 * np.abs(d).astype(np.float64)
     err7 = np.abs(d7 - d).astype(np.float64)
@@ -265,7 +274,7 @@ def test_config_shapes_mostly_take_the_integer_form(m, n, nsamples, res, batch, 
 @pytest.mark.parametrize("m,n,K", [(6, 2, 64), (7, 3, 40), (8, 2, 128), (9, 1, 64), (10, 2, 100), (11, 2, 64), (12, 4, 64), (13, 2, 64), (14, 2, 64),
                                    (15, 3, 64), (16, 2, 256)])
 def test_error_bounds_hold_on_the_hardware(m, n, K, gpu_device):
-    """All three forms on EVERY (item, bin): the worst |d5 - d| / E5 must stay below 1 (E5 is a worst-case bound: typical
+    """All four forms on EVERY (item, bin): the worst |d4 - d| / E4 and |d5 - d| / E5 must stay below 1 (E5 is a worst-case bound: typical
     digits give ~0.1), and the refined form must agree with the fp64 form within its allowance; coherent and incoherent
     scenes, 0 ... 60 dB."""
     import torch
@@ -274,11 +283,12 @@ def test_error_bounds_hold_on_the_hardware(m, n, K, gpu_device):
         table, items = _scene(m, n, m * K, res, 200, snr, 600 + m + int(snr), inc)
         x = torch.from_numpy(np.ascontiguousarray(items).view(np.float32)).to(gpu_device)
         with _capi().Context(m, n, m * K, res, table) as ctx:
-            w5, w7 = ctx.debug_i8_margin(x.data_ptr(), items.shape[0])
-        assert 0.0 < w5 < 0.5, "m=%d snr=%g: worst bulk error / bound = %.3g" % (m, snr, w5)
-        assert 0.0 <= w7 < 0.5, "m=%d snr=%g: worst refined error / allowance = %.3g" % (m, snr, w7)
-        print("m=%d n=%d snr=%g %s: worst |d5 - d| / E5 = %.3g, worst |d7 - d| / allowance = %.3g"
-              % (m, n, snr, "incoherent" if inc else "coherent", w5, w7))
+            w5, w7, w4 = ctx.debug_i8_margin(x.data_ptr(), items.shape[0])
+        assert 0.0 < w5 < 0.5, "m=%d snr=%g: worst five-digit error / bound = %.3g" % (m, snr, w5)
+        assert 0.0 <= w7 < 0.5, "m=%d snr=%g: worst seven-digit error / allowance = %.3g" % (m, snr, w7)
+        assert 0.0 < w4 < 0.5, "m=%d snr=%g: worst four-digit error / bound = %.3g" % (m, snr, w4)
+        print("m=%d n=%d snr=%g %s: worst |d4 - d| / E4 = %.3g, |d5 - d| / E5 = %.3g, |d7 - d| / allowance = %.3g"
+              % (m, n, snr, "incoherent" if inc else "coherent", w4, w5, w7))
 
 
 @pytest.mark.gpu
