@@ -132,6 +132,7 @@ struct baz_music_ctx {
     bool i8_ok = false;            // image built (finite table, scale representable, size within I8_IMAGE_LIMIT)
     int i8_on = 1;                 // BAZ_MUSIC_EXACT=1: every value on the fp64 matrix core (A/B; the round-3 scan)
     int i8_abl = 0;                // lab (BAZ_MUSIC_I8_ABL): ablation mask of scan_i8_kernel (timing only)
+    int refine_nocount = 0;        // lab (BAZ_MUSIC_NO_REFINE_COUNT): the scans do not count the values they recompute
     uint32_t num_cus = 256;        // compute units of the device (launch geometry of scan_i8_kernel)
     int i8_wgs_per_cu[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};   // [NMAX > 2][SPEC][VEC4]: resident workgroups per CU (occupancy API, on first use)
     unsigned long long* dI8Stat = nullptr;   // [0] wave tiles that ran the refined form, [1] wave tiles walked, [2] .. [4] VAL margins
@@ -708,7 +709,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             rf.Gs = c->refine_off ? nullptr : c->dG;
             rf.TB = c->dTB + c->tb_step_elems;
             rf.below = c->refine_below;
-            rf.count = c->dRefined + c->stat_parity;
+            rf.count = c->refine_nocount ? nullptr : c->dRefined + c->stat_parity;
             rf.A2 = nullptr;
             unsigned long long* stats = c->coarse_stats ? c->dMargin : nullptr;     // lab: exact tile evaluations, summed over launches
 #define BAZ_COARSE_ARGS dim3(CG.groups * CG.nsplit), dim3(256), 0, c->stream, dQ, c->dCS, c->dCS + (size_t)(c->cs_tiles + 1) * cs_c_units(M), \
@@ -743,7 +744,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             rf.Gs = c->refine_off ? nullptr : c->dG;
             rf.TB = c->dTB + c->tb_step_elems;
             rf.below = c->refine_below;
-            rf.count = c->dRefined + c->stat_parity;
+            rf.count = c->refine_nocount ? nullptr : c->dRefined + c->stat_parity;
             rf.A2 = nullptr;
             // its own bin ranges: whole rounds of the resident workgroup slots (i8_nsplit)
             int& per_cu = c->i8_wgs_per_cu[NMAX > 2 ? 1 : 0][spec ? 1 : 0][vec4 ? 1 : 0];
@@ -814,7 +815,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
     rf.Gs = c->refine_off ? nullptr : c->dG;
     rf.TB = c->dTB + c->tb_step_elems;
     rf.below = c->refine_below;
-    rf.count = c->dRefined + c->stat_parity;
+    rf.count = c->refine_nocount ? nullptr : c->dRefined + c->stat_parity;
     rf.A2 = c->dA2p ? c->dA2p + 64 : nullptr;
     const double2* fb0 = c->dFB + c->fb_step_elems;   // step 0 (a padded step lies in front)
     if constexpr (M >= 6 && NMAX == 2) {
@@ -1606,6 +1607,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         }
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_NO_ROWCLASS")) { if (atoi(v)) c->nclass = 1; }   // lab: round-1 row order
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_NO_REFINE")) c->refine_off = atoi(v);              // lab
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_NO_REFINE_COUNT")) c->refine_nocount = atoi(v);    // lab: no statistic atomics
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COV_OLD")) c->lab_cov_old = atoi(v);               // lab
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SUB_EVD")) c->sub_evd = atoi(v);                   // lab / tests
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_NSPLIT")) c->force_nsplit = std::max(0, atoi(v));  // tests / lab

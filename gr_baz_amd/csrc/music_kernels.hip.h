@@ -1394,8 +1394,70 @@ __device__ __forceinline__ uint32_t literal_tile(v4f64 (&acc)[4], const ScanRefi
     constexpr int KS2 = (2 * M + 3) / 4;      // k-steps over the 2m real coordinates (re a_0, im a_0, re a_1, ...)
     const double* __restrict__ tb1 = reinterpret_cast<const double*>(tbl + (size_t)st * KS2 * 2 * 64);
     uint32_t cnt = 0;
-    // One bin tile at a time (the scheduling barriers keep the four chains apart): this rare path must not raise the
-    // register count -- hence the occupancy -- of the ordinary steps around it.
+    if constexpr (KS2 <= 2) {
+        // Up to 4 antennas (round 4).  With every item of a wave in another scene and 60 dB of SNR a third of the steps of a
+        // config-2 scan come here (the nulls of 16 unrelated items are spread over its 57 steps), and the form below -- every
+        // operand fetched from L2 in front of the MFMA that uses it, behind a branch (the select on 4 s + g < 2 m made hipcc
+        // branch around each load and wait for it), 16 dependent round trips per step, the first of them behind the previous
+        // step's spectrum stores (vmcnt retires in issue order) -- cost 11 us per visit.  The item's coefficients do not depend
+        // on the bin tile and the table's do not depend on the eigenvector: 2 nn KS2 UNCONDITIONAL loads (clamped index, the
+        // select afterwards) in one batch + KS2 per bin tile that holds a near-null value; the same MFMAs on the same operands
+        // in the same order: the same bits.
+        constexpr int KMAX = M - 1;
+        double x0[KMAX][KS2], x1[KMAX][KS2];
+        const double sgn1 = (g & 1) ? 1.0 : -1.0;         // Im c: -gi*ar (g even: comp = im) + gr*ai (g odd: comp = re)
+        // (the addresses are formed HERE: hoisted out of the scan's step loop they would be 2 nn KS2 register pairs the ordinary
+        // steps cannot spare -- spilled, and fetched back one by one with a wait each)
+        uint32_t itq = itc, gq = (uint32_t)g;
+        asm volatile("" : "+v"(itq), "+v"(gq));
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int kk = k < nn ? k : 0;                // (a valid address also for the eigenvectors that do not exist)
+#pragma unroll
+            for (int s = 0; s < KS2; ++s) {
+                const bool in = 4 * s + (int)gq < 2 * M;
+                const uint32_t ant = in ? 2u * (uint32_t)s + (gq >> 1) : 0u;
+                const double v0 = rf.Gs[(size_t)(((uint32_t)kk * M + ant) * 2u + (gq & 1u)) * qstride + itq];
+                const double v1 = rf.Gs[(size_t)(((uint32_t)kk * M + ant) * 2u + ((gq & 1u) ^ 1u)) * qstride + itq];
+                x0[k][s] = in ? v0 : 0.0;
+                x1[k][s] = in ? sgn1 * v1 : 0.0;
+            }
+        }
+        // only the bin tiles that hold such a value (a null is a few adjacent bins: with bins 4 c + t in tile t, often not all four)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bool want = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) want |= (fabs(acc[t][r]) <= rf.below) && (bin + t < res);
+            if (!__any(want)) continue;                   // wave-uniform
+            double tbv[KS2];
+#pragma unroll
+            for (int s = 0; s < KS2; ++s) tbv[s] = tb1[(size_t)(t >> 1) * 128 + (t & 1) + (size_t)s * 256];
+            v4f64 d = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                if (k < nn) {                              // wave-uniform
+                    v4f64 p = {0, 0, 0, 0};
+#pragma unroll
+                    for (int s = 0; s < KS2; ++s) p = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[k][s], tbv[s], p, 0, 0, 0);
+                    d += p * p;
+                    p = (v4f64){0, 0, 0, 0};
+#pragma unroll
+                    for (int s = 0; s < KS2; ++s) p = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[k][s], tbv[s], p, 0, 0, 0);
+                    d += p * p;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool redo = (fabs(acc[t][r]) <= rf.below) && (bin + t < res);
+                acc[t][r] = redo ? d[r] : acc[t][r];
+                cnt += (redo && row_ok[r]) ? 1u : 0u;
+            }
+        }
+        return cnt;
+    }
+    // 5 antennas and more: one bin tile at a time (the scheduling barriers keep the four chains apart): this rare path must
+    // not raise the register count -- hence the occupancy -- of the ordinary steps around it.
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         v4f64 d = {0, 0, 0, 0};
@@ -1537,6 +1599,7 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
         gate_d[r] = __builtin_bit_cast(double, (uint64_t)BAZ_KEY_EMPTY_BITS | 0xFFFFFull);
     }
     const bool refine_on = rf.Gs != nullptr;                         // wave-uniform
+    uint32_t refined_wave = 0;                                       // (wave-uniform: values this wave recomputed in literal form)
     [[maybe_unused]] const float below_f = refine_on ? (float)rf.below : -1.0f;
     [[maybe_unused]] const double below_d = refine_on ? rf.below : -1.0;
 
@@ -1717,10 +1780,13 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
 #pragma unroll
                                     for (int t = 0; t < 4; ++t) sv[r][t] = strength_f32(fabs(acc[t][r]));
                             }
-                            if (rf.count) {         // statistic (baz_music_refined_items): values recomputed
+                            if (rf.count) {         // statistic (baz_music_refined_items): values recomputed, summed in a
+                                                    // scalar register; ONE atomic per wave at the end (round 4: an atomic per
+                                                    // refined step -- 290,000 per launch of an incoherent 60-dB batch, all on
+                                                    // one address -- cost 0.46 of that scan's 2.24 ms)
 #pragma unroll
                                 for (int msk = 1; msk < 64; msk <<= 1) cnt += __shfl_xor(cnt, msk, 64);
-                                if (lane == 0 && cnt) atomicAdd(rf.count, (unsigned long long)cnt);
+                                refined_wave += (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
                             }
                         }
                         const uint32_t nobin = ~keep_mask;          // bin field of a key that must never be selected
@@ -1787,6 +1853,7 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
         }
     }
 
+    if (rf.count && lane == 0 && refined_wave) atomicAdd(rf.count, (unsigned long long)refined_wave);
     // merge the 16 lanes c = 0..15 that share an item row, then emit this range's candidates.
     // (Letting the wave that has walked a row's WHOLE bin range write ang / lvl itself -- lvl read back from its own
     // spectrum stores after s_waitcnt vmcnt(0) -- saves the merge launch and loses more than it saves: scan 0.721 ->
