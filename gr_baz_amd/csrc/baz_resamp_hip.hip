@@ -19,6 +19,7 @@ typedef unsigned __int128 u128;
 typedef __int128 i128;
 
 struct baz_resamp_ctx {
+    bool stopped_at_bad = false;   // the last two-input call ended on an unusable ratio sample
     uint32_t nstreams = 0;
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -199,9 +200,12 @@ int64_t process2_device_locked(baz_resamp_ctx* c, const void* d_in, uint64_t in_
     WalkResult w;
     RS_TRY(hipMemcpyAsync(&w, c->d_walk, sizeof(w), hipMemcpyDeviceToHost, c->stream));
     RS_TRY(hipStreamSynchronize(c->stream));
-    // the window STARTS on an unusable ratio sample: the previous call stopped here and nothing was consumed since.  The
-    // one output this call could emit is the one already delivered; report it instead of looping
-    if (w.status == 1 && w.ii == 0 && w.n <= 1) return BAZ_RESAMP_E_INVALID;
+    // The window STARTS on an unusable ratio sample and the PREVIOUS call already stopped on it (nothing was consumed since):
+    // the one output this call could emit is the one already delivered; report it instead of looping.  A first
+    // call -- or a control stream that begins with such a sample -- still delivers its output.
+    const bool at_bad_start = (w.status == 1 && w.ii == 0 && w.n <= 1);
+    if (at_bad_start && c->stopped_at_bad) return BAZ_RESAMP_E_INVALID;
+    c->stopped_at_bad = (w.status == 1);
     c->mu = (u128)w.frac;
     if (w.last_bits) {                                              // d_mu_inc = the last ratio sample read (.cc:207,215)
         float r;

@@ -104,21 +104,34 @@ __device__ __noinline__ v4f64 literal16(const double* __restrict__ Gs, const dou
     constexpr int KS2 = (2 * M + 3) / 4;
     const uint32_t st = bin >> 6, w = bin & 63u, c4 = w >> 2, t = w & 3u;
     const double* __restrict__ tb = reinterpret_cast<const double*>(TB + ((size_t)st * KS2 * 2 + (t >> 1)) * 64 + (g * 16 + c4)) + (t & 1u);
+    // Operands in batches (round 4): the table's KS2 values once, the eigenvector's 2 KS2 coefficients per k with UNCONDITIONAL
+    // loads (clamped index, the select afterwards).  The form before -- `cond ? sgn * ga[..] : 0` in front of every MFMA -- made
+    // hipcc branch around each load and wait for it: 4 nn KS2 dependent L2 round trips per tile, which an incoherent 60-dB batch
+    // pays in a third of its steps.  Same MFMAs, same operands, same order: the same bits.
+    double tbv[KS2];
+#pragma unroll
+    for (int s = 0; s < KS2; ++s) tbv[s] = tb[(size_t)s * 256];
+    const double sgn1 = (g & 1) ? 1.0 : -1.0;             // Im c: -gi*ar (g even) / +gr*ai (g odd)
     v4f64 d = {0, 0, 0, 0};
     for (int k = 0; k < nn; ++k) {
+        double x0[KS2], x1[KS2];
 #pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            v4f64 p = {0, 0, 0, 0};
-            const int comp = part ? ((g & 1) ^ 1) : (g & 1);
-            const double sgn = (part && !(g & 1)) ? -1.0 : 1.0;
-            const double* __restrict__ ga = Gs + (size_t)((k * M + (g >> 1)) * 2 + comp) * qstride + itc;
-#pragma unroll
-            for (int s = 0; s < KS2; ++s) {
-                const double a = (4 * s + g < 2 * M) ? sgn * ga[(size_t)s * 4 * qstride] : 0.0;
-                p = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tb[(size_t)s * 256], p, 0, 0, 0);
-            }
-            d += p * p;
+        for (int s = 0; s < KS2; ++s) {
+            const bool in = 4 * s + g < 2 * M;
+            const int ant = in ? 2 * s + (g >> 1) : 0;
+            const double v0 = Gs[(size_t)((k * M + ant) * 2 + (g & 1)) * qstride + itc];
+            const double v1 = Gs[(size_t)((k * M + ant) * 2 + ((g & 1) ^ 1)) * qstride + itc];
+            x0[s] = in ? v0 : 0.0;
+            x1[s] = in ? sgn1 * v1 : 0.0;
         }
+        v4f64 p = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) p = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[s], tbv[s], p, 0, 0, 0);
+        d += p * p;
+        p = (v4f64){0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) p = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[s], tbv[s], p, 0, 0, 0);
+        d += p * p;
     }
     return d;
 }

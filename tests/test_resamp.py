@@ -322,6 +322,15 @@ def test_hip_two_input_branch_stops_at_the_end_of_the_input_and_at_unusable_rati
         # error, not a one-output / zero-consumed loop
         with pytest.raises(resamp.ResampError):
             blk.work(x[30:], 500, rr=bad[30:])
+    # a control stream that BEGINS with an unusable sample: the first call delivers what the reference would (its one output,
+    # nothing consumed); only the call after it -- same window, nothing consumed -- is the loop that must be an error
+    first_bad = ratio.copy()
+    first_bad[0] = np.nan
+    with resamp.Resampler(0.0, 1.0) as blk:
+        out, k = blk.work(x, 500, rr=first_bad)
+        assert out.shape[0] <= 1 and k == 0
+        with pytest.raises(resamp.ResampError):
+            blk.work(x, 500, rr=first_bad)
     tiny = np.full(4000, 2.0 ** -20, np.float32)              # valid tiny ratios (< 2^-11) keep running, like the reference
     with resamp.Resampler(0.0, 1.0) as blk:
         out, k = blk.work(x, 300, rr=tiny)
