@@ -55,7 +55,7 @@ STREAMS_PER_GPU, ITEMS_PER_STREAM = 8, 32768
 STRONG_STREAMS = 64        # BASELINE configs[3]: 64 independent 4-antenna streams, the same ones at every GPU count
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_MFMA_PEAK_TF = 78.6   # AMD datasheet; ubench: v_mfma_f64_16x16x4_f64 = 65 cycles/SIMD -> 77 TF (profiles/r01_ubench_fp64_rates.txt)
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03_scan_pmc_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r04_scan_pmc_traffic.json")
 
 
 def kernel_sources_sha():
@@ -530,7 +530,7 @@ def main():
                        "stage_ms_per_launch_separate_pass": {nm: stage[s][0] / max(stage[s][1], 1)
                                                for s, nm in enumerate(("cov (+ evd when fused)", "evd_proj", "scan_mfma", "topn_merge"))},
                        # the one dense contraction (north_star): useful fp64 flops 8*m*N per item against the fp64
-                       # matrix peak; rocprofv3 MFMA-busy for the same kernel is in profiles/r03_bench_pmc_summary.txt
+                       # matrix peak; rocprofv3 MFMA-busy for the same kernel is in profiles/r04_bench_pmc_summary.txt
                        "covariance_mfma": cov_mfma},
             "roofline": {"bound": "hbm", "kernel": "scan_mfma_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
