@@ -159,7 +159,11 @@ def _table_f32(table, res, m):
 class Context:
     """One baz_music_ctx: the device-side state of one baz_music_doa block instance."""
 
-    def __init__(self, m, n, nsamples, resolution, table, device_id=-1, lab=False):
+    def __init__(self, m, n, nsamples, resolution, table, device_id=-1, lab=None):
+        # lab=None: the lab form of the library where BAZ_MUSIC_LAB_LIB is set (lab / quick: tests/lab harnesses whose switches
+        # the release form does not read), else the release form
+        if lab is None:
+            lab = bool(os.environ.get("BAZ_MUSIC_LAB_LIB"))
         L = self._L = lib(lab)
         self.m, self.n, self.nsamples, self.res = int(m), int(n), int(nsamples), int(resolution)
         t = _table_f32(table, self.res, self.m) if (self.res > 0 and self.m > 0) else \

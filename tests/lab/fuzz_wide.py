@@ -23,7 +23,7 @@ def run(m, n, N, res, table, items, mfma):
     os.environ["BAZ_MUSIC_WIDE_MFMA"] = mfma
     os.environ["BAZ_MUSIC_WIDE_COV_MFMA"] = mfma
     batch = len(items)
-    with capi.Context(m, n, N, res, table) as ctx:
+    with capi.Context(m, n, N, res, table, lab=True) as ctx:          # (the lab form of the library: the release form does not read the switches)
         x = torch.from_numpy(items.view(np.float32)).to(dev)
         ang = torch.full((batch, n), -1.0, dtype=torch.float32, device=dev); lvl = torch.full_like(ang, -1.0)
         spec = torch.full((batch, res), -1.0, dtype=torch.float32, device=dev)
