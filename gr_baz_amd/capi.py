@@ -33,6 +33,7 @@ SYMBOLS = [
     "baz_music_refined_values", "baz_music_debug_coarse_margin", "baz_music_debug_coarse_fired",
     "baz_music_host_register", "baz_music_set_host_pinning", "baz_music_host_unregister_all", "baz_music_host_pinned_bytes",
     "baz_music_debug_i8_margin", "baz_music_debug_i8_stats", "baz_music_uses_i8_scan", "baz_music_debug_i8_image",
+    "baz_music_debug_i8_nsplit",
 ]
 
 _vp = ctypes.c_void_p
@@ -143,6 +144,8 @@ def _bind(L):
     L.baz_music_debug_i8_stats.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     L.baz_music_uses_i8_scan.restype = ctypes.c_int
     L.baz_music_uses_i8_scan.argtypes = [_vp]
+    L.baz_music_debug_i8_nsplit.restype = _u32
+    L.baz_music_debug_i8_nsplit.argtypes = [_u32, _u32, _u32]
     L.baz_music_debug_i8_image.restype = ctypes.c_size_t
     L.baz_music_debug_i8_image.argtypes = [_u32, _u32, _f32p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t,
                                            ctypes.POINTER(ctypes.c_double)]

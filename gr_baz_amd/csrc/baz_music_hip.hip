@@ -2196,6 +2196,13 @@ extern "C" __attribute__((visibility("default"))) int baz_music_debug_i8_times(b
 // BAZ_MUSIC_EXACT=1), else 0.
 int baz_music_uses_i8_scan(const baz_music_ctx* c) { return (c && !c->wide && i8_active(c)) ? 1 : 0; }
 
+// HOST-ONLY tap (no device needed): the bin ranges per item i8_nsplit() chooses for a launch of `batch` items over `nsteps`
+// 64-bin steps on a device with `slots` resident workgroups (CUs x workgroups per CU).
+uint32_t baz_music_debug_i8_nsplit(uint32_t batch, uint32_t nsteps, uint32_t slots)
+{
+    return i8_nsplit(batch, nsteps, std::max<uint32_t>(1u, slots), 0);
+}
+
 // HOST-ONLY tap (no device needed): the digit images and parameters build_i8_image() produces for a table.  Returns the
 // images' size in bytes (also when `out` is NULL or too small: nothing is written then), 0 when the table has no image.
 // params[0 .. 6] = level weights, [7] = 2^54, [8] = T, [9] = E5, [10] = allowance of the refined form, [11] = 5, [12] = 7,

@@ -165,6 +165,8 @@ BAZ_MUSIC_API int baz_music_debug_i8_stats(baz_music_ctx* ctx, uint64_t* refined
 BAZ_MUSIC_API int baz_music_uses_i8_scan(const baz_music_ctx* ctx);
 BAZ_MUSIC_API size_t baz_music_debug_i8_image(uint32_t m, uint32_t resolution, const float* table_ri, uint8_t* out,
                                               size_t out_bytes, double* params);
+/*   (host only) the bin ranges per item the int8 scan launches with: whole rounds of the `slots` resident workgroups. */
+BAZ_MUSIC_API uint32_t baz_music_debug_i8_nsplit(uint32_t batch, uint32_t nsteps, uint32_t slots);
 BAZ_MUSIC_API uint32_t baz_music_q_stride(uint32_t batch);
 
 /* Algorithmic HBM bytes per item: 8*nsamples + 8*n + 4*resolution (the last

@@ -168,6 +168,25 @@ def test_integer_forms_from_the_images_stay_inside_their_bounds(m, scale):
     assert (err7 <= allow7).all(), float((err7 / allow7).max())
 
 
+def test_bin_ranges_fill_the_resident_workgroup_slots_in_whole_rounds():
+    """i8_nsplit: the launch's workgroups (64 items x one bin range) should be a whole number of rounds of the device's resident
+    slots -- config 3's 16,384 items on 768 slots (256 CUs x 3) took 8 ranges = 2,048 workgroups = 2.67 rounds in the second
+    form, 3 ranges = one round now -- with at most 16 ranges, none shorter than 4 steps, and the fewest rounds among fillings
+    within 3 % of the best."""
+    ns = _capi().lib().baz_music_debug_i8_nsplit
+    assert ns(16384, 563, 768) == 3                      # config 3: 256 groups x 3 = 768 = one round
+    assert ns(16384, 57, 512) == 2                       # config 5's MUSIC stage (2 workgroups per CU): 512 = one round
+    assert ns(65536, 57, 768) == 3                       # 1,024 groups: 3,072 workgroups = four rounds exactly
+    assert ns(64, 563, 768) == 16                        # one group: as many ranges as allowed
+    assert ns(64, 8, 768) == 2 and ns(64, 3, 768) == 1   # ... but none shorter than 4 steps
+    assert ns(1 << 20, 563, 768) == 1                    # more groups than slots in every case: one range
+    for batch in (1, 63, 64, 65, 1000, 4096, 16384, 100000):
+        for nsteps in (1, 4, 57, 563):
+            for slots in (256, 512, 768, 1024):
+                k = ns(batch, nsteps, slots)
+                assert 1 <= k <= 16 and (k == 1 or k <= nsteps // 4)
+
+
 def test_tables_without_an_image():
     z = np.zeros((90, 8), np.complex64)
     assert _capi().debug_i8_image(8, 90, z)[0] is None                          # all zero: no scale
