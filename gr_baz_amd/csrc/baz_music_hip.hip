@@ -784,6 +784,11 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
                         case 40: BAZ_I8_ABL(40); break;    // stores alone
                         case 64: BAZ_I8_ABL(64); break;    // plain stores
                         case 1024: BAZ_I8_ABL(1024); break; // staggered workgroup starts
+                        case 16384: BAZ_I8_ABL(16384); break; // stores nt only
+                        case 32768: BAZ_I8_ABL(32768); break; // stores sc0 nt
+                        case 65536: BAZ_I8_ABL(65536); break; // stores sc1 only
+                        case 16424: BAZ_I8_ABL(16424); break; // stores alone, nt only
+                        case 65576: BAZ_I8_ABL(65576); break; // stores alone, sc1 only
                         case 8192: BAZ_I8_ABL(8192); break; // s_memtime around wait / stores / barrier (baz_music_debug_i8_times)
                         case 8193: BAZ_I8_ABL(8193); break;
                         case 2048: BAZ_I8_ABL(2048); break; // rows 256-B aligned (row stride rounded down to 64 bins)

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (!stail) {                       // wave-uniform: whole step inside the row
-                        if (row_ok[r]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, (ABL & 64) ? 0 : (1 | 2 | 16));
+                        if (row_ok[r]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, (ABL & 64) ? 0 : ((ABL & 16384) ? 16 : ((ABL & 32768) ? (1 | 16) : ((ABL & 65536) ? 2 : (1 | 2 | 16)))));
                     } else {
                         if (row_ok[r] && sbin < res) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, (1 | 2 | 16));
                     }
@@ -575,6 +575,7 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
             if constexpr (!(ABL & 8)) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");           // (the next phase's ds_reads stay behind the barrier for the compiler too)
             }
             if constexpr ((ABL & 8192) != 0) {
                 tm3 = __builtin_readcyclecounter();
