@@ -274,12 +274,13 @@ __global__ __launch_bounds__(256, (RG <= 2 && M <= 4) ? 3 : 2) void scan_coarse_
     [[maybe_unused]] uint32_t fired = 0;          // exact (row group, tile) evaluations of this wave (lab statistic)
 
     // ---- table staging: L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no registers) ----------
-    auto stage_load = [&](uint32_t ph, int b, const bool with_x) {
+    auto stage_load = [&](uint32_t ph, int b, const bool with_x, const int tile_stride = 1) {
         const uint4* __restrict__ sc = imgC + (size_t)ph * (TPP * TC_UNITS) + lane;        // (the C array carries one tile of padding)
+        constexpr int CPT = TC_UNITS / 64;                     // 1-KiB chunks per tile
 #pragma unroll
         for (int i = 0; i < (C_CHUNKS + 3) / 4; ++i) {
             const int j = i * 4 + wave;                        // wave-uniform: chunk j of the phase
-            if (j < C_CHUNKS)
+            if (j < C_CHUNKS && ((j / CPT) % tile_stride) == 0)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sc + j * 64),
                                                  (__attribute__((address_space(3))) void*)(&stage[b][j * 64]), 16, 0, 0);
         }
@@ -366,28 +367,35 @@ __global__ __launch_bounds__(256, (RG <= 2 && M <= 4) ? 3 : 2) void scan_coarse_
                     asm volatile("" : "+v"(pm[q][r]));
                 }
         };
-        if (ph_begin < ph_end) stage_load(ph_begin, 0, false);
+        // EVERY OTHER bin tile only (round 4): the n-th smallest of the minima over a SUBSET of a row's bins is still an upper
+        // bound of its n-th smallest d, and 16 bins further on the spectrum has barely moved -- half of this pass's MFMAs,
+        // reductions and staged operands, the same share of exact tiles in pass 2 (config 2, 262,144 items: scan 0.220 -> 0.197 ms
+        // on coherent streams, 0.488 -> 0.475 on an incoherent batch; every fourth tile: 0.186 / 0.494 with 26 instead of 23 % of
+        // the tiles exact there; profiles/r04_coarse_pass1_stride.txt).
+        constexpr int PS = (LAB == 3) ? 1 : ((LAB == 4 && TPP >= 8) ? 4 : 2);     // (lab 3 / 4: every tile / every fourth tile)
+        static_assert(TPP % (2 * PS) == 0, "pass 1 walks its tiles of a phase in pairs");
+        if (ph_begin < ph_end) stage_load(ph_begin, 0, false, PS);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         BOp bA, bB;
         v4f32 uA[RG], uB[RG];
         for (uint32_t ph = ph_begin; ph < ph_end; ++ph) {
-            if (ph + 1 < ph_end) stage_load(ph + 1, buf ^ 1, false);
+            if (ph + 1 < ph_end) stage_load(ph + 1, buf ^ 1, false, PS);
             const char* __restrict__ T0 = reinterpret_cast<const char*>(&stage[buf][0]) + (((WIDE ? g : (g & 1)) * 16 + c) * 16);
             if (ph == ph_begin) {                                              // prologue of the pass: tile 0
                 ld_b(T0, 0, bA);
                 issue(uA, bA, T0, 0, false);
             }
-            ld_b(T0, 1, bB);
+            ld_b(T0, PS, bB);
 #pragma nounroll
-            for (int tl = 0; tl < TPP; tl += 2) {
-                issue(uB, bB, T0, tl + 1, false);                              // tile tl + 1 ...
-                ld_b(T0, tl + 2, bA);
+            for (int tl = 0; tl < TPP; tl += 2 * PS) {
+                issue(uB, bB, T0, tl + PS, false);                             // tile tl + PS ...
+                ld_b(T0, tl + 2 * PS, bA);
                 reduce1(uA);                                                   // ... while tile tl is reduced
                 interleave();
-                issue(uA, bA, T0, tl + 2, false);                              // tile tl + 2 (= tile 0 of the next phase at the end) ...
-                ld_b(T0, (tl + 3 <= TPP) ? tl + 3 : TPP, bB);
-                reduce1(uB);                                                   // ... while tile tl + 1 is reduced
+                issue(uA, bA, T0, tl + 2 * PS, false);                         // tile tl + 2 PS (= tile 0 of the next phase at the end) ...
+                ld_b(T0, (tl + 3 * PS <= TPP) ? tl + 3 * PS : TPP, bB);
+                reduce1(uB);                                                   // ... while tile tl + PS is reduced
                 interleave();
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
