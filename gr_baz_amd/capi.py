@@ -33,7 +33,7 @@ SYMBOLS = [
     "baz_music_refined_values", "baz_music_debug_coarse_margin", "baz_music_debug_coarse_fired",
     "baz_music_host_register", "baz_music_set_host_pinning", "baz_music_host_unregister_all", "baz_music_host_pinned_bytes",
     "baz_music_debug_i8_margin", "baz_music_debug_i8_stats", "baz_music_uses_i8_scan", "baz_music_debug_i8_image",
-    "baz_music_debug_i8_nsplit",
+    "baz_music_debug_i8_nsplit", "baz_music_last_retune_ms", "baz_music_debug_table_image", "baz_music_debug_host_table_image",
 ]
 
 _vp = ctypes.c_void_p
@@ -139,7 +139,7 @@ def _bind(L):
     L.baz_music_host_pinned_bytes.restype = ctypes.c_uint64
     L.baz_music_host_pinned_bytes.argtypes = [_vp]
     L.baz_music_debug_i8_margin.restype = ctypes.c_int
-    L.baz_music_debug_i8_margin.argtypes = [_vp, _vp, _u32, ctypes.POINTER(ctypes.c_float)]   # float worst[2]
+    L.baz_music_debug_i8_margin.argtypes = [_vp, _vp, _u32, ctypes.POINTER(ctypes.c_float)]   # float worst[3]
     L.baz_music_debug_i8_stats.restype = ctypes.c_int
     L.baz_music_debug_i8_stats.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     L.baz_music_uses_i8_scan.restype = ctypes.c_int
@@ -149,6 +149,12 @@ def _bind(L):
     L.baz_music_debug_i8_image.restype = ctypes.c_size_t
     L.baz_music_debug_i8_image.argtypes = [_u32, _u32, _f32p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t,
                                            ctypes.POINTER(ctypes.c_double)]
+    L.baz_music_last_retune_ms.restype = ctypes.c_int
+    L.baz_music_last_retune_ms.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    L.baz_music_debug_table_image.restype = ctypes.c_size_t
+    L.baz_music_debug_table_image.argtypes = [_vp, ctypes.c_int, _vp, ctypes.c_size_t]
+    L.baz_music_debug_host_table_image.restype = ctypes.c_size_t
+    L.baz_music_debug_host_table_image.argtypes = [_u32, _u32, _u32, _f32p, ctypes.c_int, _vp, ctypes.c_size_t]
     return L
 
 
@@ -200,6 +206,23 @@ class Context:
         t = _table_f32(table, self.res, self.m)
         self._chk(self._L.baz_music_set_table(self._h, t.view(np.float32).ctypes.data_as(_f32p)),
                   "baz_music_set_table")
+
+    def last_retune_ms(self):
+        """(wall milliseconds of the last set_table, milliseconds of it spent waiting for / holding the lock shared with process)."""
+        a, b = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self._chk(self._L.baz_music_last_retune_ms(self._h, ctypes.byref(a), ctypes.byref(b)), "baz_music_last_retune_ms")
+        return float(a.value), float(b.value)
+
+    def debug_table_image(self, which):
+        """Image `which` of the table in force, copied back from the device (uint8 array), or None when the configuration has none."""
+        n = int(self._L.baz_music_debug_table_image(self._h, int(which), None, 0))
+        if n == 0:
+            return None
+        out = np.zeros(n, np.uint8)
+        got = int(self._L.baz_music_debug_table_image(self._h, int(which), _vp(out.ctypes.data), n))
+        if got != n:
+            raise MusicError(E_HIP, "baz_music_debug_table_image")
+        return out
 
     def process(self, items, want_lvl=True, want_spectrum=True, out=None):
         """items: (batch, nsamples) complex64 host array -> (ang, lvl|None, spectrum|None).
@@ -351,6 +374,22 @@ def debug_i8_image(m, resolution, table):
                                    par.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
     return img, {"wt": par[:7].copy(), "sq": par[7], "t_acc": par[8], "e_bound": par[9], "e_refined": par[10],
                  "ns": int(par[11]), "nd": int(par[12]), "e4_bound": par[13], "t4": par[14]}
+
+
+TABLE_IMAGES = {0: "FB", 1: "TB", 2: "coarse", 3: "i8", 4: "a2p", 5: "TA", 6: "a2", 7: "params"}
+
+
+def debug_host_table_image(m, n, resolution, table, which, lab=False):
+    """HOST-ONLY: image `which` of `table` as the round-4 host routines build it (uint8 array), or None.  Needs no device."""
+    t = _table_f32(table, int(resolution), int(m))
+    tp = t.view(np.float32).ctypes.data_as(_f32p)
+    L = lib(lab)
+    nb = int(L.baz_music_debug_host_table_image(int(m), int(n), int(resolution), tp, int(which), None, 0))
+    if nb == 0:
+        return None
+    out = np.zeros(nb, np.uint8)
+    L.baz_music_debug_host_table_image(int(m), int(n), int(resolution), tp, int(which), _vp(out.ctypes.data), nb)
+    return out
 
 
 def q_stride(batch):

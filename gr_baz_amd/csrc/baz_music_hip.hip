@@ -9,8 +9,10 @@
 #include "music_wide_kernels.hip.h"
 #include "scan_coarse_kernels.hip.h"
 #include "scan_i8_kernels.hip.h"
+#include "table_kernels.hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -81,7 +83,27 @@ struct baz_music_ctx {
     bool s_has_spec = false;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;   // baz_music_process_device_on: ordering against the caller's stream
-    std::mutex mtx;   // serialises set_table against process*, like d_mutex (.cc:67,101)
+    std::mutex mtx;   // serialises process* against the table SWAP of set_table, like d_mutex (.cc:67,101)
+    // Retune without stalling the stream (round 5): baz_music_set_table builds every image of the new table with the kernels
+    // of table_kernels.hip.h on `s_tab` into the SHADOW set and takes `mtx` only to exchange the two sets (TableSet below)
+    struct TableSet {
+        double2* dFB = nullptr; double2* dTB = nullptr; uint4* dCS = nullptr; uint4* dIB = nullptr; double* dA2p = nullptr;
+        float2* dTA = nullptr; double* dA2 = nullptr;
+        CoarseParams cs = {0.0f, 0.0f, 0.0, 0.0, 1};
+        I8Params i8 = {};
+        bool cs_ok = false, i8_ok = false;
+        double refine_below = 0.0;
+    } shadow;
+    std::mutex tab_mtx;              // retunes among themselves (held for a whole baz_music_set_table; never while `mtx` is wanted by work())
+    hipStream_t s_tab = nullptr;     // side stream of the table builders (highest priority: they are tiny)
+    hipEvent_t ev_swap = nullptr;    // recorded on the launch stream at every swap: batches that still read the retired set
+    bool swap_recorded = false;
+    float* dRaw = nullptr;           // the raw fp32 table on the device (resolution x m complex64)
+    float* hRaw = nullptr;           // its page-locked staging copy (the caller's vector may be pageable and short-lived)
+    void* dTabStats = nullptr;       // baztab::TableStats
+    void* hTabStats = nullptr;       // ... page-locked
+    double last_retune_ms = 0.0;     // wall time of the last baz_music_set_table, of which ...
+    double last_swap_wait_ms = 0.0;  // ... waiting for and holding `mtx`
     int profiling = 0;      // 0 off, 1 every stage, 2 only the dominant (scan) stage
     int lab_variant = 0;
     // literal-form refinement of near-null tiles (literal_tile() inside the scan)
@@ -256,37 +278,8 @@ void build_TB(const float* table_ri, uint32_t m, uint32_t res, uint32_t steps, s
 
 uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 
-// float -> IEEE binary16, round to nearest even (values here are finite and below 65504)
-uint16_t f16_bits(float f)
-{
-    uint32_t x;
-    std::memcpy(&x, &f, 4);
-    const uint32_t sign = (x >> 16) & 0x8000u;
-    const int32_t ex = (int32_t)((x >> 23) & 0xFF) - 127 + 15;
-    uint32_t man = x & 0x7FFFFFu;
-    if (((x >> 23) & 0xFF) == 0xFF) return (uint16_t)(sign | 0x7C00u | (man ? 0x200u : 0u));
-    if (ex >= 31) return (uint16_t)(sign | 0x7C00u);
-    if (ex <= 0) {                      // subnormal or zero
-        if (ex < -10) return (uint16_t)sign;
-        man |= 0x800000u;
-        const int shift = 14 - ex;      // 24-bit significand -> 10-bit field of a subnormal
-        uint32_t h = man >> shift;
-        const uint32_t rem = man & ((1u << shift) - 1u), half = 1u << (shift - 1);
-        if (rem > half || (rem == half && (h & 1u))) ++h;
-        return (uint16_t)(sign | h);
-    }
-    uint32_t h = ((uint32_t)ex << 10) | (man >> 13);
-    const uint32_t rem = man & 0x1FFFu;
-    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;   // may carry into the exponent: still right
-    return (uint16_t)(sign | h);
-}
-float f16_value(uint16_t h)
-{
-    const int ex = (h >> 10) & 0x1F;
-    const float man = (float)(h & 0x3FF);
-    float v = ex ? std::ldexp(1.0f + man / 1024.0f, ex - 15) : std::ldexp(man, -24);
-    return (h & 0x8000u) ? -v : v;
-}
+using baztab::f16_bits;
+using baztab::f16_value;
 
 // Table images of the coarse-gated scan (scan_coarse_kernel): the C array (1,024 B per 16-bin tile) followed by the X
 // array (2,048 B per tile):
@@ -295,6 +288,25 @@ float f16_value(uint16_t h)
 //   X    k-step pair p, lane (g, c), component s & 1: F[bin][e = 4 s + g], s = 2 p + (s & 1)   (fp64 B operand)
 // Fs = F * FS, Fh = f16(Fs), Fl = f16(Fs - Fh); bins outside the table: a huge diagonal (never selected), like build_FB.
 // Returns false when the table's scale cannot be represented (the full scan is used then).
+// The coarse form's scales and thresholds from max|F| (shared by the device builders and the host checker); false when the
+// table's scale cannot be represented.
+bool coarse_params_from(double fmax, uint32_t m, CoarseParams& cp, double& FS)
+{
+    if (!(fmax > 0.0) || !std::isfinite(fmax)) return false;
+    int ex = 0;
+    (void)std::frexp(fmax, &ex);                    // fmax = f * 2^ex, f in [0.5, 1)
+    const int fs_exp = 14 - ex;                     // fmax * 2^fs_exp in [2^13, 2^14)
+    if (fs_exp < -90 || fs_exp > 90) return false;  // SC must stay a comfortable float
+    FS = std::ldexp(1.0, fs_exp);
+    const double SC = 1024.0 * FS;
+    cp.sc = SC;
+    cp.fmax = fmax;
+    const double nga = (double)cs_ng((int)m);             // the allowance E = nga 2^-16 (S + D)
+    cp.sc_up = std::nextafter((float)(SC * (1.0 + nga * 0x1p-16) * (1.0 + 0x1p-20)), INFINITY);
+    cp.es_factor = std::nextafter((float)(nga * 0x1p-16 * fmax * SC), INFINITY);
+    return true;
+}
+
 bool build_coarse_image(const std::vector<double>& F, uint32_t m, uint32_t res, uint32_t tiles, std::vector<uint8_t>& img,
                         CoarseParams& cp)
 {
@@ -304,18 +316,9 @@ bool build_coarse_image(const std::vector<double>& F, uint32_t m, uint32_t res, 
         if (!std::isfinite(v)) return false;
         fmax = std::max(fmax, std::fabs(v));
     }
-    if (!(fmax > 0.0)) return false;
-    int ex = 0;
-    (void)std::frexp(fmax, &ex);                    // fmax = f * 2^ex, f in [0.5, 1)
-    const int fs_exp = 14 - ex;                     // fmax * 2^fs_exp in [2^13, 2^14)
-    if (fs_exp < -90 || fs_exp > 90) return false;  // SC must stay a comfortable float
-    const double FS = std::ldexp(1.0, fs_exp), SC = 1024.0 * FS;
-    cp.sc = SC;
-    cp.fmax = fmax;
+    double FS = 0.0;
+    if (!coarse_params_from(fmax, m, cp, FS)) return false;
     const uint32_t ng = (uint32_t)cs_groups((int)m);      // groups of 16 terms (fp64 operand)
-    const double nga = (double)cs_ng((int)m);             // the allowance E = nga 2^-16 (S + D)
-    cp.sc_up = std::nextafter((float)(SC * (1.0 + nga * 0x1p-16) * (1.0 + 0x1p-20)), INFINITY);
-    cp.es_factor = std::nextafter((float)(nga * 0x1p-16 * fmax * SC), INFINITY);
     const bool wide = m > 4;                              // coarse operands in groups of 32 terms, Fh and Fl 1 KiB each
     const size_t cbytes = (size_t)cs_c_units((int)m) * 16, xbytes = (size_t)ng * CS_X_UNITS * 16;
     // [C of every tile and of one more (the kernel stages the first tile of the NEXT phase with every phase)][X of every tile]
@@ -368,23 +371,20 @@ constexpr size_t I8_IMAGE_LIMIT = (size_t)384 << 20;
 size_t i8_image_bytes5(uint32_t m, uint32_t steps) { return (size_t)steps * 4 * i8_nkb((int)m) * I8_NS * 1024; }
 size_t i8_image_bytes(uint32_t m, uint32_t steps) { return (size_t)steps * 4 * i8_nkb((int)m) * I8_ND * 1024; }
 
-bool build_i8_image(const std::vector<double>& F, uint32_t m, uint32_t res, uint32_t steps, std::vector<uint8_t>& img,
-                    I8Params& ip)
+// The int8 forms' fixed-point scale, level weights and a-priori bounds from max|F| (shared by the device builders and the host
+// checker); sf = the factor that turns F into its 2^54-scaled integer.  false: scale out of range.
+bool i8_params_from(double fmax, uint32_t m, I8Params& ip, double& sf)
 {
-    const uint32_t mm = m * m, nkb = (uint32_t)i8_nkb((int)m);
+    const uint32_t mm = m * m;
     constexpr int NS = I8_NS, ND = I8_ND;
-    double fmax = 0.0;
-    for (double v : F) {
-        if (!std::isfinite(v)) return false;
-        fmax = std::max(fmax, std::fabs(v));
-    }
-    if (!(fmax > 0.0)) return false;
+    if (!(fmax > 0.0) || !std::isfinite(fmax)) return false;
     int ex = 0;
     (void)std::frexp(fmax / I8_QMAX, &ex);          // fmax / QMAX = f 2^ex, f in [0.5, 1)  ->  fmax / 2^ex < QMAX
     // (float) wt[3] = Fscale 2^-36 must scale the bulk form's integer V in [1, 2^48) without leaving the normal float range
     if (ex < -88 || ex > 100) return false;
     const double fscale = std::ldexp(1.0, ex);
-    const double sq = std::ldexp(1.0, 8 * ND - 2), sf = sq / fscale;
+    const double sq = std::ldexp(1.0, 8 * ND - 2);
+    sf = sq / fscale;
     for (int l = 0; l < ND; ++l) ip.wt[l] = std::ldexp(fscale, -12 - 8 * l);
     ip.sq = sq;
     // digits cut off + levels dropped + the low byte of the level-4 sum (scan_i8_kernels.hip.h, "Error bound")
@@ -401,6 +401,21 @@ bool build_i8_image(const std::vector<double>& F, uint32_t m, uint32_t res, uint
     // (VAL) the refined form against the fp64 form it is compared with: its own digits (7.07 2^-54 MM Fscale) plus the fp64
     // form's accumulation error, <= MM 2^-53 sum_e |q_e F_e| <= MM^2 2^-53 Fscale in the worst case
     ip.e_refined = (double)mm * fscale * std::ldexp(1.0, -54) * (7.07 + 2.0 * (double)mm);
+    return true;
+}
+
+bool build_i8_image(const std::vector<double>& F, uint32_t m, uint32_t res, uint32_t steps, std::vector<uint8_t>& img,
+                    I8Params& ip)
+{
+    const uint32_t mm = m * m, nkb = (uint32_t)i8_nkb((int)m);
+    constexpr int NS = I8_NS, ND = I8_ND;
+    double fmax = 0.0;
+    for (double v : F) {
+        if (!std::isfinite(v)) return false;
+        fmax = std::max(fmax, std::fabs(v));
+    }
+    double sf = 0.0;
+    if (!i8_params_from(fmax, m, ip, sf)) return false;
     img.assign(i8_image_bytes(m, steps), 0);
     uint8_t* img2 = img.data() + i8_image_bytes5(m, steps);
     for (uint32_t bin = 0; bin < res; ++bin) {
@@ -1155,93 +1170,176 @@ int process_wide_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void
     return BAZ_MUSIC_OK;
 }
 
-int upload_table_wide(baz_music_ctx* c, const float* table_ri)
+// ---- the table's device images: allocation, device-side construction, exchange -----------------------------------
+using TableSet = baz_music_ctx::TableSet;
+
+size_t coarse_image_bytes(const baz_music_ctx* c)
 {
-    std::vector<float> ta((size_t)c->m * c->res * 2);
-    for (uint32_t b = 0; b < c->res; ++b)
-        for (uint32_t i = 0; i < c->m; ++i) {
-            ta[2 * ((size_t)i * c->res + b)] = table_ri[2 * ((size_t)b * c->m + i)];
-            ta[2 * ((size_t)i * c->res + b) + 1] = table_ri[2 * ((size_t)b * c->m + i) + 1];
+    return ((size_t)(c->cs_tiles + 1) * cs_c_units((int)c->m) + (size_t)c->cs_tiles * CS_X_UNITS * cs_groups((int)c->m)) * 16;
+}
+bool wants_i8_image(const baz_music_ctx* c)
+{
+    return !c->wide && c->m >= 6 && c->n <= 4 && i8_image_bytes(c->m, c->fb_steps) <= I8_IMAGE_LIMIT;
+}
+
+// one set of buffers for the configuration of `c` (what baz_music_create used to allocate in place)
+int alloc_table_set(baz_music_ctx* c, TableSet& T)
+{
+    const size_t pad_steps = (size_t)c->fb_steps + 2;
+    if (c->wide) {
+        if (hipMalloc((void**)&T.dTA, (size_t)c->m * c->res * sizeof(float2)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+        if (hipMalloc((void**)&T.dA2, (size_t)c->res * sizeof(double)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+        if (c->wide_mfma) {
+            if (hipMalloc((void**)&T.dTB, pad_steps * c->tb_step_elems * sizeof(double2)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+            if (hipMalloc((void**)&T.dA2p, pad_steps * 64 * sizeof(double)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
         }
-    std::vector<double> a2(c->res);
-    double amax2 = 0.0;
-    for (uint32_t b = 0; b < c->res; ++b) {
-        double v = 0.0;
-        for (uint32_t i = 0; i < c->m; ++i) {
-            const double re = table_ri[2 * ((size_t)b * c->m + i)], im = table_ri[2 * ((size_t)b * c->m + i) + 1];
-            v += re * re + im * im;
-        }
-        a2[b] = v;
-        if (v > amax2 && v < 1e300) amax2 = v;
+        return BAZ_MUSIC_OK;
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));   // no batch in flight reads the old table
-    HIP_TRY(c, hipMemcpy(c->dTA, ta.data(), ta.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->dA2, a2.data(), a2.size() * sizeof(double), hipMemcpyHostToDevice));
-    c->refine_below = amax2 * (double)c->m * 1e-8;        // the threshold of the specialised kernels' refinement
-    if (c->wide_mfma) {       // raw-table B-operand image and ||a||^2 per bin, padded like the specialised kernels' (huge outside)
-        std::vector<double> TB;
-        build_TB(table_ri, c->m, c->res, c->fb_steps, TB);
-        HIP_TRY(c, hipMemcpy(c->dTB, TB.data(), TB.size() * sizeof(double), hipMemcpyHostToDevice));
-        std::vector<double> a2p((size_t)(c->fb_steps + 2) * 64, 1e300);
-        for (uint32_t b = 0; b < c->res; ++b) a2p[64 + b] = a2[b];
-        HIP_TRY(c, hipMemcpy(c->dA2p, a2p.data(), a2p.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
+    if (hipMalloc((void**)&T.dFB, pad_steps * c->fb_step_elems * sizeof(double2)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (hipMalloc((void**)&T.dTB, pad_steps * c->tb_step_elems * sizeof(double2)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (c->m <= 8 && hipMalloc((void**)&T.dCS, coarse_image_bytes(c)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (wants_i8_image(c) && hipMalloc((void**)&T.dIB, i8_image_bytes(c->m, c->fb_steps)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (short_form_applies(c->m, c->n) && hipMalloc((void**)&T.dA2p, pad_steps * 64 * sizeof(double)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     return BAZ_MUSIC_OK;
 }
 
-int upload_table(baz_music_ctx* c, const float* table_ri)
+void free_table_set(TableSet& T)
 {
-    if (c->wide) return upload_table_wide(c, table_ri);
-    std::vector<double> F;
-    build_F(table_ri, c->m, c->res, F);
-    std::vector<double> FB;
-    build_FB(F, c->m, c->res, c->fb_steps, FB);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));   // no batch in flight reads the old table
-    HIP_TRY(c, hipMemcpy(c->dFB, FB.data(), FB.size() * sizeof(double), hipMemcpyHostToDevice));
-    std::vector<double> TB;
-    build_TB(table_ri, c->m, c->res, c->fb_steps, TB);
-    HIP_TRY(c, hipMemcpy(c->dTB, TB.data(), TB.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (T.dFB) (void)hipFree(T.dFB);
+    if (T.dTB) (void)hipFree(T.dTB);
+    if (T.dCS) (void)hipFree(T.dCS);
+    if (T.dIB) (void)hipFree(T.dIB);
+    if (T.dA2p) (void)hipFree(T.dA2p);
+    if (T.dTA) (void)hipFree(T.dTA);
+    if (T.dA2) (void)hipFree(T.dA2);
+    T = TableSet();
+}
+
+// the set the kernels are launched with lives in the context's own fields (every launch site reads c->dFB, c->cs, ...)
+TableSet active_table_set(const baz_music_ctx* c)
+{
+    TableSet T;
+    T.dFB = c->dFB; T.dTB = c->dTB; T.dCS = c->dCS; T.dIB = c->dIB; T.dA2p = c->dA2p; T.dTA = c->dTA; T.dA2 = c->dA2;
+    T.cs = c->cs; T.i8 = c->i8; T.cs_ok = c->cs_ok; T.i8_ok = c->i8_ok; T.refine_below = c->refine_below;
+    return T;
+}
+void install_table_set(baz_music_ctx* c, const TableSet& T)
+{
+    c->dFB = T.dFB; c->dTB = T.dTB; c->dCS = T.dCS; c->dIB = T.dIB; c->dA2p = T.dA2p; c->dTA = T.dTA; c->dA2 = T.dA2;
+    c->cs = T.cs; c->i8 = T.i8; c->cs_ok = T.cs_ok; c->i8_ok = T.i8_ok; c->refine_below = T.refine_below;
+}
+
+inline dim3 grid_for(size_t threads) { return dim3((unsigned)((threads + 255) / 256)); }
+
+// Builds every image of the table in c->hRaw into `T` on c->s_tab and WAITS for them (the caller holds c->tab_mtx, not c->mtx):
+// raw table H2D, the three scalars (table_stats_kernel, one small D2H), the parameters on the host, the image kernels.
+int build_tables_device(baz_music_ctx* c, TableSet& T)
+{
+    hipStream_t s = c->s_tab;
+    const uint32_t m = c->m, res = c->res, steps = c->fb_steps;
+    const size_t raw_bytes = (size_t)res * m * 2 * sizeof(float);
+    HIP_TRY(c, hipMemcpyAsync(c->dRaw, c->hRaw, raw_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(c->dTabStats, 0, sizeof(baztab::TableStats), s));
+    hipLaunchKernelGGL(baztab::table_stats_kernel, grid_for(res), dim3(256), 0, s, c->dRaw, m, res, c->wide ? 0 : 1,
+                       static_cast<baztab::TableStats*>(c->dTabStats));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->hTabStats, c->dTabStats, sizeof(baztab::TableStats), hipMemcpyDeviceToHost, s));
+    // (meanwhile: the images that need no scalar)
+    const size_t pad_steps = (size_t)steps + 2;
+    if (T.dFB) {
+        hipLaunchKernelGGL(baztab::build_fb_kernel, grid_for(pad_steps * c->fb_step_elems), dim3(256), 0, s, c->dRaw, m, res, steps, T.dFB);
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (T.dTB) {
+        hipLaunchKernelGGL(baztab::build_tb_kernel, grid_for(pad_steps * c->tb_step_elems), dim3(256), 0, s, c->dRaw, m, res, steps, T.dTB);
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (T.dA2p) {   // ||a||^2 per bin, huge outside the table like FB's diagonal there
+        hipLaunchKernelGGL(baztab::build_a2_kernel, grid_for(pad_steps * 64), dim3(256), 0, s, c->dRaw, m, res, (uint32_t)(pad_steps * 64), 64u, T.dA2p);
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (T.dA2) {
+        hipLaunchKernelGGL(baztab::build_a2_kernel, grid_for(res), dim3(256), 0, s, c->dRaw, m, res, res, 0u, T.dA2);
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (T.dTA) {
+        hipLaunchKernelGGL(baztab::build_ta_kernel, grid_for((size_t)m * res), dim3(256), 0, s, reinterpret_cast<const float2*>(c->dRaw), m, res, T.dTA);
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (T.dCS) HIP_TRY(c, hipMemsetAsync(T.dCS, 0, coarse_image_bytes(c), s));
+    if (T.dIB) HIP_TRY(c, hipMemsetAsync(T.dIB, 0, i8_image_bytes(m, steps), s));
+    HIP_TRY(c, hipStreamSynchronize(s));                 // the scalars are on the host
+    const baztab::TableStats st = *static_cast<const baztab::TableStats*>(c->hTabStats);
+    double fmax, amax2;
+    std::memcpy(&fmax, &st.fmax_bits, sizeof(double));
+    std::memcpy(&amax2, &st.amax2_bits, sizeof(double));
     // projector-form accuracy: |error(d)| ~ m^2 eps ||a||^2 absolute; a d at or below m 1e-8 max||a||^2 (relative
     // error there <~ 1e-7) is recomputed in the reference's literal form (literal_tile() in the scan)
-    double amax2 = 0.0;
-    for (uint32_t b = 0; b < c->res; ++b) {
-        double a2 = 0.0;
-        for (uint32_t i = 0; i < c->m; ++i) {
-            const double re = table_ri[2 * ((size_t)b * c->m + i)], im = table_ri[2 * ((size_t)b * c->m + i) + 1];
-            a2 += re * re + im * im;
-        }
-        if (a2 > amax2 && a2 < 1e300) amax2 = a2;
-    }
-    c->refine_below = amax2 * (double)c->m * 1e-8;
-    c->cs_ok = false;
-    if (c->dCS) {    // coarse-gated scan: f16 pieces of the scaled table + the fp64 operand, per 16-bin tile
-        std::vector<uint8_t> img;
-        if (build_coarse_image(F, c->m, c->res, c->cs_tiles, img, c->cs)) {
-            if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COARSE_LAZY")) c->cs.lazy = atoi(v);            // lab
-            HIP_TRY(c, hipMemcpy(c->dCS, img.data(), img.size(), hipMemcpyHostToDevice));
-            c->cs_ok = true;
-        }
-    }
-    c->i8_ok = false;
-    if (c->dIB) {    // int8-matrix-core scan: the table's digit image
-        std::vector<uint8_t> img;
-        if (build_i8_image(F, c->m, c->res, c->fb_steps, img, c->i8)) {
-            HIP_TRY(c, hipMemcpy(c->dIB, img.data(), img.size(), hipMemcpyHostToDevice));
-            c->i8_ok = true;
+    T.refine_below = amax2 * (double)m * 1e-8;
+    T.cs_ok = false;
+    T.i8_ok = false;
+    const bool finite = st.nonfinite == 0;
+    if (T.dCS && finite) {    // coarse-gated scan: f16 pieces of the scaled table + the fp64 operand, per 16-bin tile
+        double FS = 0.0;
+        if (coarse_params_from(fmax, m, T.cs, FS)) {
+            T.cs.lazy = 1;
+            if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COARSE_LAZY")) T.cs.lazy = atoi(v);            // lab
+            uint8_t* img = reinterpret_cast<uint8_t*>(T.dCS);
+            hipLaunchKernelGGL(baztab::build_coarse_c_kernel, grid_for((size_t)(c->cs_tiles + 1) * 16 * m * m), dim3(256), 0, s,
+                               c->dRaw, m, res, c->cs_tiles, FS, img);
+            HIP_TRY(c, hipGetLastError());
+            double* X0 = reinterpret_cast<double*>(img + (size_t)(c->cs_tiles + 1) * cs_c_units((int)m) * 16);
+            hipLaunchKernelGGL(baztab::build_coarse_x_kernel, grid_for((size_t)c->cs_tiles * 256 * cs_groups((int)m)), dim3(256), 0, s,
+                               c->dRaw, m, res, c->cs_tiles, X0);
+            HIP_TRY(c, hipGetLastError());
+            T.cs_ok = true;
         }
     }
-    if (c->dA2p) {   // ||a||^2 per bin for the scan's short form; huge outside the table, like FB's diagonal there
-        std::vector<double> a2((size_t)(c->fb_steps + 2) * 64, 1e300);
-        for (uint32_t b = 0; b < c->res; ++b) {
-            double v = 0.0;
-            for (uint32_t i = 0; i < c->m; ++i) {
-                const double re = table_ri[2 * ((size_t)b * c->m + i)], im = table_ri[2 * ((size_t)b * c->m + i) + 1];
-                v += re * re + im * im;
-            }
-            a2[64 + b] = v;
+    if (T.dIB && finite) {    // int8-matrix-core scan: the table's digit image
+        double sf = 0.0;
+        if (i8_params_from(fmax, m, T.i8, sf)) {
+            uint8_t* img = reinterpret_cast<uint8_t*>(T.dIB);
+            hipLaunchKernelGGL(baztab::build_i8_kernel, grid_for((size_t)res * i8_nkb((int)m) * 4), dim3(256), 0, s, c->dRaw, m, res,
+                               steps, sf, img, img + i8_image_bytes5(m, steps));
+            HIP_TRY(c, hipGetLastError());
+            T.i8_ok = true;
         }
-        HIP_TRY(c, hipMemcpy(c->dA2p, a2.data(), a2.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return BAZ_MUSIC_OK;
+}
+
+// Replaces set_array_response's body (.cc:60-70).  The caller holds c->tab_mtx.  `first`: called from baz_music_create (no
+// batch can be in flight, the images go straight into the active set).
+int retune(baz_music_ctx* c, const float* table_ri, bool first)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    std::memcpy(c->hRaw, table_ri, (size_t)c->res * c->m * 2 * sizeof(float));
+    if (first) {
+        TableSet T = active_table_set(c);
+        const int r = build_tables_device(c, T);
+        install_table_set(c, T);
+        return r;
+    }
+    // the shadow set was the active one until the previous swap: batches launched before that swap may still read it
+    if (c->swap_recorded) HIP_TRY(c, hipStreamWaitEvent(c->s_tab, c->ev_swap, 0));
+    const int r = build_tables_device(c, c->shadow);
+    if (r != BAZ_MUSIC_OK) return r;                      // the old table stays in force
+    const auto t1 = std::chrono::steady_clock::now();
+    {
+        std::lock_guard<std::mutex> lk(c->mtx);           // .cc:67 -- for the exchange of a few pointers only
+        const TableSet old = active_table_set(c);
+        install_table_set(c, c->shadow);
+        c->shadow = old;
+        c->swap_recorded = hipEventRecord(c->ev_swap, c->stream) == hipSuccess;
+        if (!c->swap_recorded) {                          // cannot order the next retune behind the batches in flight: drain them now
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(c->stream);
+        }
+    }
+    const auto t2 = std::chrono::steady_clock::now();
+    c->last_retune_ms = std::chrono::duration<double, std::milli>(t2 - t0).count();
+    c->last_swap_wait_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
     return BAZ_MUSIC_OK;
 }
 
@@ -1510,6 +1608,27 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
     return BAZ_MUSIC_OK;
 }
 
+// baz_music_create's last step: both table sets, the builders' side stream and staging buffers, then the first table
+int create_tables(baz_music_ctx* c, const float* table_ri)
+{
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
+    if (hipStreamCreateWithPriority(&c->s_tab, hipStreamNonBlocking, hi) != hipSuccess) return BAZ_MUSIC_E_HIP;
+    if (hipEventCreateWithFlags(&c->ev_swap, hipEventDisableTiming) != hipSuccess) return BAZ_MUSIC_E_HIP;
+    const size_t raw_bytes = (size_t)c->res * c->m * 2 * sizeof(float);
+    if (hipMalloc((void**)&c->dRaw, raw_bytes) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (hipHostMalloc((void**)&c->hRaw, raw_bytes, hipHostMallocDefault) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (hipMalloc(&c->dTabStats, sizeof(baztab::TableStats)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (hipHostMalloc(&c->hTabStats, sizeof(baztab::TableStats), hipHostMallocDefault) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    TableSet first;
+    int r = alloc_table_set(c, first);
+    install_table_set(c, first);                          // (also after a failed allocation: destroy frees what exists)
+    if (r == BAZ_MUSIC_OK) r = alloc_table_set(c, c->shadow);
+    if (r != BAZ_MUSIC_OK) return r;
+    std::lock_guard<std::mutex> tl(c->tab_mtx);
+    return retune(c, table_ri, true);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1576,8 +1695,6 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
                 if (!ok) { r = BAZ_MUSIC_E_HIP; break; }
             }
             if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SUB_EVD")) c->sub_evd = atoi(v);                   // lab / tests
-            if (hipMalloc((void**)&c->dTA, (size_t)m * resolution * sizeof(float2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
-            if (hipMalloc((void**)&c->dA2, (size_t)resolution * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_WIDE_LITERAL")) c->wide_literal_only = atoi(v);   // lab / tests
             if (hipMalloc((void**)&c->dRefined, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMemset(c->dRefined, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
@@ -1590,10 +1707,8 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
                 c->fb_steps = (resolution + 63) / 64;
                 c->keep_mask = (resolution <= (1u << 16)) ? 0xFFFF0000u : 0xFFF00000u;
                 c->tb_step_elems = (size_t)2 * ((2 * m + 3) / 4) * 64;
-                if (hipMalloc((void**)&c->dTB, (size_t)(c->fb_steps + 2) * c->tb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
-                if (hipMalloc((void**)&c->dA2p, (size_t)(c->fb_steps + 2) * 64 * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             }
-            r = upload_table(c, table_ri);
+            r = create_tables(c, table_ri);
             break;
         }
         c->fb_steps = (resolution + 63) / 64;
@@ -1625,8 +1740,6 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
                 c->covevd_blocks = (uint32_t)per_cu * (uint32_t)std::max(1, prop.multiProcessorCount);
             else (void)hipGetLastError();
         }
-        if (hipMalloc((void**)&c->dFB, (size_t)(c->fb_steps + 2) * c->fb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
-        if (hipMalloc((void**)&c->dTB, (size_t)(c->fb_steps + 2) * c->tb_step_elems * sizeof(double2)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SIG_SCAN")) c->sig_scan = atoi(v);                  // lab / tests
         if (const char* v = getenv("BAZ_MUSIC_COARSE")) c->coarse = atoi(v);                      // A/B, tests
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COARSE_RG")) c->coarse_rg = atoi(v);                // lab
@@ -1634,18 +1747,15 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COARSE_STATS")) c->coarse_stats = atoi(v);          // lab
         if (m <= 8) {
             c->cs_tiles = round_up((resolution + 15) / 16, 8);
-            if (hipMalloc((void**)&c->dCS, ((size_t)(c->cs_tiles + 1) * cs_c_units((int)m) + (size_t)c->cs_tiles * CS_X_UNITS * cs_groups((int)m)) * 16) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMalloc((void**)&c->dMargin, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMemset(c->dMargin, 0, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         }
         if (const char* v = getenv("BAZ_MUSIC_EXACT")) c->i8_on = atoi(v) ? 0 : 1;                // A/B: 1 = the fp64 scan everywhere
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8_ABL")) c->i8_abl = atoi(v);                  // lab
-        if (m >= 6 && n <= 4 && i8_image_bytes(m, c->fb_steps) <= I8_IMAGE_LIMIT) {
-            if (hipMalloc((void**)&c->dIB, i8_image_bytes(m, c->fb_steps)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+        if (wants_i8_image(c)) {
             if (hipMalloc((void**)&c->dI8Stat, 8 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMemset(c->dI8Stat, 0, 8 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         }
-        if (short_form_applies(m, n) && hipMalloc((void**)&c->dA2p, (size_t)(c->fb_steps + 2) * 64 * sizeof(double)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         {
             // ONE workgroup per CU (4 persistent waves, 8 KiB in flight each = 8 MB chip-wide): measured against 2 / 3 / 4 /
             // 6 (the occupancy limit) / 8 per CU, the fewest concurrent input streams read fastest -- 0.370 vs 0.396 ms per
@@ -1657,7 +1767,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         }
         if (hipMalloc((void**)&c->dRefined, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         if (hipMemset(c->dRefined, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
-        r = upload_table(c, table_ri);
+        r = create_tables(c, table_ri);
     } while (0);
     if (r != BAZ_MUSIC_OK) {
         baz_music_destroy(c);
@@ -1694,26 +1804,32 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         for (auto& p : c->prof)
             for (auto e : p.ev) (void)hipEventDestroy(e);
-        if (c->dFB) (void)hipFree(c->dFB);
+        if (c->s_tab) (void)hipStreamSynchronize(c->s_tab);
+        {
+            TableSet act = active_table_set(c);
+            free_table_set(act);
+            install_table_set(c, act);
+            free_table_set(c->shadow);
+        }
+        if (c->dRaw) (void)hipFree(c->dRaw);
+        if (c->hRaw) (void)hipHostFree(c->hRaw);
+        if (c->dTabStats) (void)hipFree(c->dTabStats);
+        if (c->hTabStats) (void)hipHostFree(c->hTabStats);
+        if (c->ev_swap) (void)hipEventDestroy(c->ev_swap);
+        if (c->s_tab) (void)hipStreamDestroy(c->s_tab);
         if (c->dCand) (void)hipFree(c->dCand);
         if (c->dR) (void)hipFree(c->dR);
         if (c->dQ) (void)hipFree(c->dQ);
         if (c->dG) (void)hipFree(c->dG);
         if (c->dRedo) (void)hipFree(c->dRedo);
         if (c->dSs) (void)hipFree(c->dSs);
-        if (c->dA2p) (void)hipFree(c->dA2p);
-        if (c->dTB) (void)hipFree(c->dTB);
-        if (c->dCS) (void)hipFree(c->dCS);
-        if (c->dIB) (void)hipFree(c->dIB);
         if (c->dI8Stat) (void)hipFree(c->dI8Stat);
         if (c->dMargin) (void)hipFree(c->dMargin);
         if (c->dRefined) (void)hipFree(c->dRefined);
         if (c->dPeakSpec) (void)hipFree(c->dPeakSpec);
-        if (c->dTA) (void)hipFree(c->dTA);
         if (c->dGw) (void)hipFree(c->dGw);
         if (c->dWS) (void)hipFree(c->dWS);
         if (c->dSw) (void)hipFree(c->dSw);
-        if (c->dA2) (void)hipFree(c->dA2);
         host_unregister_all_locked(c);
         free_slots(c);
         if (c->ev_in) (void)hipEventDestroy(c->ev_in);
@@ -1728,9 +1844,18 @@ void baz_music_destroy(baz_music_ctx* c)
 int baz_music_set_table(baz_music_ctx* c, const float* table_ri)
 {
     if (!c || !table_ri) return BAZ_MUSIC_E_INVALID;
-    std::lock_guard<std::mutex> lk(c->mtx);   // .cc:67
+    std::lock_guard<std::mutex> tl(c->tab_mtx);   // one retune at a time; work() is held up for the pointer exchange only (retune())
     DeviceGuard guard(c->device);
-    return upload_table(c, table_ri);
+    return retune(c, table_ri, false);
+}
+
+int baz_music_last_retune_ms(baz_music_ctx* c, double* total_ms, double* swap_ms)
+{
+    if (!c) return BAZ_MUSIC_E_INVALID;
+    std::lock_guard<std::mutex> tl(c->tab_mtx);
+    if (total_ms) *total_ms = c->last_retune_ms;
+    if (swap_ms) *swap_ms = c->last_swap_wait_ms;
+    return BAZ_MUSIC_OK;
 }
 
 int baz_music_set_stream(baz_music_ctx* c, void* hip_stream)
@@ -2229,6 +2354,163 @@ size_t baz_music_debug_i8_image(uint32_t m, uint32_t resolution, const float* ta
     }
     if (out && out_bytes >= img.size()) std::memcpy(out, img.data(), img.size());
     return img.size();
+}
+
+// ---- the table images: what the device builders produced (active set) against the former host builders -------------------
+// which: 0 FB, 1 TB, 2 coarse (C then X), 3 int8 digits (0 .. 4 then 5, 6), 4 ||a||^2 padded, 5 transposed table (m > 16),
+// 6 ||a||^2 plain (m > 16), 7 the parameters as BAZ_MUSIC_TABLE_NPARAMS doubles.  Returns the image's size in bytes (0: this
+// configuration has no such image); written when out_bytes suffices.
+namespace {
+constexpr int TABLE_NPARAMS = 22;
+void pack_table_params(const TableSet& T, bool has_cs, bool has_i8, double* p)
+{
+    for (int i = 0; i < TABLE_NPARAMS; ++i) p[i] = 0.0;
+    p[0] = T.refine_below;
+    if (has_cs && T.cs_ok) { p[1] = 1.0; p[2] = T.cs.sc_up; p[3] = T.cs.es_factor; p[4] = T.cs.sc; p[5] = T.cs.fmax; }
+    if (has_i8 && T.i8_ok) {
+        p[6] = 1.0;
+        for (int l = 0; l < I8_ND; ++l) p[7 + l] = T.i8.wt[l];
+        p[14] = T.i8.sq; p[15] = T.i8.t_acc; p[16] = T.i8.e_bound; p[17] = T.i8.e_refined; p[18] = T.i8.ws_f;
+        p[19] = T.i8.t_acc_f; p[20] = T.i8.t4_f; p[21] = T.i8.e4_bound;
+    }
+}
+}  // namespace
+
+size_t baz_music_debug_table_image(baz_music_ctx* c, int which, void* out, size_t out_bytes)
+{
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    DeviceGuard guard(c->device);
+    const size_t pad_steps = (size_t)c->fb_steps + 2;
+    const void* src = nullptr;
+    size_t bytes = 0;
+    switch (which) {
+        case 0: src = c->dFB; bytes = pad_steps * c->fb_step_elems * sizeof(double2); break;
+        case 1: src = c->dTB; bytes = pad_steps * c->tb_step_elems * sizeof(double2); break;
+        case 2: src = c->dCS; bytes = c->dCS ? coarse_image_bytes(c) : 0; break;
+        case 3: src = c->dIB; bytes = c->dIB ? i8_image_bytes(c->m, c->fb_steps) : 0; break;
+        case 4: src = c->dA2p; bytes = pad_steps * 64 * sizeof(double); break;
+        case 5: src = c->dTA; bytes = (size_t)c->m * c->res * sizeof(float2); break;
+        case 6: src = c->dA2; bytes = (size_t)c->res * sizeof(double); break;
+        case 7: {
+            double p[TABLE_NPARAMS];
+            pack_table_params(active_table_set(c), c->dCS != nullptr, c->dIB != nullptr, p);
+            if (out && out_bytes >= sizeof(p)) std::memcpy(out, p, sizeof(p));
+            return sizeof(p);
+        }
+        default: return 0;
+    }
+    if (!src) return 0;
+    // an image whose parameters could not be formed is not built (its bytes are whatever the buffer held): report it as absent
+    if ((which == 2 && !c->cs_ok) || (which == 3 && !c->i8_ok)) return 0;
+    if (out && out_bytes >= bytes) {
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+    }
+    return bytes;
+}
+
+// HOST-ONLY (no device needed): the same image from the round-4 host builders -- the checker of the device builders.
+size_t baz_music_debug_host_table_image(uint32_t m, uint32_t n, uint32_t resolution, const float* table_ri, int which, void* out,
+                                        size_t out_bytes)
+{
+    if (!table_ri || m == 0 || n == 0 || n >= m || m > BAZ_MUSIC_MAX_M || resolution == 0) return 0;
+    const bool wide = m > BAZ_MUSIC_FAST_M;
+    const uint32_t res = resolution, steps = (res + 63) / 64;
+    std::vector<uint8_t> bytes;
+    auto from_doubles = [&](const std::vector<double>& v) {
+        bytes.resize(v.size() * sizeof(double));
+        std::memcpy(bytes.data(), v.data(), bytes.size());
+    };
+    auto a2_of = [&](uint32_t b) {
+        double v = 0.0;
+        for (uint32_t i = 0; i < m; ++i) {
+            const double re = table_ri[2 * ((size_t)b * m + i)], im = table_ri[2 * ((size_t)b * m + i) + 1];
+            v += re * re + im * im;
+        }
+        return v;
+    };
+    const bool has_cs = !wide && m <= 8;
+    const bool has_i8 = !wide && m >= 6 && n <= 4 && i8_image_bytes(m, steps) <= I8_IMAGE_LIMIT;
+    const bool has_a2p = wide ? (n <= 8) : short_form_applies(m, n);
+    const bool has_tb = wide ? (n <= 8) : true;
+    std::vector<double> F;
+    if (!wide && (which == 0 || which == 2 || which == 3 || which == 7)) build_F(table_ri, m, res, F);
+    switch (which) {
+        case 0: {
+            if (wide) return 0;
+            std::vector<double> FB;
+            build_FB(F, m, res, steps, FB);
+            from_doubles(FB);
+            break;
+        }
+        case 1: {
+            if (!has_tb) return 0;
+            std::vector<double> TB;
+            build_TB(table_ri, m, res, steps, TB);
+            from_doubles(TB);
+            break;
+        }
+        case 2: {
+            if (!has_cs) return 0;
+            CoarseParams cp = {0.0f, 0.0f, 0.0, 0.0, 1};
+            if (!build_coarse_image(F, m, res, round_up((res + 15) / 16, 8), bytes, cp)) return 0;
+            break;
+        }
+        case 3: {
+            if (!has_i8) return 0;
+            I8Params ip = {};
+            if (!build_i8_image(F, m, res, steps, bytes, ip)) return 0;
+            break;
+        }
+        case 4: {
+            if (!has_a2p) return 0;
+            std::vector<double> a2((size_t)(steps + 2) * 64, 1e300);
+            for (uint32_t b = 0; b < res; ++b) a2[64 + b] = a2_of(b);
+            from_doubles(a2);
+            break;
+        }
+        case 5: {
+            if (!wide) return 0;
+            std::vector<float> ta((size_t)m * res * 2);
+            for (uint32_t b = 0; b < res; ++b)
+                for (uint32_t i = 0; i < m; ++i) {
+                    ta[2 * ((size_t)i * res + b)] = table_ri[2 * ((size_t)b * m + i)];
+                    ta[2 * ((size_t)i * res + b) + 1] = table_ri[2 * ((size_t)b * m + i) + 1];
+                }
+            bytes.resize(ta.size() * sizeof(float));
+            std::memcpy(bytes.data(), ta.data(), bytes.size());
+            break;
+        }
+        case 6: {
+            if (!wide) return 0;
+            std::vector<double> a2(res);
+            for (uint32_t b = 0; b < res; ++b) a2[b] = a2_of(b);
+            from_doubles(a2);
+            break;
+        }
+        case 7: {
+            TableSet T;
+            double amax2 = 0.0;
+            for (uint32_t b = 0; b < res; ++b) {
+                const double a2 = a2_of(b);
+                if (a2 > amax2 && a2 < 1e300) amax2 = a2;
+            }
+            T.refine_below = amax2 * (double)m * 1e-8;
+            std::vector<uint8_t> scratch;
+            if (has_cs) T.cs_ok = build_coarse_image(F, m, res, round_up((res + 15) / 16, 8), scratch, T.cs);
+            if (has_i8) T.i8_ok = build_i8_image(F, m, res, steps, scratch, T.i8);
+            std::vector<double> p(TABLE_NPARAMS);
+            pack_table_params(T, has_cs, has_i8, p.data());
+            from_doubles(p);
+            break;
+        }
+        default: return 0;
+    }
+    if (out && out_bytes >= bytes.size()) std::memcpy(out, bytes.data(), bytes.size());
+    return bytes.size();
 }
 
 int baz_music_debug_evd(baz_music_ctx* c, const void* d_R, uint32_t batch, void* d_Q)

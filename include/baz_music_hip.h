@@ -69,8 +69,16 @@ BAZ_MUSIC_API int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, 
 BAZ_MUSIC_API void baz_music_destroy(baz_music_ctx* ctx);
 
 /* Replaces baz_music_doa::set_array_response (lib/baz_music_doa.cc:60-70): takes effect for
- * every item submitted after it returns. Thread-safe against process*(). */
+ * every item submitted after it returns. Thread-safe against process*().
+ * The reference holds d_mutex (.cc:67) for one vector copy (.cc:69).  Here every device image of the new table (bilinear-form
+ * table, raw-table operand, f16 pieces of the gated scan, int8 digit planes, ||a||^2) is built BY THE DEVICE on a side stream
+ * into a second set of buffers while process*() keeps running on the old one; the lock that serialises against process*() is
+ * taken only to exchange the two sets (gr_baz_amd/csrc/table_kernels.hip.h).  A batch sees the old table or the new one, never a
+ * mixture.  Concurrent callers of set_table are serialised among themselves. */
 BAZ_MUSIC_API int baz_music_set_table(baz_music_ctx* ctx, const float* table_ri);
+/* Wall time of the last baz_music_set_table() of this context in milliseconds, and the part of it spent waiting for and
+ * holding the lock shared with process*() (what a running work() can be held up by). */
+BAZ_MUSIC_API int baz_music_last_retune_ms(baz_music_ctx* ctx, double* total_ms, double* swap_ms);
 
 /* NUMERIC CONTRACT of the float outputs.  The reference stores (float)(1.0 / d), d = ||G^H a||^2 in fp64
  * (lib/baz_music_doa.cc:114-121,153).  Here d is evaluated in fp64 (projector form, literal form near nulls) and the
@@ -165,6 +173,17 @@ BAZ_MUSIC_API int baz_music_debug_i8_stats(baz_music_ctx* ctx, uint64_t* refined
 BAZ_MUSIC_API int baz_music_uses_i8_scan(const baz_music_ctx* ctx);
 BAZ_MUSIC_API size_t baz_music_debug_i8_image(uint32_t m, uint32_t resolution, const float* table_ri, uint8_t* out,
                                               size_t out_bytes, double* params);
+/*   table images : `table_image` copies image `which` of the table IN FORCE back from the device -- 0 the bilinear-form table in
+ *                          MFMA B-operand order, 1 the raw table in that order, 2 the gated scan's f16 pieces + fp64 operand, 3 the
+ *                          int8 digit planes, 4 ||a||^2 per bin (padded), 5 / 6 the run-time-m path's transposed table and
+ *                          ||a||^2, 7 the scalar parameters (BAZ_MUSIC_TABLE_NPARAMS doubles) -- and returns its size in bytes
+ *                          (0: no such image for this configuration / table; nothing is written when out_bytes is too small).
+ *                          `host_table_image` (needs no device) builds the same image with the round-4 host routines: the
+ *                          checker the device builders must agree with byte for byte (tests/test_retune.py). */
+#define BAZ_MUSIC_TABLE_NPARAMS 22
+BAZ_MUSIC_API size_t baz_music_debug_table_image(baz_music_ctx* ctx, int which, void* out, size_t out_bytes);
+BAZ_MUSIC_API size_t baz_music_debug_host_table_image(uint32_t m, uint32_t n, uint32_t resolution, const float* table_ri,
+                                                      int which, void* out, size_t out_bytes);
 /*   (host only) the bin ranges per item the int8 scan launches with: whole rounds of the `slots` resident workgroups. */
 BAZ_MUSIC_API uint32_t baz_music_debug_i8_nsplit(uint32_t batch, uint32_t nsteps, uint32_t slots);
 BAZ_MUSIC_API uint32_t baz_music_q_stride(uint32_t batch);

@@ -1,0 +1,240 @@
+"""set_array_response without stalling the stream (/root/reference/lib/baz_music_doa.cc:60-70, python/music_doa_helper.py:100-103).
+
+The reference holds its mutex for one vector copy.  The replacement builds every device image of the new table ON the device
+(gr_baz_amd/csrc/table_kernels.hip.h) into a shadow set and holds the lock shared with work() for the pointer exchange only.
+Pinned here:
+  * the device-built images equal the round-4 host-built ones byte for byte, parameters included (cfg2, cfg3, m = 16, odd
+    shapes, the run-time-m path, tables with huge / zero / non-finite entries);
+  * a retune while another thread keeps submitting config-3 batches: set_table returns within 10 ms, no batch of the submitting
+    thread is held up by more than 1 ms over its undisturbed time, every batch is computed with exactly one table.
+CPU part: the host checker itself against the numpy oracle's table (no device needed)."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from oracle import music_oracle as mo
+
+
+def _capi():
+    from gr_baz_amd import capi
+    return capi
+
+
+def _table(m, res, scale=1.0, freq=mo.FREQUENCY):
+    arr = mo.array_geometry(m)
+    return (mo.steering_table_c64(arr, res, freq, mo.SPACING) * np.float32(scale)).astype(np.complex64)
+
+
+# ---------------------------------------------------------------------------------------------------------- CPU: the checker
+def test_host_checker_FB_and_a2_follow_the_table():
+    """baz_music_debug_host_table_image needs no device: FB holds F[bin][e] in the documented order, a2p ||a||^2."""
+    capi = _capi()
+    m, n, res = 4, 2, 130
+    t = _table(m, res)
+    fb = capi.debug_host_table_image(m, n, res, t, 0).view(np.float64)
+    steps, ks = (res + 63) // 64, (m * m + 3) // 4
+    fb = fb.reshape(steps + 2, 2 * ks, 64, 2)
+    a = t.astype(np.complex128)
+    for (sti, s, tt, lane) in [(1, 0, 0, 0), (1, 3, 2, 37), (2, 1, 3, 63), (3, 2, 1, 5)]:
+        g, c = lane >> 4, lane & 15
+        b, e = 64 * (sti - 1) + 4 * c + tt, 4 * s + g
+        r, cc = divmod(e, m)
+        if b >= res:
+            want = 1e300 if r == cc else 0.0
+        elif r == cc:
+            want = abs(a[b, r]) ** 2
+        elif r < cc:
+            want = (np.conj(a[b, r]) * a[b, cc]).real
+        else:
+            want = (np.conj(a[b, cc]) * a[b, r]).imag
+        got = fb[sti, 2 * s + (tt >> 1), lane, tt & 1]
+        assert got == pytest.approx(want, rel=1e-15, abs=1e-300)
+    assert capi.debug_host_table_image(m, n, res, t, 4) is None          # no short form at m = 4
+    a2p = capi.debug_host_table_image(9, 2, res, _table(9, res), 4).view(np.float64)
+    assert a2p[0] == 1e300 and a2p[64 + res] == 1e300
+    assert a2p[64 + 7] == pytest.approx(9.0, rel=1e-6)
+    par = capi.debug_host_table_image(8, 2, res, _table(8, res), 7).view(np.float64)
+    assert len(par) == 22 and par[1] == 1.0 and par[6] == 1.0 and par[0] == pytest.approx(8 * 8 * 1e-8, rel=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------- GPU
+SHAPES = [
+    ("cfg2", 4, 2, 1024, 3600, 1.0),
+    ("cfg3", 8, 2, 4096, 36000, 1.0),
+    ("cfg5", 16, 2, 4096, 3600, 1.0),
+    ("m2", 2, 1, 64, 77, 1.0),
+    ("m3", 3, 2, 96, 1000, 3.7),
+    ("m5", 5, 3, 640, 720, 0.01),
+    ("m6n1", 6, 1, 384, 1441, 1.0),
+    ("m7", 7, 4, 448, 500, 250.0),
+    ("m9", 9, 2, 576, 250, 1.0),
+    ("m12n9", 12, 9, 768, 720, 1e-6),
+    ("m13", 13, 2, 832, 4097, 1.0),
+    ("wide24", 24, 5, 1536, 500, 1.0),
+    ("wide64n8", 64, 8, 4096, 360, 2.0),
+    ("wide33n32", 33, 32, 2112, 90, 1.0),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,m,n,N,res,scale", SHAPES, ids=[s[0] for s in SHAPES])
+def test_device_built_images_equal_the_host_built_ones(name, m, n, N, res, scale, gpu_device):
+    capi = _capi()
+    t0 = _table(m, res, scale)
+    t1 = _table(m, res, scale * 1.7, freq=mo.FREQUENCY * 0.83)
+    with capi.Context(m, n, N, res, t0) as ctx:
+        for rnd, t in enumerate((t0, t1, t0)):           # create, a retune into the shadow set, a retune back into the first
+            if rnd:
+                ctx.set_table(t)
+            for which, label in capi.TABLE_IMAGES.items():
+                dev = ctx.debug_table_image(which)
+                host = capi.debug_host_table_image(m, n, res, t, which)
+                assert (dev is None) == (host is None), "%s: image %s exists on one side only" % (name, label)
+                if dev is not None:
+                    assert dev.shape == host.shape, "%s: image %s sizes differ" % (name, label)
+                    bad = np.flatnonzero(dev != host)
+                    assert bad.size == 0, "%s round %d: image %s differs in %d bytes, first at %d" % (name, rnd, label, bad.size, bad[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["nan", "inf", "zero", "huge", "tiny"])
+def test_device_built_images_on_degenerate_tables(kind, gpu_device):
+    capi = _capi()
+    m, n, N, res = 8, 2, 512, 300
+    t = _table(m, res)
+    if kind == "nan":
+        t[17, 3] = np.nan
+    elif kind == "inf":
+        t[5, 0] = np.inf
+    elif kind == "zero":
+        t[:] = 0
+    elif kind == "huge":
+        t *= np.float32(1e12)
+    else:
+        t *= np.float32(1e-18)
+    with capi.Context(m, n, N, res, _table(m, res)) as ctx:
+        ctx.set_table(t)
+        for which, label in capi.TABLE_IMAGES.items():
+            dev = ctx.debug_table_image(which)
+            host = capi.debug_host_table_image(m, n, res, t, which)
+            assert (dev is None) == (host is None), "%s: image %s exists on one side only" % (kind, label)
+            if dev is not None:
+                if which in (0, 1, 4, 7):        # (NaN payloads: compare as bits)
+                    assert np.array_equal(dev, host), "%s: image %s differs" % (kind, label)
+                else:
+                    assert np.array_equal(dev, host)
+        par = capi.debug_host_table_image(m, n, res, t, 7).view(np.float64)
+        assert ctx.uses_i8_scan() == bool(par[6])
+        assert bool(par[6]) == (kind == "huge")          # (1e-18: the digit scale leaves the float range; the fp64 scan runs)
+
+
+@pytest.mark.gpu
+def test_retune_does_not_stall_the_submitting_thread(gpu_device):
+    """Thread A keeps one config-3 batch per call in flight (process_device + sync), thread B retunes 20 times."""
+    import torch
+    capi = _capi()
+    c = mo.make_config("cfg3", 64, snr_db=20.0, seed=501)
+    m, n, N, res = c["m"], c["n"], c["nsamples"], c["res"]
+    B = 4096
+    tA = c["table"]
+    tB = mo.steering_table_c64(c["array"], res, mo.FREQUENCY * 0.9, mo.SPACING)
+    reps = (B + 63) // 64
+    x = torch.from_numpy(np.ascontiguousarray(np.tile(c["items"], (reps, 1))[:B]).view(np.float32)).to(gpu_device)
+    ang = torch.zeros(B, n, dtype=torch.float32, device=gpu_device)
+    lvl = torch.zeros_like(ang)
+    spec = torch.zeros(B, res, dtype=torch.float32, device=gpu_device)
+    sA = mo.music_doa_work_batch(c["items"][:4], tA, m, n)[2]
+    sB = mo.music_doa_work_batch(c["items"][:4], tB, m, n)[2]
+    torch.cuda.synchronize()
+    with capi.Context(m, n, N, res, tA) as ctx:
+        ctx.reserve(B)
+
+        def one_call():
+            t0 = time.perf_counter()
+            ctx.process_device(x.data_ptr(), B, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr())
+            ctx.sync()
+            return time.perf_counter() - t0
+
+        for _ in range(10):
+            one_call()
+        quiet = np.array([one_call() for _ in range(60)])
+        base = float(np.median(quiet))
+        quiet_worst = float(quiet.max())
+
+        walls, swaps, stop, err = [], [], threading.Event(), []
+
+        def retuner():
+            try:
+                for k in range(20):
+                    time.sleep(0.004)
+                    t0 = time.perf_counter()
+                    ctx.set_table(tB if (k & 1) == 0 else tA)
+                    walls.append(time.perf_counter() - t0)
+                    swaps.append(ctx.last_retune_ms())
+            except Exception as e:      # noqa: BLE001
+                err.append(e)
+            finally:
+                stop.set()
+
+        th = threading.Thread(target=retuner)
+        busy = []
+        seen = set()
+        th.start()
+        try:
+            while not stop.is_set():
+                busy.append(one_call())
+                s = spec[:4].cpu().numpy().astype(np.float64)
+                relA = np.max(np.abs(s - sA) / sA)
+                relB = np.max(np.abs(s - sB) / sB)
+                assert min(relA, relB) <= 1e-5, "a batch mixed two steering tables"
+                seen.add("A" if relA <= relB else "B")
+        finally:
+            stop.set()
+            th.join()
+        assert not err, err
+    busy = np.array(busy)
+    walls_ms = np.array(walls) * 1e3
+    gap_ms = (float(busy.max()) - base) * 1e3
+    print("\nretune at cfg3, %d-item batches: undisturbed call %.3f ms (worst %.3f), during 20 retunes worst %.3f ms -> extra gap %.3f ms; "
+          "set_table wall: median %.3f ms, worst %.3f ms; lock wait+hold worst %.4f ms; tables seen %s"
+          % (B, base * 1e3, quiet_worst * 1e3, busy.max() * 1e3, gap_ms, np.median(walls_ms), walls_ms.max(),
+             max(s[1] for s in swaps), sorted(seen)))
+    assert len(walls) == 20
+    assert walls_ms.max() <= 10.0, "set_table took %.2f ms" % walls_ms.max()
+    assert gap_ms <= 1.0, "work() was held up by %.3f ms" % gap_ms
+    assert seen == {"A", "B"}
+
+
+@pytest.mark.gpu
+def test_retune_between_batches_in_flight_never_tears(gpu_device):
+    """Batches queued WITHOUT waiting (many in flight) while the table is exchanged twice in between: the retired set must not
+    be rebuilt while a queued batch still reads it (the second retune waits on the swap event)."""
+    import torch
+    capi = _capi()
+    c = mo.make_config("cfg2", 256, snr_db=20.0, seed=77)
+    m, n, N, res = c["m"], c["n"], c["nsamples"], c["res"]
+    tA = c["table"]
+    tB = mo.steering_table_c64(c["array"], res, mo.FREQUENCY * 0.9, mo.SPACING)
+    tC = mo.steering_table_c64(c["array"], res, mo.FREQUENCY * 1.1, mo.SPACING)
+    want = {k: mo.music_doa_work_batch(c["items"][:8], t, m, n)[2] for k, t in (("A", tA), ("B", tB), ("C", tC))}
+    B = 32768
+    x = torch.from_numpy(np.ascontiguousarray(np.tile(c["items"], (B // 256, 1))).view(np.float32)).to(gpu_device)
+    outs = [(torch.zeros(B, n, dtype=torch.float32, device=gpu_device), torch.zeros(B, res, dtype=torch.float32, device=gpu_device))
+            for _ in range(6)]
+    torch.cuda.synchronize()
+    with capi.Context(m, n, N, res, tA) as ctx:
+        ctx.reserve(B)
+        order = []
+        for k, (a, s) in enumerate(outs):
+            ctx.process_device(x.data_ptr(), B, a.data_ptr(), None, s.data_ptr())
+            order.append("ABC"[min(k // 2, 2)])
+            if k == 1:
+                ctx.set_table(tB)
+            if k == 3:
+                ctx.set_table(tC)
+        ctx.sync()
+    for lab, (a, s) in zip(order, outs):
+        got = s[:8].cpu().numpy().astype(np.float64)
+        assert np.max(np.abs(got - want[lab]) / want[lab]) <= 1e-5, "batch expected table %s" % lab
