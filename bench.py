@@ -153,6 +153,60 @@ def cpu_baseline(table, seconds_per_thread=2.0):
     return out
 
 
+I8_MFMA_PEAK_TOPS = 5000.0   # dense int8 = 2 x the ~2.5 PF bf16 dense peak (MI355X_MICROARCH.md, matrix cores; ubench >= 3944 TOPS)
+VERIFY_TOL = 1e-5            # north_star's relative tolerance on float outputs
+
+
+def verify_against_oracle(torch, np, x, ang, lvl, spec, table, m, n, nsamples, res, count):
+    """The line proves what it timed: AFTER the timed region, `count` items spread over the batch are
+    copied back together with what the LAST timed step left in the output buffers, and the CPU oracle (the plain-C restatement
+    of work(), oracle/music_ref.c -- the checker, never the thing measured) recomputes them.  Returns scalar keys:
+    verified_items, verified_max_rel_err (spectrum and lvl, relative), verified_bins_identical (DoA bins equal, or different
+    only between bins whose reference strengths agree to 2e-5: the reference's own tie rule), verified_ok."""
+    from oracle import music_ref as mr
+    B = x.shape[0]
+    idx = np.unique(np.linspace(0, B - 1, min(count, B)).astype(np.int64))
+    ti = torch.from_numpy(idx).to(x.device)
+    items = x.index_select(0, ti).cpu().numpy().view(np.complex64).reshape(len(idx), nsamples)
+    ga = ang.index_select(0, ti).cpu().numpy()
+    gl = lvl.index_select(0, ti).cpu().numpy().astype(np.float64)
+    ao, lo, so = mr.work_batch(np.ascontiguousarray(items), table, m, n)
+    worst = float(np.max(np.abs(gl - lo) / lo))
+    if spec is not None:
+        gs = spec.index_select(0, ti).cpu().numpy().astype(np.float64)
+        worst = max(worst, float(np.max(np.abs(gs - so) / so)))
+    swaps, wrong = 0, 0
+    if not np.array_equal(ga, ao):
+        for r in np.flatnonzero(np.any(ga != ao, axis=1)):
+            # same bins in another order, or a bin whose reference strength ties with the reference's choice
+            ref_bins = np.rint(ao[r].astype(np.float64) * res / 360.0).astype(np.int64) % res
+            got_bins = np.rint(ga[r].astype(np.float64) * res / 360.0).astype(np.int64) % res
+            tie = np.all(np.abs(so[r][got_bins] - so[r][ref_bins]) <= 2e-5 * so[r][ref_bins])
+            swaps += 1 if tie else 0
+            wrong += 0 if tie else 1
+    ok = bool(worst <= VERIFY_TOL and wrong == 0 and np.isfinite(worst))
+    return {"verified_items": int(len(idx)), "verified_max_rel_err": worst, "verified_bins_identical": bool(wrong == 0),
+            "verified_bins_tie_swaps": int(swaps), "verified_ok": ok, "verified_against": "oracle/music_ref.c (plain-C restatement of work())"}
+
+
+def time_retunes(np, synth, ctx, table, m, res, arr, step, sync, count=5):
+    """set_array_response while batches are in flight: wall milliseconds of baz_music_set_table (median of `count`, alternating
+    between two tables; the last call restores `table`) and the part spent on the lock shared with work()."""
+    lam2 = synth.C_LIGHT / (FREQUENCY * 0.9)
+    from gr_baz_amd.baz.music_doa_helper import calculate_antenna_array_response
+    t2 = np.array(calculate_antenna_array_response([[SPACING * x, SPACING * y] for x, y in arr], res, lam2)).astype(np.complex64)
+    walls, locks = [], []
+    for k in range(2 * count):
+        step()
+        step()
+        t0 = time.perf_counter()
+        ctx.set_table(t2 if (k & 1) == 0 else table)
+        walls.append((time.perf_counter() - t0) * 1e3)
+        locks.append(ctx.last_retune_ms()[1])
+    sync()
+    return statistics.median(walls), max(walls), max(locks)
+
+
 def helper_table(np, synth, m, res):
     """Steering table exactly as music_doa_helper builds it, rounded to complex64 like SWIG does."""
     from gr_baz_amd.baz.music_doa_helper import calculate_antenna_array_response
@@ -208,6 +262,11 @@ def extra_music(torch, np, capi, synth, dev, stream, m, nsamples, res, batch, wi
         step()
         refined = ctx.refined_values()
         bpi = ctx.bytes_per_item(with_spectrum)
+        scan_kernel = ctx.stage_name(capi.STAGE_SCAN)       # the kernel the last launch took
+        uses_i8 = "scan_i8_kernel" in scan_kernel
+        stream.synchronize()
+        verified = verify_against_oracle(torch, np, x, ang, lvl, spec, table, m, N_EMIT, nsamples, res, 16)
+        retune_med, retune_max, retune_lock = time_retunes(np, synth, ctx, table, m, res, arr, step, stream.synchronize, 3)
         ctx.set_stream(None)
     stage = {nm: st[s][0] / max(st[s][1], 1) for s, nm in enumerate(("cov", "evd", "scan", "merge"))}
     scan_s = stage["scan"] * 1e-3
@@ -216,8 +275,20 @@ def extra_music(torch, np, capi, synth, dev, stream, m, nsamples, res, batch, wi
     out = {"items_per_step": batch, "ms_per_step": ms, "steps_timed": n, "snapshots_per_s": batch / ms * 1e3,
            "scene": scene, "snr_db": snr_db, "values_recomputed_in_literal_form_per_step": refined,
            "algorithmic_bytes_per_item": bpi, "pipeline_hbm_fraction_of_8TBs": batch / ms * 1e3 * bpi / 8e12,
-           "stage_ms_per_launch": stage}
-    if m > 16:                     # run-time-m kernels; to 32 antennas the short form on the fp64 matrix core (n <= 2)
+           "stage_ms_per_launch": stage, "scan_kernel_launched": scan_kernel,
+           "retune_ms": retune_med, "retune_ms_worst": retune_max, "retune_lock_ms_worst": retune_lock}
+    out.update(verified)
+    if uses_i8:
+        # int8 matrix core: the first tier's 10 v_mfma_i32_16x16x64_i8 per 16 x 16 tile and block of 64 terms (every tile runs
+        # them; the second / third tiers add to it where values need more digits) against the int8 dense peak -- a lower bound of
+        # the matrix work, never an "fp64-equivalent" rate
+        nkb = -(-mm // 64)
+        tiles = -(-res // 64) * 4
+        i8_tops = 2.0 * 64 * 256 * 10 * nkb * tiles * (batch / 16.0) / scan_s / 1e12 if scan_s > 0 else 0.0
+        out["scan_form"] = "int8 digits, exact int32 accumulation (scan_i8_kernel); first tier = 10 MFMAs per tile and 64 terms"
+        out["scan_int8_tops_first_tier"] = i8_tops
+        out["scan_frac_of_int8_matrix_peak_5000TOPS"] = i8_tops / I8_MFMA_PEAK_TOPS
+    elif m > 16:                     # run-time-m kernels; to 32 antennas the short form on the fp64 matrix core (n <= 2)
         sf = 2.0 * 4 * N_EMIT * m * res * batch / scan_s / 1e12 if scan_s > 0 else 0.0
         out["scan_form"] = "short form, 4*n*m FMA per (item, bin), scan_wide_mfma_kernel"
         out["scan_fp64_tflops"] = sf
@@ -292,13 +363,17 @@ def extra_cfg5(torch, np, capi, synth, dev, stream, nitems, seconds):
         stream.synchronize()
         st = [Mx.stage_ms(s)[0] for s in range(capi.NUM_STAGES)]
         Mx.profile(False)
+        stream.synchronize()
+        # the MUSIC stage of the chain on the items the front-end handed it (the front-end engines have their own parity tests)
+        verified = verify_against_oracle(torch, np, d_items, ang, lvl, spec, table, m, N_EMIT, N, res, 8)
     finally:
         for e in (R, A, Mx):
             e.set_stream(None)
             e.close()
     in_b, rs_b = m * L * 8, m * T_out * 8
     chain_bytes = in_b + rs_b + rs_b + nitems * N * 8 + nitems * N * 8 + nitems * (4 * res + 8 * N_EMIT)
-    return {"items_per_step": nitems, "ms_per_step": ms, "steps_timed": n, "snapshots_per_s": nitems / ms * 1e3,
+    return {**verified, "verified_stage": "music (on the front-end's output)",
+            "items_per_step": nitems, "ms_per_step": ms, "steps_timed": n, "snapshots_per_s": nitems / ms * 1e3,
             "complex_samples_per_s_per_antenna": T_out / ms * 1e3,
             "engine_ms": {"resampler": eng[0], "agc_interleave": eng[1], "music": eng[2]},
             "music_stage_ms": dict(zip(("cov", "evd", "scan", "merge"), st)),
@@ -334,7 +409,7 @@ def self_launch(n):
     import subprocess
     import torch
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if ndev < n and os.environ.get("BAZ_BENCH_SHARE_DEVICES") != "1":
+    if ndev < n and os.environ.get("BAZ_BENCH_SHARE_DEVICES") != "1" and "--dry-ranks" not in sys.argv:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (one process per GPU)" % (n, ndev))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -344,6 +419,72 @@ def self_launch(n):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
     raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dry_ranks_main(args):
+    """--dry-ranks: the launcher, the rank environment, the dealing of the streams, the barrier / max-over-ranks clock and the
+    gathered rank records of an N-rank run WITHOUT any GPU work -- a rehearsal of the SCALE day on a box that has no (or not
+    enough) GPUs (tests/test_sharding.py feeds it 8 ranks).  A step is a sleep of the time the ranks' items would take at
+    2.5e8 items/s; the barrier / clock ask for RCCL exactly like the real run, fall back to gloo where RCCL cannot initialise,
+    and the line says so.  "dry_run": true -- the value is NOT a measurement."""
+    from gr_baz_amd import sharding
+    rank, local_rank, world = sharding.dist_env()
+    if world != max(1, args.gpus):
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    strong = args.scaling == "strong"
+    if strong and STRONG_STREAMS % world:
+        raise SystemExit("--scaling strong deals %d streams: --gpus must divide it" % STRONG_STREAMS)
+    active = sharding.init_process_group(use_gpu=False, local_rank=local_rank, try_nccl=True)
+    n_streams = STRONG_STREAMS if strong else STREAMS_PER_GPU * world
+    mine = sharding.streams_of_rank(n_streams, world, rank)
+    batch = len(mine) * ITEMS_PER_STREAM
+    group_items = min(len(mine), STREAMS_PER_GPU) * ITEMS_PER_STREAM
+    n_groups = batch // group_items
+    step = lambda: time.sleep(batch / 2.5e8)
+    for _ in range(args.warmup):
+        step()
+    rounds, timed_total = [], 0.0
+    while True:
+        sharding.barrier(active, False)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        elapsed = time.perf_counter() - t0
+        sharding.barrier(active, False)
+        tmax = sharding.max_over_ranks(elapsed, active, False)
+        rounds.append(tmax)
+        timed_total += tmax
+        if timed_total >= args.min_seconds or len(rounds) >= 200:
+            break
+    t_med = statistics.median(rounds)
+    total_items = sharding.sum_over_ranks(float(batch * args.steps), active, False)
+    ranks = [{"rank": rank, "items_per_step": batch, "streams": mine, "device": "none (dry run)"}]
+    if active:
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ranks[0])
+        ranks = gathered
+    assert len(ranks) == world and sorted(r["rank"] for r in ranks) == list(range(world)), ranks
+    if rank == 0:
+        info = sharding.backend_info() if active else {"backend": None, "requested": None, "fell_back": False, "fallback_reason": None}
+        print(json.dumps({
+            "metric": "MUSIC-DoA snapshots/s (4 ant, 1024 samp, 3600 bins)", "dry_run": True,
+            "value": total_items / t_med, "unit": "snapshots/s (SIMULATED steps: launcher rehearsal, not a measurement)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_med / args.steps * 1e3,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "none",
+            "config": {"workload": "dry run of cfg2's dealing: %d streams x %d items per rank per step, no device work"
+                                   % (len(mine), ITEMS_PER_STREAM),
+                       "items_per_gpu_per_step": batch, "items_per_step_all_gpus": int(total_items / args.steps + 0.5),
+                       "streams_total": n_streams, "launch_sequences_per_step": n_groups, "items_per_launch_sequence": group_items,
+                       "parallelism": "independent streams, s mod %d, no collective" % world,
+                       "collective_backend_for_barrier_and_clock": info["backend"],
+                       "collective_backend_requested": info["requested"],
+                       "collective_backend_fell_back": info["fell_back"],
+                       "collective_backend_fallback_reason": info["fallback_reason"],
+                       "ranks": ranks}}), flush=True)
+    if active:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 def main():
@@ -357,10 +498,14 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary cfg2-no-spectrum / cfg3 / cfg5 measurements")
     ap.add_argument("--ramp-seconds", type=float, default=0.25, help="untimed steady load before warm-up (clock ramp)")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat the K-step timed region until this much timed work")
+    ap.add_argument("--dry-ranks", action="store_true",
+                    help="launcher rehearsal without GPU work: N ranks, the dealing, barrier / clock and rank records only")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         return self_launch(args.gpus)                        # plain `python bench.py --gpus N`: start the N ranks ourselves
+    if args.dry_ranks:
+        return dry_ranks_main(args)
 
     import numpy as np
     import torch
@@ -384,7 +529,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     active = sharding.init_process_group(use_gpu=True, local_rank=local_rank)
-    backend = sharding._BACKEND if active else None
+    binfo = sharding.backend_info() if active else {"backend": None, "requested": None, "fell_back": False, "fallback_reason": None}
+    backend = binfo["backend"]
 
     arr, table = helper_table(np, synth, M, RES)
 
@@ -461,14 +607,21 @@ def main():
     stage = [ctx.stage_ms(s) for s in range(capi.NUM_STAGES)]
     ctx.profile(False)
     cov_name = ctx.stage_name(capi.STAGE_COV)
+    scan_name = ctx.stage_name(capi.STAGE_SCAN)
     bpi = ctx.bytes_per_item(True)
+    # outside the timed region: what the last timed step left in the output buffers against the CPU oracle, then the cost of
+    # a retune (set_array_response) while batches are in flight
+    verified = verify_against_oracle(torch, np, x, ang, lvl, spec, table, M, N_EMIT, NSAMPLES, RES, 256)
+    retune_med, retune_max, retune_lock = time_retunes(np, synth, ctx, table, M, RES, arr, step, torch.cuda.synchronize, 5)
     ctx.set_stream(None)
     ctx.close()
 
     t_med = statistics.median(rounds)
     total_items = sharding.sum_over_ranks(float(batch * args.steps), active, True)
     value = total_items / t_med
-    ranks = [{"rank": rank, "items_per_step": batch, "streams": mine, "device": torch.cuda.get_device_name(local_rank)}]
+    ranks = [{"rank": rank, "items_per_step": batch, "streams": mine, "device": torch.cuda.get_device_name(local_rank),
+              "verified_items": verified["verified_items"], "verified_max_rel_err": verified["verified_max_rel_err"],
+              "verified_bins_identical": verified["verified_bins_identical"], "verified_ok": verified["verified_ok"]}]
     if active:
         import torch.distributed as dist
         gathered = [None] * world
@@ -524,15 +677,24 @@ def main():
                        "items_per_gpu_per_step": batch, "items_per_step_all_gpus": int(total_items / args.steps + 0.5),
                        "streams_total": n_streams, "launch_sequences_per_step": n_groups, "items_per_launch_sequence": group_items,
                        "parallelism": "independent streams, s mod %d, no collective" % world,
-                       "collective_backend_for_barrier_and_clock": backend, "ranks": ranks,
+                       "collective_backend_for_barrier_and_clock": backend,
+                       "collective_backend_requested": binfo["requested"], "collective_backend_fell_back": binfo["fell_back"],
+                       "collective_backend_fallback_reason": binfo["fallback_reason"], "ranks": ranks,
                        "algorithmic_bytes_per_item": bpi,
+                       # every rank checked a sample of what its last timed step wrote against the CPU oracle (outside the timed region)
+                       "verified_items": sum(r["verified_items"] for r in ranks),
+                       "verified_max_rel_err": max(r["verified_max_rel_err"] for r in ranks),
+                       "verified_bins_identical": all(r["verified_bins_identical"] for r in ranks),
+                       "verified_ok": all(r["verified_ok"] for r in ranks),
+                       "verified_tolerance": VERIFY_TOL, "verified_against": verified["verified_against"],
+                       "retune_ms": retune_med, "retune_ms_worst": retune_max, "retune_lock_ms_worst": retune_lock,
                        "pipeline_hbm_fraction_of_8TBs": value / world * bpi / 8e12,
                        "stage_ms_per_launch_separate_pass": {nm: stage[s][0] / max(stage[s][1], 1)
                                                for s, nm in enumerate(("cov (+ evd when fused)", "evd_proj", "scan_mfma", "topn_merge"))},
                        # the one dense contraction (north_star): useful fp64 flops 8*m*N per item against the fp64
                        # matrix peak; rocprofv3 MFMA-busy for the same kernel is in profiles/r04_bench_pmc_summary.txt
                        "covariance_mfma": cov_mfma},
-            "roofline": {"bound": "hbm", "kernel": "scan_mfma_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": scan_name.split("::")[-1].split("<")[0], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_stale": traffic_stale, "traffic_profile": traffic_src,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_avg_s * 1e3,
@@ -603,6 +765,13 @@ def main():
             cfgd["incoherent_snr60_snapshots_per_s"] = pick("cfg2_incoherent_snr60", "snapshots_per_s")
             cfgd["incoherent_snr60_default_wiring_snapshots_per_s"] = pick("cfg2_incoherent_snr60_without_spectrum_port", "snapshots_per_s")
             cfgd["cfg3_snapshots_per_s"] = pick("cfg3", "snapshots_per_s")
+            cfgd["cfg3_verified_items"] = pick("cfg3", "verified_items")
+            cfgd["cfg3_verified_max_rel_err"] = pick("cfg3", "verified_max_rel_err")
+            cfgd["cfg3_verified_bins_identical"] = pick("cfg3", "verified_bins_identical")
+            cfgd["cfg3_retune_ms"] = pick("cfg3", "retune_ms")
+            cfgd["cfg3_scan_int8_tops_first_tier"] = pick("cfg3", "scan_int8_tops_first_tier")
+            cfgd["cfg3_scan_frac_of_int8_matrix_peak"] = pick("cfg3", "scan_frac_of_int8_matrix_peak_5000TOPS")
+            cfgd["extras_all_verified_ok"] = all(v.get("verified_ok", True) for v in extra.values() if isinstance(v, dict))
             cfgd["cfg3_scan_ms"] = pick("cfg3", "stage_ms_per_launch", "scan")
             cfgd["cfg3_scan_frac_of_hbm_8TBs"] = pick("cfg3", "scan_frac_of_hbm_8TBs")
             cfgd["cfg3_pipeline_hbm_frac"] = pick("cfg3", "pipeline_hbm_fraction_of_8TBs")
@@ -615,9 +784,14 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(table)
         print(json.dumps(line), flush=True)
+        failed = not line["config"]["verified_ok"] or not line["config"].get("extras_all_verified_ok", True)
+    else:
+        failed = False
     if active:
         import torch.distributed as dist
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit("bench.py: the timed outputs do NOT agree with the CPU oracle within %g (see verified_* in the line)" % VERIFY_TOL)
 
 
 if __name__ == "__main__":

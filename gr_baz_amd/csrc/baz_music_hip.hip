@@ -173,6 +173,7 @@ struct baz_music_ctx {
     int single_limit_mib = 64;                           // page-locked calls below this much traffic run as ONE chunk (BAZ_MUSIC_SINGLE_MIB)
     StageProf prof[BAZ_MUSIC_NUM_STAGES];
     std::string stage_name[BAZ_MUSIC_NUM_STAGES];
+    int scan_kind = -1;     // the scan kernel the LAST launch took: 0 scan_mfma_kernel, 1 scan_i8_kernel, 2 scan_coarse_kernel (-1: none yet)
     char hip_err[256] = {0};
 };
 
@@ -739,6 +740,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
 #undef BAZ_COARSE_ARGS
             HIP_TRY(c, hipGetLastError());
             c->last_nsplit = CG.nsplit;
+            c->scan_kind = 2;
             return BAZ_MUSIC_OK;
         }
     }
@@ -828,9 +830,11 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             else BAZ_I8_LAUNCH(false, false);
 #undef BAZ_I8_LAUNCH
             HIP_TRY(c, hipGetLastError());
+            c->scan_kind = 1;
             return BAZ_MUSIC_OK;
         }
     }
+    c->scan_kind = 0;
     ScanRefine rf;
     rf.Gs = c->refine_off ? nullptr : c->dG;
     rf.TB = c->dTB + c->tb_step_elems;
@@ -2135,6 +2139,15 @@ int baz_music_stage_ms(baz_music_ctx* c, int stage, double* total_ms, uint64_t* 
 const char* baz_music_stage_name(baz_music_ctx* c, int stage)
 {
     if (!c || stage < 0 || stage >= BAZ_MUSIC_NUM_STAGES) return "";
+    if (stage == BAZ_MUSIC_STAGE_SCAN && !c->wide) {
+        // the kernel the LAST scan launch took (it depends on the wiring of the call and on the table in force: ADVICE r4);
+        // before the first launch: what a call with the spectrum port would take
+        std::lock_guard<std::mutex> lk(c->mtx);
+        const int kind = c->scan_kind >= 0 ? c->scan_kind : (i8_active(c) ? 1 : 0);
+        char buf[128];
+        snprintf(buf, sizeof(buf), kind == 1 ? "bazmusic::scan_i8_kernel<%u," : (kind == 2 ? "bazmusic::scan_coarse_kernel<%u," : "bazmusic::scan_mfma_kernel<%u,"), c->m);
+        c->stage_name[stage] = buf;
+    }
     return c->stage_name[stage].c_str();
 }
 

@@ -134,6 +134,7 @@ int64_t process_device_locked(baz_resamp_ctx* c, const void* d_in, uint64_t in_s
                               uint64_t out_stride, uint32_t noutput, uint64_t* consumed)
 {
     if (consumed) *consumed = 0;
+    c->stopped_at_bad = false;       // the one-input path changes the state: a later two-input call is a first call again
     if (noutput == 0) return 0;
     // .cc:165-170: a pending mu applies to the first output; .cc:175-181: a pending ratio from the first step on;
     // .cc:184-189: the adjustment is added to the first step
@@ -377,6 +378,7 @@ int baz_resamp_set_mu(baz_resamp_ctx* c, double mu)
     std::lock_guard<std::mutex> lk(c->mtx);
     c->mu_update = to_fixed((long double)mu, &c->exact);
     c->update_mu = true;
+    c->stopped_at_bad = false;       // a state change: the next two-input call delivers its output
     return BAZ_RESAMP_OK;
 }
 
@@ -387,6 +389,7 @@ static int set_ratio_ld(baz_resamp_ctx* c, long double r)
     std::lock_guard<std::mutex> lk(c->mtx);
     c->mu_inc_update = to_fixed(r, &c->exact);
     c->update = true;
+    c->stopped_at_bad = false;
     return BAZ_RESAMP_OK;
 }
 
@@ -411,6 +414,7 @@ int baz_resamp_adjust(baz_resamp_ctx* c, double d)
     std::lock_guard<std::mutex> lk(c->mtx);
     c->mu_adj = to_fixed_signed((long double)d * from_fixed(c->mu_inc), &c->exact);      // .cc:132
     c->update_mu_adj = true;
+    c->stopped_at_bad = false;
     return BAZ_RESAMP_OK;
 }
 
@@ -433,6 +437,7 @@ int baz_resamp_set_taps(baz_resamp_ctx* c, const float* taps)
     DeviceGuard guard(c->device);
     RS_TRY(hipStreamSynchronize(c->stream));        // no launch in flight reads the old table
     std::memcpy(c->taps, taps, sizeof(c->taps));
+    c->stopped_at_bad = false;
     RS_TRY(hipMemcpy(c->d_taps, c->taps, sizeof(c->taps), hipMemcpyHostToDevice));
     return BAZ_RESAMP_OK;
 }

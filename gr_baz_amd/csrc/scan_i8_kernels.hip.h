@@ -451,9 +451,12 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
                     // Five-digit values at or below T: two more digits of both operands (levels 5 and 6 on top of the accumulated
                     // ones: 13 NKB MFMAs) and the low byte of the level-4 sum; digits 5, 6 of q from this lane's LDS slot, of F
                     // from the image in L2.
+                    // (rows without digits and bins outside the table have V = 0: they are replaced below -- exact16 / a huge d -- and
+                    // must not send the wave through the 13 MFMAs, nor count as refined tiles: ADVICE r4)
                     bool lowt = false;
+                    const bool in_table = bin + t < res;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) lowt |= !form4[r] && !(fabs(d[r]) > tacc_d);
+                    for (int r = 0; r < 4; ++r) lowt |= (VAL || (sane_r[r] && in_table)) && !form4[r] && !(fabs(d[r]) > tacc_d);
                     if (VAL || __any(lowt)) {
                         ++fell;
                         v4i32 L5 = {0, 0, 0, 0}, L6 = {0, 0, 0, 0};
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
                         }
                     }
                     // bins outside the table (last step of a row): zero digits gave d = 0; they must never be selected
-                    const bool inside = bin + t < res;
+                    const bool inside = in_table;
                     if (tail_step) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) d[r] = inside ? d[r] : 1e300;

@@ -26,8 +26,12 @@ def dist_env():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_process_group(use_gpu: bool, local_rank: int = 0):
-    """Initialises torch.distributed when WORLD_SIZE > 1.  Returns True if a group is active."""
+def init_process_group(use_gpu: bool, local_rank: int = 0, try_nccl: bool = False):
+    """Initialises torch.distributed when WORLD_SIZE > 1.  Returns True if a group is active.
+    The backend asked for is "nccl" (= RCCL) on a GPU run -- or wherever try_nccl says so (bench.py --dry-ranks: the launcher
+    rehearsal on a box without GPUs, which must go through the same fall-back) -- unless BAZ_BENCH_BACKEND names another.  When
+    RCCL cannot initialise, the barrier / clock fall back to gloo LOUDLY: on stderr and in backend_info(), which bench.py prints
+    into its JSON line (collective_backend_*): a fall-back must never pass for an RCCL run."""
     import torch.distributed as dist
     rank, _, world = dist_env()
     if world <= 1:
@@ -35,13 +39,14 @@ def init_process_group(use_gpu: bool, local_rank: int = 0):
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        global _BACKEND
+        global _BACKEND, _REQUESTED, _FALLBACK_REASON
         backend = "gloo"
         if use_gpu:
             import torch
             torch.cuda.set_device(local_rank)
-            if os.environ.get("BAZ_BENCH_BACKEND", "nccl") == "nccl":
-                backend = "nccl"      # = RCCL on ROCm; used for the barrier / clock only
+        if (use_gpu or try_nccl) and os.environ.get("BAZ_BENCH_BACKEND", "nccl") == "nccl":
+            backend = "nccl"          # = RCCL on ROCm; used for the barrier / clock only
+        _REQUESTED = backend
         if backend == "nccl":
             import torch
             try:
@@ -50,11 +55,17 @@ def init_process_group(use_gpu: bool, local_rank: int = 0):
                 dist.barrier(device_ids=[local_rank])          # first collective: creates the RCCL communicator
             except Exception as e:   # RCCL unusable on this box: the data path needs no collective anyway
                 import sys
-                print("[gr_baz_amd.sharding] RCCL init failed (%s); using gloo for the barrier/clock" % e,
+                _FALLBACK_REASON = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+                print("[gr_baz_amd.sharding] RCCL init FAILED (%s); using gloo for the barrier/clock" % _FALLBACK_REASON,
                       file=sys.stderr, flush=True)
                 if dist.is_initialized():
                     dist.destroy_process_group()
-                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29511")) + 1)
+                # Under torch.distributed.run the AGENT hosts the rendezvous store on MASTER_PORT and the ranks are its clients:
+                # the gloo group is set up through the same store (found by bench.py --dry-ranks: a new port has no server
+                # behind it and every rank waits forever).  Without an agent rank 0 hosted the store itself and the failed
+                # attempt may still hold the port: move on by one.
+                if os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() != "true":
+                    os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29511")) + 1)
                 backend = "gloo"
                 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
@@ -64,6 +75,13 @@ def init_process_group(use_gpu: bool, local_rank: int = 0):
 
 
 _BACKEND = "gloo"
+_REQUESTED = "gloo"
+_FALLBACK_REASON = None
+
+
+def backend_info():
+    """What the barrier / clock actually run on: {"backend", "requested", "fell_back", "fallback_reason"}."""
+    return {"backend": _BACKEND, "requested": _REQUESTED, "fell_back": _BACKEND != _REQUESTED, "fallback_reason": _FALLBACK_REASON}
 
 
 def _on_gpu(use_gpu: bool) -> bool:

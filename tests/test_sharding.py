@@ -74,3 +74,35 @@ def test_world_size_2_gloo():
     assert tot0 == tot1 == 1600.0          # items of ALL ranks
     assert t0 == t1 == 2.0                 # max over ranks
     assert rate0 == rate1 == 800.0         # whole-job throughput
+
+
+def test_launcher_rehearsal_eight_dry_ranks():
+    """The SCALE day without GPUs (task 7): `python bench.py --gpus 8 --scaling strong --dry-ranks` starts its own
+    eight ranks under torch.distributed.run exactly like the real run, deals BASELINE configs[3]'s 64 streams s mod 8, asks for
+    RCCL for the barrier / clock, cannot have it here, falls back to gloo -- and the line must SAY so.  (This rehearsal found
+    that the fall-back used to pick a new rendezvous port, which under the launcher's agent store has no server behind it:
+    every rank waited forever.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BAZ_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--scaling", "strong", "--dry-ranks",
+                        "--steps", "2", "--warmup", "1", "--min-seconds", "0.05"], capture_output=True, text=True, timeout=420,
+                       cwd=root, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-2000:]
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["dry_run"] is True and d["n_gpus"] == 8 and d["scaling"] == "strong"
+    ranks = c["ranks"]
+    assert [x["rank"] for x in ranks] == list(range(8))
+    assert all(x["streams"] == list(range(x["rank"], 64, 8)) for x in ranks)                 # s mod 8: disjoint and complete
+    assert sorted(s for x in ranks for s in x["streams"]) == list(range(64))
+    assert all(x["items_per_step"] == 8 * 32768 for x in ranks) and c["items_per_step_all_gpus"] == 64 * 32768
+    # the fall-back is named: asked for RCCL, runs on gloo, with the reason
+    assert c["collective_backend_requested"] == "nccl" and c["collective_backend_for_barrier_and_clock"] == "gloo"
+    assert c["collective_backend_fell_back"] is True and c["collective_backend_fallback_reason"]
+    assert "RCCL init FAILED" in r.stderr
