@@ -376,7 +376,7 @@ def debug_i8_image(m, resolution, table):
                  "ns": int(par[11]), "nd": int(par[12]), "e4_bound": par[13], "t4": par[14]}
 
 
-TABLE_IMAGES = {0: "FB", 1: "TB", 2: "coarse", 3: "i8", 4: "a2p", 5: "TA", 6: "a2", 7: "params"}
+TABLE_IMAGES = {0: "FB", 1: "TB", 2: "coarse", 3: "i8", 4: "a2p", 5: "TA", 6: "a2", 7: "params", 8: "i8 packed (m <= 4)"}
 
 
 def debug_host_table_image(m, n, resolution, table, which, lab=False):

@@ -9,6 +9,7 @@
 #include "music_wide_kernels.hip.h"
 #include "scan_coarse_kernels.hip.h"
 #include "scan_i8_kernels.hip.h"
+#include "scan_i8p_kernels.hip.h"
 #include "table_kernels.hip.h"
 
 #include <algorithm>
@@ -89,6 +90,7 @@ struct baz_music_ctx {
     struct TableSet {
         double2* dFB = nullptr; double2* dTB = nullptr; uint4* dCS = nullptr; uint4* dIB = nullptr; double* dA2p = nullptr;
         float2* dTA = nullptr; double* dA2 = nullptr;
+        uint4* dIP = nullptr;            // level-packed int8 operands (m <= 4; shares i8 / i8_ok with dIB: a configuration has one of the two)
         CoarseParams cs = {0.0f, 0.0f, 0.0, 0.0, 1};
         I8Params i8 = {};
         bool cs_ok = false, i8_ok = false;
@@ -150,6 +152,8 @@ struct baz_music_ctx {
     unsigned long long* dMargin = nullptr;   // baz_music_debug_coarse_margin: worst error / allowance (float bits << 32 | where)
     // int8-matrix-core scan (scan_i8_kernels.hip.h): 6 <= m <= 16, n <= 4
     uint4* dIB = nullptr;          // digit image of the table (build_i8_image)
+    uint4* dIP = nullptr;          // level-packed digit operands, 2 .. 4 antennas (build_i8p_kernel); parameters in `i8` as well
+    int i8p_on = 1;                // lab (BAZ_MUSIC_I8P=0): m <= 4 keeps the fp64 scan with the spectrum port (also BAZ_MUSIC_EXACT=1)
     I8Params i8 = {};
     bool i8_ok = false;            // image built (finite table, scale representable, size within I8_IMAGE_LIMIT)
     int i8_on = 1;                 // BAZ_MUSIC_EXACT=1: every value on the fp64 matrix core (A/B; the round-3 scan)
@@ -173,7 +177,7 @@ struct baz_music_ctx {
     int single_limit_mib = 64;                           // page-locked calls below this much traffic run as ONE chunk (BAZ_MUSIC_SINGLE_MIB)
     StageProf prof[BAZ_MUSIC_NUM_STAGES];
     std::string stage_name[BAZ_MUSIC_NUM_STAGES];
-    int scan_kind = -1;     // the scan kernel the LAST launch took: 0 scan_mfma_kernel, 1 scan_i8_kernel, 2 scan_coarse_kernel (-1: none yet)
+    int scan_kind = -1;     // the scan kernel the LAST launch took: 0 scan_mfma_kernel, 1 scan_i8_kernel, 2 scan_coarse_kernel, 3 scan_i8p_kernel (-1: none yet)
     char hip_err[256] = {0};
 };
 
@@ -438,12 +442,54 @@ bool build_i8_image(const std::vector<double>& F, uint32_t m, uint32_t res, uint
     return true;
 }
 
+// Level-packed digit operands for 2 .. 4 antennas (scan_i8p_kernels.hip.h), host checker of baztab::build_i8p_kernel:
+//     B [((st + 1) * 4 + t) * 64 + 16 s + c][j]  = digit s (0 .. 3) of Fi[bin = 64 st + 4 c + t][e = j]       (16 bytes per entry)
+//     B'[ ...                     16 s + c][j]  = digit 4 + s (s = 0 .. 2), slot 3 zero;  B' follows B (i8p_operand_units each)
+bool build_i8p_image(const std::vector<double>& F, uint32_t m, uint32_t res, uint32_t steps, std::vector<uint8_t>& img, I8Params& ip)
+{
+    const uint32_t mm = m * m;
+    constexpr int ND = I8_ND;
+    double fmax = 0.0;
+    for (double v : F) {
+        if (!std::isfinite(v)) return false;
+        fmax = std::max(fmax, std::fabs(v));
+    }
+    double sf = 0.0;
+    if (!i8_params_from(fmax, m, ip, sf)) return false;
+    img.assign(i8p_image_bytes(steps), 0);
+    uint8_t* img2 = img.data() + i8p_operand_units(steps) * 16;
+    for (uint32_t bin = 0; bin < res; ++bin) {
+        const uint32_t st = bin >> 6, w = bin & 63u, c = w >> 2, t = w & 3u;
+        for (uint32_t e = 0; e < mm; ++e) {
+            long long v = std::llrint(F[(size_t)bin * mm + e] * sf);
+            const size_t unit = ((size_t)(st + 1) * 4 + t) * 64 + c;
+            int dgs[ND];
+            for (int s = ND - 1; s >= 1; --s) {
+                const long long h = (v + 128) >> 8;
+                dgs[s] = (int)((v - h * 256) & 255);
+                v = h;
+            }
+            dgs[0] = (int)(v & 255);
+            for (int s = 0; s < ND; ++s) {
+                uint8_t* base = (s < 4) ? img.data() + (unit + (size_t)s * 16) * 16 : img2 + (unit + (size_t)(s - 4) * 16) * 16;
+                base[e] = (uint8_t)dgs[s];
+            }
+        }
+    }
+    return true;
+}
+
 // the scan's short form (scan_mfma_kernel, SIG) needs fewer MFMAs than the projector GEMM
 bool short_form_applies(uint32_t m, uint32_t n) { return (n == 2 && m >= 9 && m <= 16) || (n == 1 && m >= 6 && m <= 16); }
 // The int8-matrix-core scan applies: 6 .. 16 antennas (row classes below, run-time-m kernels above), lists of <= 4 keys.
 bool i8_active(const baz_music_ctx* c)
 {
     return c->i8_on && c->i8_ok && c->dIB && c->m >= 6 && c->m <= 16 && c->n <= 4 && !c->lab_variant;
+}
+// ... and its level-packed form for 2 .. 4 antennas (scan_i8p_kernels.hip.h), with the spectrum port
+bool i8p_active(const baz_music_ctx* c)
+{
+    return c->i8_on && c->i8p_on && c->i8_ok && c->dIP && c->m <= 4 && c->n <= 4 && !c->lab_variant;
 }
 bool short_form_in_use(const baz_music_ctx* c)
 {
@@ -750,6 +796,40 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
     if ((size_t)batch * G.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;   // reserve_candidates() sized it
     const bool spec = d_spec != nullptr;
     const bool vec4 = (c->res % 4u) == 0 && (reinterpret_cast<uintptr_t>(d_spec) % 16u) == 0;
+    if constexpr (M <= 4 && NMAX <= 4) {
+        // 2 .. 4 antennas with the spectrum port: the int8 matrix core with level-packed operands (scan_i8p_kernels.hip.h); same
+        // geometry (row classes, bin ranges) and candidate lists as the fp64 scan below.  Without the port the coarse-gated scan above.
+        if (spec && i8p_active(c) && dQ == c->dQ) {
+            ScanRefine rf;
+            rf.Gs = c->refine_off ? nullptr : c->dG;
+            rf.TB = c->dTB + c->tb_step_elems;
+            rf.below = c->refine_below;
+            rf.count = c->refine_nocount ? nullptr : c->dRefined + c->stat_parity;
+            rf.A2 = nullptr;
+            const uint4* p1 = c->dIP + I8P_STEP_UNITS;                            // step 0 (a padded step lies in front)
+            const uint4* p2 = p1 + i8p_operand_units(c->fb_steps);
+#define BAZ_I8P_ARGS dim3(G.blocks), dim3(256), 0, c->stream, dQ, p1, p2, c->dFB + c->fb_step_elems, d_spec, cand, batch, c->res, qstride, \
+                     G.nsplit, c->nclass, G.rows_per_class, c->keep_mask, c->n, rf, c->i8, c->dI8Stat, nullptr
+#ifdef BAZ_MUSIC_LAB
+            if constexpr (M == 4 && NMAX == 2) {       // lab: timing ablations (wrong results)
+                if (vec4 && c->i8_abl) {
+                    if (c->i8_abl == 1) hipLaunchKernelGGL((scan_i8p_kernel<M, NMAX, true, true, false, 1>), BAZ_I8P_ARGS);
+                    else if (c->i8_abl == 2) hipLaunchKernelGGL((scan_i8p_kernel<M, NMAX, true, true, false, 2>), BAZ_I8P_ARGS);
+                    else hipLaunchKernelGGL((scan_i8p_kernel<M, NMAX, true, true, false, 3>), BAZ_I8P_ARGS);
+                    HIP_TRY(c, hipGetLastError());
+                    c->scan_kind = 3;
+                    return BAZ_MUSIC_OK;
+                }
+            }
+#endif
+            if (vec4) hipLaunchKernelGGL((scan_i8p_kernel<M, NMAX, true, true>), BAZ_I8P_ARGS);
+            else hipLaunchKernelGGL((scan_i8p_kernel<M, NMAX, true, false>), BAZ_I8P_ARGS);
+#undef BAZ_I8P_ARGS
+            HIP_TRY(c, hipGetLastError());
+            c->scan_kind = 3;
+            return BAZ_MUSIC_OK;
+        }
+    }
     if constexpr (M >= 6 && NMAX <= 4) {
         // the bulk of the values on the int8 matrix core, exactly accumulated; steps with a value under the accuracy
         // threshold in this kernel's own fp64 form (scan_i8_kernels.hip.h).  Same launch geometry (nclass = 1 from m = 6 on).
@@ -1203,6 +1283,7 @@ int alloc_table_set(baz_music_ctx* c, TableSet& T)
     if (hipMalloc((void**)&T.dTB, pad_steps * c->tb_step_elems * sizeof(double2)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     if (c->m <= 8 && hipMalloc((void**)&T.dCS, coarse_image_bytes(c)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     if (wants_i8_image(c) && hipMalloc((void**)&T.dIB, i8_image_bytes(c->m, c->fb_steps)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (c->m <= 4 && c->n <= 4 && hipMalloc((void**)&T.dIP, i8p_image_bytes(c->fb_steps)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     if (short_form_applies(c->m, c->n) && hipMalloc((void**)&T.dA2p, pad_steps * 64 * sizeof(double)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     return BAZ_MUSIC_OK;
 }
@@ -1213,6 +1294,7 @@ void free_table_set(TableSet& T)
     if (T.dTB) (void)hipFree(T.dTB);
     if (T.dCS) (void)hipFree(T.dCS);
     if (T.dIB) (void)hipFree(T.dIB);
+    if (T.dIP) (void)hipFree(T.dIP);
     if (T.dA2p) (void)hipFree(T.dA2p);
     if (T.dTA) (void)hipFree(T.dTA);
     if (T.dA2) (void)hipFree(T.dA2);
@@ -1224,12 +1306,14 @@ TableSet active_table_set(const baz_music_ctx* c)
 {
     TableSet T;
     T.dFB = c->dFB; T.dTB = c->dTB; T.dCS = c->dCS; T.dIB = c->dIB; T.dA2p = c->dA2p; T.dTA = c->dTA; T.dA2 = c->dA2;
+    T.dIP = c->dIP;
     T.cs = c->cs; T.i8 = c->i8; T.cs_ok = c->cs_ok; T.i8_ok = c->i8_ok; T.refine_below = c->refine_below;
     return T;
 }
 void install_table_set(baz_music_ctx* c, const TableSet& T)
 {
     c->dFB = T.dFB; c->dTB = T.dTB; c->dCS = T.dCS; c->dIB = T.dIB; c->dA2p = T.dA2p; c->dTA = T.dTA; c->dA2 = T.dA2;
+    c->dIP = T.dIP;
     c->cs = T.cs; c->i8 = T.i8; c->cs_ok = T.cs_ok; c->i8_ok = T.i8_ok; c->refine_below = T.refine_below;
 }
 
@@ -1297,6 +1381,15 @@ int build_tables_device(baz_music_ctx* c, TableSet& T)
                                c->dRaw, m, res, c->cs_tiles, X0);
             HIP_TRY(c, hipGetLastError());
             T.cs_ok = true;
+        }
+    }
+    if (T.dIP) HIP_TRY(c, hipMemsetAsync(T.dIP, 0, i8p_image_bytes(steps), s));
+    if (T.dIP && finite) {    // 2 .. 4 antennas: level-packed digit operands
+        double sf = 0.0;
+        if (i8_params_from(fmax, m, T.i8, sf)) {
+            hipLaunchKernelGGL(baztab::build_i8p_kernel, grid_for(res), dim3(256), 0, s, c->dRaw, m, res, steps, sf, T.dIP);
+            HIP_TRY(c, hipGetLastError());
+            T.i8_ok = true;
         }
     }
     if (T.dIB && finite) {    // int8-matrix-core scan: the table's digit image
@@ -1756,7 +1849,8 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         }
         if (const char* v = getenv("BAZ_MUSIC_EXACT")) c->i8_on = atoi(v) ? 0 : 1;                // A/B: 1 = the fp64 scan everywhere
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8_ABL")) c->i8_abl = atoi(v);                  // lab
-        if (wants_i8_image(c)) {
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8P")) c->i8p_on = atoi(v) ? 1 : 0;             // lab A/B: 0 = fp64 scan at m <= 4
+        if (wants_i8_image(c) || (m <= 4 && n <= 4)) {
             if (hipMalloc((void**)&c->dI8Stat, 8 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMemset(c->dI8Stat, 0, 8 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         }
@@ -2143,9 +2237,9 @@ const char* baz_music_stage_name(baz_music_ctx* c, int stage)
         // the kernel the LAST scan launch took (it depends on the wiring of the call and on the table in force: ADVICE r4);
         // before the first launch: what a call with the spectrum port would take
         std::lock_guard<std::mutex> lk(c->mtx);
-        const int kind = c->scan_kind >= 0 ? c->scan_kind : (i8_active(c) ? 1 : 0);
+        const int kind = c->scan_kind >= 0 ? c->scan_kind : (i8_active(c) ? 1 : (i8p_active(c) ? 3 : 0));
         char buf[128];
-        snprintf(buf, sizeof(buf), kind == 1 ? "bazmusic::scan_i8_kernel<%u," : (kind == 2 ? "bazmusic::scan_coarse_kernel<%u," : "bazmusic::scan_mfma_kernel<%u,"), c->m);
+        snprintf(buf, sizeof(buf), kind == 1 ? "bazmusic::scan_i8_kernel<%u," : (kind == 2 ? "bazmusic::scan_coarse_kernel<%u," : (kind == 3 ? "bazmusic::scan_i8p_kernel<%u," : "bazmusic::scan_mfma_kernel<%u,")), c->m);
         c->stage_name[stage] = buf;
     }
     return c->stage_name[stage].c_str();
@@ -2265,6 +2359,47 @@ int baz_music_debug_i8_margin(baz_music_ctx* c, const void* d_in, uint32_t batch
     if (!c || !d_in || !worst || batch == 0) return BAZ_MUSIC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
+    if (!c->wide && c->m <= 4 && c->m >= 2 && c->n <= 4 && c->dIP && c->i8_ok) {
+        // 2 .. 4 antennas: the level-packed form (scan_i8p_kernels.hip.h), VAL instantiation, one bin range per row
+        int r = ensure_workspace(c, batch);
+        if (r) return r;
+        r = reserve_candidates(c, batch);
+        if (r) return r;
+        const uint32_t qstride = baz_music_q_stride(batch);
+        if (c->fused_covevd) r = launch_covevd(c, static_cast<const float*>(d_in), batch, c->dQ, qstride, c->dG);
+        else {
+            r = launch_cov(c, static_cast<const float*>(d_in), batch, c->dR);
+            if (!r) r = launch_evd(c, c->dR, batch, c->dQ, qstride, c->dG);
+        }
+        if (r) return r;
+        HIP_TRY(c, hipMemsetAsync(c->dI8Stat + 2, 0, 3 * sizeof(unsigned long long), c->stream));
+        ScanRefine rf;
+        rf.Gs = nullptr; rf.TB = c->dTB + c->tb_step_elems; rf.below = 0.0; rf.count = nullptr; rf.A2 = nullptr;
+        const ScanGeom G = scan_geometry(batch, c->fb_steps, c->nclass, 1, c->m);
+        const uint4* p1 = c->dIP + I8P_STEP_UNITS;
+        const uint4* p2 = p1 + i8p_operand_units(c->fb_steps);
+#define BAZ_VALP(MV)                                                                                                          \
+    case MV: hipLaunchKernelGGL((scan_i8p_kernel<MV, 2, false, false, true>), dim3(G.blocks), dim3(256), 0, c->stream, c->dQ, p1, p2, \
+                                c->dFB + c->fb_step_elems, nullptr, c->dCand, batch, c->res, qstride, 1u, c->nclass, G.rows_per_class, \
+                                c->keep_mask, c->n, rf, c->i8, nullptr, c->dI8Stat + 2); break;
+        switch (c->m) {
+#ifndef BAZ_MUSIC_QUICK
+            BAZ_VALP(2) BAZ_VALP(3)
+#endif
+            BAZ_VALP(4)
+            default: return BAZ_MUSIC_E_UNSUPPORTED;
+        }
+#undef BAZ_VALP
+        HIP_TRY(c, hipGetLastError());
+        unsigned long long packed[3] = {0, 0, 0};
+        HIP_TRY(c, hipMemcpyAsync(packed, c->dI8Stat + 2, sizeof(packed), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k < 3; ++k) {
+            const unsigned int bits = (unsigned int)packed[k];
+            std::memcpy(worst + k, &bits, sizeof(float));
+        }
+        return BAZ_MUSIC_OK;
+    }
     if (c->wide || !c->dIB || !c->i8_ok || c->m < 6 || c->m > 16 || c->n > 4) return BAZ_MUSIC_E_UNSUPPORTED;
     int r = ensure_workspace(c, batch);
     if (r) return r;
@@ -2337,7 +2472,7 @@ extern "C" __attribute__((visibility("default"))) int baz_music_debug_i8_times(b
 
 // 1 when this context's scan runs on the int8 matrix core (6 <= m <= 16, n <= 4, a table whose digit image exists, not
 // BAZ_MUSIC_EXACT=1), else 0.
-int baz_music_uses_i8_scan(const baz_music_ctx* c) { return (c && !c->wide && i8_active(c)) ? 1 : 0; }
+int baz_music_uses_i8_scan(const baz_music_ctx* c) { return (c && !c->wide && (i8_active(c) || i8p_active(c))) ? 1 : 0; }
 
 // HOST-ONLY tap (no device needed): the bin ranges per item i8_nsplit() chooses for a launch of `batch` items over `nsteps`
 // 64-bin steps on a device with `slots` resident workgroups (CUs x workgroups per CU).
@@ -2405,9 +2540,10 @@ size_t baz_music_debug_table_image(baz_music_ctx* c, int which, void* out, size_
         case 4: src = c->dA2p; bytes = pad_steps * 64 * sizeof(double); break;
         case 5: src = c->dTA; bytes = (size_t)c->m * c->res * sizeof(float2); break;
         case 6: src = c->dA2; bytes = (size_t)c->res * sizeof(double); break;
+        case 8: src = c->dIP; bytes = c->dIP ? i8p_image_bytes(c->fb_steps) : 0; break;
         case 7: {
             double p[TABLE_NPARAMS];
-            pack_table_params(active_table_set(c), c->dCS != nullptr, c->dIB != nullptr, p);
+            pack_table_params(active_table_set(c), c->dCS != nullptr, c->dIB != nullptr || c->dIP != nullptr, p);
             if (out && out_bytes >= sizeof(p)) std::memcpy(out, p, sizeof(p));
             return sizeof(p);
         }
@@ -2415,7 +2551,7 @@ size_t baz_music_debug_table_image(baz_music_ctx* c, int which, void* out, size_
     }
     if (!src) return 0;
     // an image whose parameters could not be formed is not built (its bytes are whatever the buffer held): report it as absent
-    if ((which == 2 && !c->cs_ok) || (which == 3 && !c->i8_ok)) return 0;
+    if ((which == 2 && !c->cs_ok) || ((which == 3 || which == 8) && !c->i8_ok)) return 0;
     if (out && out_bytes >= bytes) {
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
             (void)hipGetLastError();
@@ -2447,10 +2583,11 @@ size_t baz_music_debug_host_table_image(uint32_t m, uint32_t n, uint32_t resolut
     };
     const bool has_cs = !wide && m <= 8;
     const bool has_i8 = !wide && m >= 6 && n <= 4 && i8_image_bytes(m, steps) <= I8_IMAGE_LIMIT;
+    const bool has_i8p = m <= 4 && n <= 4;
     const bool has_a2p = wide ? (n <= 8) : short_form_applies(m, n);
     const bool has_tb = wide ? (n <= 8) : true;
     std::vector<double> F;
-    if (!wide && (which == 0 || which == 2 || which == 3 || which == 7)) build_F(table_ri, m, res, F);
+    if (!wide && (which == 0 || which == 2 || which == 3 || which == 7 || which == 8)) build_F(table_ri, m, res, F);
     switch (which) {
         case 0: {
             if (wide) return 0;
@@ -2476,6 +2613,12 @@ size_t baz_music_debug_host_table_image(uint32_t m, uint32_t n, uint32_t resolut
             if (!has_i8) return 0;
             I8Params ip = {};
             if (!build_i8_image(F, m, res, steps, bytes, ip)) return 0;
+            break;
+        }
+        case 8: {
+            if (!has_i8p) return 0;
+            I8Params ip = {};
+            if (!build_i8p_image(F, m, res, steps, bytes, ip)) return 0;
             break;
         }
         case 4: {
@@ -2515,8 +2658,9 @@ size_t baz_music_debug_host_table_image(uint32_t m, uint32_t n, uint32_t resolut
             std::vector<uint8_t> scratch;
             if (has_cs) T.cs_ok = build_coarse_image(F, m, res, round_up((res + 15) / 16, 8), scratch, T.cs);
             if (has_i8) T.i8_ok = build_i8_image(F, m, res, steps, scratch, T.i8);
+            if (has_i8p) T.i8_ok = build_i8p_image(F, m, res, steps, scratch, T.i8);
             std::vector<double> p(TABLE_NPARAMS);
-            pack_table_params(T, has_cs, has_i8, p.data());
+            pack_table_params(T, has_cs, has_i8 || has_i8p, p.data());
             from_doubles(p);
             break;
         }

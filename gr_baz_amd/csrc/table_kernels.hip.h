@@ -18,7 +18,7 @@
 // gfx950 only.
 #pragma once
 
-#include "scan_i8_kernels.hip.h"      // (scan_coarse_kernels.hip.h, music_kernels.hip.h: layouts and their constexpr helpers)
+#include "scan_i8p_kernels.hip.h"     // (scan_i8_kernels.hip.h, scan_coarse_kernels.hip.h, music_kernels.hip.h: layouts and their constexpr helpers)
 
 namespace baztab {
 
@@ -281,6 +281,45 @@ __global__ __launch_bounds__(256) void build_i8_kernel(const float* __restrict__
         uint8_t* dst = (s >= NS) ? img2 + (tile * (ND - NS) + (size_t)(s - NS)) * 1024 + in_lane
                                  : img + (tile * NS + (size_t)s) * 1024 + in_lane;
         *reinterpret_cast<uint4*>(dst) = make_uint4(dig[s][0], dig[s][1], dig[s][2], dig[s][3]);
+    }
+}
+
+// Level-packed int8 operands for 2 .. 4 antennas (scan_i8p_kernels.hip.h): one thread per bin = 16 terms x 7 digits; digit s of the
+// terms goes to slot s of B (s <= 3) or slot s - 4 of B' (the image's second half), 16 B each.  Padded steps, bins outside the table,
+// terms e >= m^2 and B' slot 3 stay zero (the caller clears the image first).
+__global__ __launch_bounds__(256) void build_i8p_kernel(const float* __restrict__ tab, uint32_t m, uint32_t res, uint32_t steps, double sf,
+                                                        uint4* __restrict__ img)
+{
+    constexpr int ND = I8_ND;
+    const uint32_t mm = m * m;
+    const uint32_t bin = blockIdx.x * 256u + threadIdx.x;
+    if (bin >= res) return;
+    const uint32_t st = bin >> 6, w = bin & 63u, c = w >> 2, t = w & 3u;
+    const float* a = tab + (size_t)bin * m * 2;
+    uint32_t dig[ND][4];
+#pragma unroll
+    for (int s = 0; s < ND; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dig[s][q] = 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if ((uint32_t)j < mm) {
+            long long v = __double2ll_rn(tab_F(a, m, (uint32_t)j) * sf);
+#pragma unroll
+            for (int s = ND - 1; s >= 1; --s) {
+                const long long h = (v + 128) >> 8;                      // floor((v + 128) / 256)
+                dig[s][j >> 2] |= (uint32_t)((v - h * 256) & 255) << (8 * (j & 3));
+                v = h;
+            }
+            dig[0][j >> 2] |= (uint32_t)(v & 255) << (8 * (j & 3));
+        }
+    }
+    uint4* B1 = img + ((size_t)(st + 1) * 4 + t) * 64 + c;
+    uint4* B2 = B1 + i8p_operand_units(steps);
+#pragma unroll
+    for (int s = 0; s < ND; ++s) {
+        uint4* dst = (s < 4) ? B1 + s * 16 : B2 + (s - 4) * 16;
+        *dst = make_uint4(dig[s][0], dig[s][1], dig[s][2], dig[s][3]);
     }
 }
 
