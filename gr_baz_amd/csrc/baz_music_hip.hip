@@ -153,7 +153,9 @@ struct baz_music_ctx {
     // int8-matrix-core scan (scan_i8_kernels.hip.h): 6 <= m <= 16, n <= 4
     uint4* dIB = nullptr;          // digit image of the table (build_i8_image)
     uint4* dIP = nullptr;          // level-packed digit operands, 2 .. 4 antennas (build_i8p_kernel); parameters in `i8` as well
-    int i8p_on = 1;                // lab (BAZ_MUSIC_I8P=0): m <= 4 keeps the fp64 scan with the spectrum port (also BAZ_MUSIC_EXACT=1)
+    int i8p_on = 0;                // LAB builds only (BAZ_MUSIC_I8P=1): the level-packed int8 scan at m <= 4.  Measured and not shipped
+                                   // (profiles/r05_i8p_negative.txt): its arithmetic is 0.31 ms against the fp64 scan's 0.56, but the spectrum
+                                   // stores alone take what the fp64 scan takes (0.59 - 0.73 ms by box), and incoherent batches run 2.4 x slower
     I8Params i8 = {};
     bool i8_ok = false;            // image built (finite table, scale representable, size within I8_IMAGE_LIMIT)
     int i8_on = 1;                 // BAZ_MUSIC_EXACT=1: every value on the fp64 matrix core (A/B; the round-3 scan)
@@ -796,8 +798,9 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
     if ((size_t)batch * G.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;   // reserve_candidates() sized it
     const bool spec = d_spec != nullptr;
     const bool vec4 = (c->res % 4u) == 0 && (reinterpret_cast<uintptr_t>(d_spec) % 16u) == 0;
+#ifdef BAZ_MUSIC_LAB
     if constexpr (M <= 4 && NMAX <= 4) {
-        // 2 .. 4 antennas with the spectrum port: the int8 matrix core with level-packed operands (scan_i8p_kernels.hip.h); same
+        // LAB (BAZ_MUSIC_I8P=1): 2 .. 4 antennas with the spectrum port: the int8 matrix core with level-packed operands (scan_i8p_kernels.hip.h); same
         // geometry (row classes, bin ranges) and candidate lists as the fp64 scan below.  Without the port the coarse-gated scan above.
         if (spec && i8p_active(c) && dQ == c->dQ) {
             ScanRefine rf;
@@ -815,6 +818,8 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
                 if (vec4 && c->i8_abl) {
                     if (c->i8_abl == 1) hipLaunchKernelGGL((scan_i8p_kernel<M, NMAX, true, true, false, 1>), BAZ_I8P_ARGS);
                     else if (c->i8_abl == 2) hipLaunchKernelGGL((scan_i8p_kernel<M, NMAX, true, true, false, 2>), BAZ_I8P_ARGS);
+                    else if (c->i8_abl == 4) hipLaunchKernelGGL((scan_i8p_kernel<M, NMAX, true, true, false, 4>), BAZ_I8P_ARGS);
+                    else if (c->i8_abl == 5) hipLaunchKernelGGL((scan_i8p_kernel<M, NMAX, true, true, false, 5>), BAZ_I8P_ARGS);
                     else hipLaunchKernelGGL((scan_i8p_kernel<M, NMAX, true, true, false, 3>), BAZ_I8P_ARGS);
                     HIP_TRY(c, hipGetLastError());
                     c->scan_kind = 3;
@@ -830,6 +835,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             return BAZ_MUSIC_OK;
         }
     }
+#endif
     if constexpr (M >= 6 && NMAX <= 4) {
         // the bulk of the values on the int8 matrix core, exactly accumulated; steps with a value under the accuracy
         // threshold in this kernel's own fp64 form (scan_i8_kernels.hip.h).  Same launch geometry (nclass = 1 from m = 6 on).
@@ -1283,7 +1289,7 @@ int alloc_table_set(baz_music_ctx* c, TableSet& T)
     if (hipMalloc((void**)&T.dTB, pad_steps * c->tb_step_elems * sizeof(double2)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     if (c->m <= 8 && hipMalloc((void**)&T.dCS, coarse_image_bytes(c)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     if (wants_i8_image(c) && hipMalloc((void**)&T.dIB, i8_image_bytes(c->m, c->fb_steps)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
-    if (c->m <= 4 && c->n <= 4 && hipMalloc((void**)&T.dIP, i8p_image_bytes(c->fb_steps)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (c->i8p_on && c->m <= 4 && c->n <= 4 && hipMalloc((void**)&T.dIP, i8p_image_bytes(c->fb_steps)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     if (short_form_applies(c->m, c->n) && hipMalloc((void**)&T.dA2p, pad_steps * 64 * sizeof(double)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     return BAZ_MUSIC_OK;
 }
@@ -1710,7 +1716,9 @@ int create_tables(baz_music_ctx* c, const float* table_ri)
 {
     int lo = 0, hi = 0;
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
-    if (hipStreamCreateWithPriority(&c->s_tab, hipStreamNonBlocking, hi) != hipSuccess) return BAZ_MUSIC_E_HIP;
+    int prio = hi;
+    if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_TAB_PRIORITY")) prio = atoi(v) > 0 ? hi : (atoi(v) < 0 ? lo : 0);   // lab: 1 highest, 0 default, -1 lowest
+    if (hipStreamCreateWithPriority(&c->s_tab, hipStreamNonBlocking, prio) != hipSuccess) return BAZ_MUSIC_E_HIP;
     if (hipEventCreateWithFlags(&c->ev_swap, hipEventDisableTiming) != hipSuccess) return BAZ_MUSIC_E_HIP;
     const size_t raw_bytes = (size_t)c->res * c->m * 2 * sizeof(float);
     if (hipMalloc((void**)&c->dRaw, raw_bytes) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
@@ -1849,8 +1857,8 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         }
         if (const char* v = getenv("BAZ_MUSIC_EXACT")) c->i8_on = atoi(v) ? 0 : 1;                // A/B: 1 = the fp64 scan everywhere
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8_ABL")) c->i8_abl = atoi(v);                  // lab
-        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8P")) c->i8p_on = atoi(v) ? 1 : 0;             // lab A/B: 0 = fp64 scan at m <= 4
-        if (wants_i8_image(c) || (m <= 4 && n <= 4)) {
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8P")) c->i8p_on = atoi(v) ? 1 : 0;             // lab: 1 = the level-packed int8 scan at m <= 4
+        if (wants_i8_image(c) || (c->i8p_on && m <= 4 && n <= 4)) {
             if (hipMalloc((void**)&c->dI8Stat, 8 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMemset(c->dI8Stat, 0, 8 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         }
@@ -2359,6 +2367,7 @@ int baz_music_debug_i8_margin(baz_music_ctx* c, const void* d_in, uint32_t batch
     if (!c || !d_in || !worst || batch == 0) return BAZ_MUSIC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
+#ifdef BAZ_MUSIC_LAB
     if (!c->wide && c->m <= 4 && c->m >= 2 && c->n <= 4 && c->dIP && c->i8_ok) {
         // 2 .. 4 antennas: the level-packed form (scan_i8p_kernels.hip.h), VAL instantiation, one bin range per row
         int r = ensure_workspace(c, batch);
@@ -2400,6 +2409,7 @@ int baz_music_debug_i8_margin(baz_music_ctx* c, const void* d_in, uint32_t batch
         }
         return BAZ_MUSIC_OK;
     }
+#endif
     if (c->wide || !c->dIB || !c->i8_ok || c->m < 6 || c->m > 16 || c->n > 4) return BAZ_MUSIC_E_UNSUPPORTED;
     int r = ensure_workspace(c, batch);
     if (r) return r;
@@ -2658,9 +2668,9 @@ size_t baz_music_debug_host_table_image(uint32_t m, uint32_t n, uint32_t resolut
             std::vector<uint8_t> scratch;
             if (has_cs) T.cs_ok = build_coarse_image(F, m, res, round_up((res + 15) / 16, 8), scratch, T.cs);
             if (has_i8) T.i8_ok = build_i8_image(F, m, res, steps, scratch, T.i8);
-            if (has_i8p) T.i8_ok = build_i8p_image(F, m, res, steps, scratch, T.i8);
+            // (the packed operands of m <= 4 exist in lab contexts only -- BAZ_MUSIC_I8P=1 --: their parameters are not part of this image)
             std::vector<double> p(TABLE_NPARAMS);
-            pack_table_params(T, has_cs, has_i8 || has_i8p, p.data());
+            pack_table_params(T, has_cs, has_i8, p.data());
             from_doubles(p);
             break;
         }

@@ -59,7 +59,8 @@ __device__ __noinline__ v4f64 exact16s(const double* __restrict__ Qs, const doub
 
 // VAL: validation build (baz_music_debug_i8_margin): every tile runs every form and the fp64 form; margin[0 .. 2] = worst
 // |d5 - d| / E5, |d7 - d| / allowance, |d4 - d| / E4 over the rows that take the integer forms; outputs are the fp64 form's.
-// ABL (lab builds only; timing, results are wrong): 1 no spectrum stores, 2 no tile arithmetic (staging, barriers, stores of a constant).
+// ABL (lab builds only; timing, results are wrong): 1 no spectrum stores, 2 no tile arithmetic (staging, barriers, stores of a constant),
+// 4 the first pass alone (no tile is ever flagged).
 template <int M, int NMAX, bool SPEC, bool VEC4, bool VAL = false, int ABL = 0>
 __global__ __launch_bounds__(256, (NMAX <= 2 && !VAL) ? 4 : 2) void scan_i8p_kernel(
     const double* __restrict__ Qs, const uint4* __restrict__ P1, const uint4* __restrict__ P2, const double2* __restrict__ FB,
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256, (NMAX <= 2 && !VAL) ? 4 : 2) void scan_i8p_ker
     bool row_ok[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) row_ok[r] = (item0 + nclass * (uint32_t)(g + 4 * r)) < batch;
-    uint32_t refined = 0, fell = 0;
+    uint32_t refined = 0, fell = 0, nflag = 0;
     [[maybe_unused]] float worst5 = 0.0f, worst7 = 0.0f, worst4 = 0.0f;
 
     if (st_begin < st_end) stage_load(st_begin, 0);
@@ -228,6 +229,8 @@ __global__ __launch_bounds__(256, (NMAX <= 2 && !VAL) ? 4 : 2) void scan_i8p_ker
                 }
                 flagged |= under ? (1u << t) : 0u;
             }
+            if constexpr ((ABL & 4) != 0) flagged = 0u;                    // lab: the first pass alone
+            nflag += (uint32_t)__builtin_popcount(flagged);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) sv[r] = (v4f32){1.0f, 2.0f, 3.0f, (float)st};
@@ -404,6 +407,7 @@ __global__ __launch_bounds__(256, (NMAX <= 2 && !VAL) ? 4 : 2) void scan_i8p_ker
     if (stat && lane == 0) {
         if (fell) atomicAdd(stat, (unsigned long long)fell);
         atomicAdd(stat + 1, (unsigned long long)(st_end - st_begin) * 4ull);
+        if (nflag) atomicAdd(stat + 5, (unsigned long long)nflag);      // (lab read-out: tiles the second pass walked)
     }
     if constexpr (VAL) {
         unsigned int w5 = __builtin_bit_cast(unsigned int, worst5), w7 = __builtin_bit_cast(unsigned int, worst7);

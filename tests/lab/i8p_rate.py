@@ -28,7 +28,9 @@ for scene in scenes:
     for label, env in (("fp64 scan (BAZ_MUSIC_I8P=0)", {"BAZ_MUSIC_I8P": "0"}), ("packed int8 scan", {"BAZ_MUSIC_I8P": "1"}),
                        ("packed int8, no stores", {"BAZ_MUSIC_I8P": "1", "BAZ_MUSIC_I8_ABL": "1"}),
                        ("packed int8, stores + staging only", {"BAZ_MUSIC_I8P": "1", "BAZ_MUSIC_I8_ABL": "2"}),
-                       ("packed int8, staging + barriers only", {"BAZ_MUSIC_I8P": "1", "BAZ_MUSIC_I8_ABL": "3"})):
+                       ("packed int8, staging + barriers only", {"BAZ_MUSIC_I8P": "1", "BAZ_MUSIC_I8_ABL": "3"}),
+                       ("packed int8, first pass alone", {"BAZ_MUSIC_I8P": "1", "BAZ_MUSIC_I8_ABL": "4"}),
+                       ("packed int8, first pass alone, no stores", {"BAZ_MUSIC_I8P": "1", "BAZ_MUSIC_I8_ABL": "5"})):
         for k in ("BAZ_MUSIC_I8P", "BAZ_MUSIC_I8_ABL"):
             os.environ.pop(k, None)
         os.environ.update(env)
@@ -51,11 +53,16 @@ for scene in scenes:
             st = [ctx.stage_ms(s) for s in range(4)]
             ctx.profile(False)
             name = ctx.stage_name(capi.STAGE_SCAN)
-            stats = ctx.debug_i8_stats() if "ABL" not in env and env["BAZ_MUSIC_I8P"] == "1" else None
+            stats = ctx.debug_i8_stats() if "BAZ_MUSIC_I8_ABL" not in env and env["BAZ_MUSIC_I8P"] == "1" else None
+            if stats:
+                import ctypes
+                v = (ctypes.c_uint64 * 4)()
+                ctx._L.baz_music_debug_i8_times(ctx._h, v)
+                stats = stats + (int(v[1]),)
             s_now = spec[::4099].clone()
             a_now = ang[::4099].clone()
         note = ""
-        if "ABL" not in "".join(env):
+        if "BAZ_MUSIC_I8_ABL" not in env:
             if ref is None:
                 ref = (s_now, a_now)
             else:
@@ -63,6 +70,6 @@ for scene in scenes:
                 note = " | vs fp64 scan: worst rel %.3g, bins equal %s" % (rel, bool((a_now == ref[1]).all()))
         print("%s %-38s step %.3f ms | cov+evd %.3f scan %.3f merge %.4f | %s%s%s" % (
             scene, label, wall, st[0][0] / st[0][1], st[2][0] / st[2][1], st[3][0] / st[3][1], name,
-            " | refined tiles %d of %d" % stats if stats else "", note), flush=True)
+            " | refined tiles %d of %d, flagged %d" % stats if stats else "", note), flush=True)
     del x, spec
     torch.cuda.empty_cache()

@@ -1,4 +1,5 @@
 """The level-packed int8 scan for 2 .. 4 antennas (gr_baz_amd/csrc/scan_i8p_kernels.hip.h; /root/reference/lib/baz_music_doa.cc:101-121).
+LAB BUILD ONLY: measured in round 5 and not shipped (a negative result with its evidence, profiles/r05_i8p_negative.txt).
 
 Same integer forms and bounds as the 6 .. 16-antenna scan (tests/test_i8_scan.py), with the digit pairs of a level laid side by
 side along K (4 MFMAs per tile for levels 0 .. 3) and scan_mfma_kernel's row classes.  Pinned here: the packed operands against a
@@ -13,6 +14,14 @@ from oracle import music_oracle as mo
 from test_i8_scan import _assert_same_choice, _both, _capi, _run, _scene
 
 
+@pytest.fixture(autouse=True)
+def _lab_build_with_the_packed_scan(monkeypatch):
+    """The packed scan is NOT shipped (profiles/r05_i8p_negative.txt: no faster than the fp64 scan, whose time is the spectrum
+    stores'; incoherent batches 2.4 x slower): it exists in the lab build of the library only, behind BAZ_MUSIC_I8P=1."""
+    monkeypatch.setenv("BAZ_MUSIC_LAB_LIB", "lab")
+    monkeypatch.setenv("BAZ_MUSIC_I8P", "1")
+
+
 # ---------------------------------------------------------------------------------------------------------- CPU: the operands
 @pytest.mark.parametrize("m,res", [(4, 130), (3, 77), (2, 64)])
 def test_packed_operands_equal_the_numpy_restatement(m, res):
@@ -20,8 +29,7 @@ def test_packed_operands_equal_the_numpy_restatement(m, res):
     t = mo.steering_table_c64(mo.array_geometry(m), res, mo.FREQUENCY, mo.SPACING) * np.float32(1.7)
     t = t.astype(np.complex64)
     img = capi.debug_host_table_image(m, 1, res, t, 8)
-    par = capi.debug_host_table_image(m, 1, res, t, 7).view(np.float64)
-    assert img is not None and par[6] == 1.0
+    assert img is not None
     steps = (res + 63) // 64
     units = (steps + 2) * 256
     assert img.size == 2 * units * 16
@@ -37,8 +45,7 @@ def test_packed_operands_equal_the_numpy_restatement(m, res):
                 F[:, r * m + c] = (np.conj(a[:, r]) * a[:, c]).real
             else:
                 F[:, r * m + c] = (np.conj(a[:, c]) * a[:, r]).imag
-    wt0 = par[7]                                                          # Fscale 2^-12
-    fscale = wt0 * 2.0 ** 12
+    fscale = 2.0 ** np.frexp(np.abs(F).max() / 1.0009765625)[1]          # the power of two with max|F| / Fscale in (0.5 QMAX, QMAX]
     Fi = np.rint(F * (2.0 ** 54 / fscale)).astype(np.int64)
     rng = np.random.default_rng(1)
     for b in list(rng.integers(0, res, size=40)) + [0, res - 1]:
