@@ -153,6 +153,7 @@ struct baz_music_ctx {
     // int8-matrix-core scan (scan_i8_kernels.hip.h): 6 <= m <= 16, n <= 4
     uint4* dIB = nullptr;          // digit image of the table (build_i8_image)
     uint4* dIP = nullptr;          // level-packed digit operands, 2 .. 4 antennas (build_i8p_kernel); parameters in `i8` as well
+    int seq_walk = 0;              // lab (BAZ_MUSIC_SEQ_WALK=1): scan_mfma_kernel walks its steps left to right (round 4's order; A/B of the strided walk)
     int i8p_on = 0;                // LAB builds only (BAZ_MUSIC_I8P=1): the level-packed int8 scan at m <= 4.  Measured and not shipped
                                    // (profiles/r05_i8p_negative.txt): its arithmetic is 0.31 ms against the fp64 scan's 0.56, but the spectrum
                                    // stores alone take what the fp64 scan takes (0.59 - 0.73 ms by box), and incoherent batches run 2.4 x slower
@@ -878,32 +879,12 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
                     switch (c->i8_abl) {
                         case 1: BAZ_I8_ABL(1); break;      // no spectrum stores
                         case 4: BAZ_I8_ABL(4); break;      // no MFMAs
-                        case 16: BAZ_I8_ABL(16); break;    // stores in flight across the next step's wait (scrap loads, vmcnt(4))
-                        case 17: BAZ_I8_ABL(17); break;    // ... without the stores
                         case 5: BAZ_I8_ABL(5); break;
-                        case 8: BAZ_I8_ABL(8); break;      // only the first phase staged: no staging loads, waits, barriers
-                        case 9: BAZ_I8_ABL(9); break;      // ... and no stores: the tiles' arithmetic alone
-                        case 32: BAZ_I8_ABL(32); break;    // staging, barriers and stores alone
-                        case 40: BAZ_I8_ABL(40); break;    // stores alone
-                        case 64: BAZ_I8_ABL(64); break;    // plain stores
-                        case 1024: BAZ_I8_ABL(1024); break; // staggered workgroup starts
-                        case 16384: BAZ_I8_ABL(16384); break; // stores nt only
-                        case 32768: BAZ_I8_ABL(32768); break; // stores sc0 nt
-                        case 65536: BAZ_I8_ABL(65536); break; // stores sc1 only
-                        case 16424: BAZ_I8_ABL(16424); break; // stores alone, nt only
-                        case 65576: BAZ_I8_ABL(65576); break; // stores alone, sc1 only
-                        case 8192: BAZ_I8_ABL(8192); break; // s_memtime around wait / stores / barrier (baz_music_debug_i8_times)
-                        case 8193: BAZ_I8_ABL(8193); break;
-                        case 2048: BAZ_I8_ABL(2048); break; // rows 256-B aligned (row stride rounded down to 64 bins)
-                        case 2088: BAZ_I8_ABL(2088); break; // ... stores alone
-                        case 4096: BAZ_I8_ABL(4096); break; // every step stores to the row's first piece (no new HBM lines)
-                        case 4104: BAZ_I8_ABL(4104); break; // ... without staging / waits / barriers
-                        case 4136: BAZ_I8_ABL(4136); break; // ... stores alone
-                        case 137: BAZ_I8_ABL(137); break;  // 9 + 128: operands + MFMAs only
-                        case 265: BAZ_I8_ABL(265); break;  // 9 + 256: operands + per-value work only
-                        case 393: BAZ_I8_ABL(393); break;  // 9 + 128 + 256: LDS reads only
-                        case 521: BAZ_I8_ABL(521); break;  // 9 + 512: ten MFMAs
-                        default: BAZ_I8_ABL(96); break;    // staging, barriers, plain stores
+                        case 33: BAZ_I8_ABL(33); break;    // staging and barriers alone
+                        case 256: BAZ_I8_ABL(256); break;  // the steps left to right (round 4's walk): A/B of the strided walk
+                        case 257: BAZ_I8_ABL(257); break;  // ... without the stores
+                        case 9: BAZ_I8_ABL(9); break;      // first phase staged only, no stores: the tiles' arithmetic alone
+                        default: BAZ_I8_ABL(32); break;    // staging, barriers and stores alone
                     }
 #undef BAZ_I8_ABL
                     HIP_TRY(c, hipGetLastError());
@@ -935,7 +916,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             const double2* tb0 = c->dTB + c->tb_step_elems;
 #define BAZ_SIG_LAUNCH(SPEC, VEC4, SIGV)                                                                                    \
     hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4, 0, (1 | 2 | 16), SIGV>), dim3(G.blocks), dim3(256), 0, c->stream, \
-                       c->dSs, tb0, d_spec, cand, batch, c->res, qstride, G.nsplit, c->nclass, G.rows_per_class, c->keep_mask, c->n, rf)
+                       c->dSs, tb0, d_spec, cand, batch, c->res, qstride, G.nsplit, c->nclass, G.rows_per_class, c->keep_mask, c->n, rf, (uint32_t)c->seq_walk)
             if (c->n == 2) {
                 if constexpr (M >= 9) {
                     if (spec && vec4) BAZ_SIG_LAUNCH(true, true, 2);
@@ -952,7 +933,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             return BAZ_MUSIC_OK;
         }
     }
-#define BAZ_SCAN_ARGS dQ, fb0, d_spec, cand, batch, c->res, qstride, G.nsplit, c->nclass, G.rows_per_class, c->keep_mask, c->n, rf
+#define BAZ_SCAN_ARGS dQ, fb0, d_spec, cand, batch, c->res, qstride, G.nsplit, c->nclass, G.rows_per_class, c->keep_mask, c->n, rf, (uint32_t)c->seq_walk
 #define BAZ_SCAN_LAUNCH(SPEC, VEC4, ABLV, AUXV)                                                                    \
     hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4, ABLV, AUXV>), dim3(G.blocks), dim3(256), 0, c->stream, \
                        BAZ_SCAN_ARGS)
@@ -1857,6 +1838,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         }
         if (const char* v = getenv("BAZ_MUSIC_EXACT")) c->i8_on = atoi(v) ? 0 : 1;                // A/B: 1 = the fp64 scan everywhere
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8_ABL")) c->i8_abl = atoi(v);                  // lab
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SEQ_WALK")) c->seq_walk = atoi(v) ? 1 : 0;        // lab
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8P")) c->i8p_on = atoi(v) ? 1 : 0;             // lab: 1 = the level-packed int8 scan at m <= 4
         if (wants_i8_image(c) || (c->i8p_on && m <= 4 && n <= 4)) {
             if (hipMalloc((void**)&c->dI8Stat, 8 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }

@@ -1524,7 +1524,7 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
                                                          double* __restrict__ cand,
                                                          uint32_t batch, uint32_t res, uint32_t qstride,
                                                          uint32_t nsplit, uint32_t nclass, uint32_t rows_per_class,
-                                                         uint32_t keep_mask, uint32_t n, ScanRefine rf)
+                                                         uint32_t keep_mask, uint32_t n, ScanRefine rf, uint32_t seq_walk = 0)
 {
     constexpr int MM = M * M;
     constexpr int KS = SIG ? (2 * M + 3) / 4 : (MM + 3) / 4;   // MFMA k-steps per bin step
@@ -1657,7 +1657,17 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
         soff[r] = ((uint32_t)(g + 4 * r) * nclass * res + 4u * (uint32_t)c) * 4u;
         row_ok[r] = (item0 + nclass * (uint32_t)(g + 4 * r)) < batch;
     }
-    for (uint32_t st = st_begin; st < st_end; ++st) {
+    // STRIDED WALK (round 5; scan_i8_kernels.hip.h has the measurement): the range's steps in SW interleaved sweeps instead of left to
+    // right.  Every step stages its own operands and stores its own 256-B pieces and the lists order their keys by (d, bin), so the order
+    // changes no result -- but after one coarse sweep the lists hold values from near every null, and the top-n gate then fires only where a
+    // later sweep passes a null's bottom instead of on every tile of the walk down to the first one.  seq_walk != 0 (lab): left to right.
+    const uint32_t nst = st_end - st_begin;
+    const uint32_t SW = seq_walk ? 1u : (nst >= 64u ? 8u : (nst >= 16u ? 4u : (nst >= 6u ? 2u : 1u)));
+    uint32_t st = st_begin, sweep = 0;
+    for (uint32_t it = 0; it < nst; ++it) {
+        uint32_t st_next = st + SW, sweep_next = sweep;          // the step after this one in walk order (wave-uniform)
+        if (st_next >= st_end) { sweep_next = sweep + 1; st_next = st_begin + sweep_next; }
+        const bool has_next = it + 1 < nst;
         v4f64 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0, 0, 0, 0};
@@ -1667,8 +1677,8 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
         for (int p = 0; p < PPS; ++p) {
             // 1. fetch this wave's quarter of the NEXT phase from L2 (lands in registers while the MFMAs run)
             const bool last_p = (p == PPS - 1);
-            const bool more = !last_p || (st + 1 < st_end);                 // wave-uniform
-            if (more) BAZ_STAGE_LOAD(last_p ? st + 1 : st, last_p ? 0 : p + 1);
+            const bool more = !last_p || has_next;                          // wave-uniform
+            if (more) BAZ_STAGE_LOAD(last_p ? st_next : st, last_p ? 0 : p + 1);
 
             // 2. this phase: B operands from LDS, MFMAs
             if constexpr (SIG) {
@@ -1851,6 +1861,8 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
             __syncthreads();
             buf ^= 1;
         }
+        st = st_next;
+        sweep = sweep_next;
     }
 
     if (rf.count && lane == 0 && refined_wave) atomicAdd(rf.count, (unsigned long long)refined_wave);

@@ -133,6 +133,29 @@ __device__ __noinline__ v4f64 exact16(const double* __restrict__ Qs, const doubl
     return acc;
 }
 
+// The float32 combinations of the level sums (signed, in units of d; round 5): hw = A_0 256 + A_1 and lw = A_2 256 + A_3 (+ A_4 / 256) as int32
+// words, two full-rate conversions and one f32 FMA -- where the fourth form spent two fp64 conversions, an fp64 FMA and an fp64 -> f32
+// conversion per value.  |result - V wt[3]| <= (2^-23 |V| + 128) wt[3] and V >= T4 / wt[3] ~ 2^33 (five digits: T / wt[3] ~ 2^27, |lw| < 2^28: + 8)
+// for a value that keeps the form: 1.3e-7 relative on top of the 7.5e-7 the form promises for d.  PAIR23: lw fits an int32 (m <= 13).
+template <bool PAIR23>
+__device__ __forceinline__ float i8_comb4(const int l0, const int l1, const int l2, const int l3, const float ws)
+{
+    const float hw = (float)(l0 * 256 + l1);
+    float lw;
+    if constexpr (PAIR23) lw = (float)(l2 * 256 + l3);
+    else lw = __builtin_fmaf((float)l2, 256.0f, (float)l3);
+    return __builtin_fmaf(hw, 65536.0f, lw) * ws;
+}
+template <bool PAIR23>
+__device__ __forceinline__ float i8_comb5(const int l0, const int l1, const int l2, const int l3, const int l4, const float ws)
+{
+    const float hw = (float)(l0 * 256 + l1);
+    float lw;
+    if constexpr (PAIR23) lw = (float)(l2 * 256 + l3 + (l4 >> 8));
+    else lw = __builtin_fmaf((float)l2, 256.0f, (float)l3) + (float)(l4 >> 8);
+    return __builtin_fmaf(hw, 65536.0f, lw) * ws;
+}
+
 // Order of the first tier's 10 digit pairs (s = digit of q, l = level = s + digit of F): the levels go round so that two
 // MFMAs on one accumulator are apart (a dependent MFMA waits for its predecessor's passes).  The second tier is the 5 pairs
 // of level 4, s = 0 .. 4.
@@ -311,6 +334,9 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
     // the row's thresholds of the ONE comparison per value and tier: at or under thr4 a four-digit value needs the second tier
     // (T4) or may enter the row's list (top-n gate), or lies outside the table / belongs to an item without digits (V = 0);
     // at or under thr5 a five-digit value needs the seven-digit form (T) or may enter the list
+    // (round 5) the floats compared with them are float32 COMBINATIONS, good to 1.3e-7 of the exact value: the thresholds carry that slack
+    // (the gate and T times 1 + 2^-21), so no value the exact path would have wanted is ever kept from it; the exact path decides in fp64
+    constexpr float SLACK = 1.0f + 0x1p-21f;
     float thr4[4], thr5[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) thr4[r] = thr5[r] = __builtin_inff();
@@ -346,15 +372,26 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
     };
     [[maybe_unused]] long long t_wait = 0, t_store = 0, t_bar = 0;       // (8192, lab: s_memtime around the step end's three parts)
     [[maybe_unused]] const long long t_loop0 = ((ABL & 8192) != 0) ? (long long)__builtin_readcyclecounter() : 0;
-    for (uint32_t st = st_begin; st < st_end; ++st) {
+    // STRIDED WALK (round 5).  The steps of the range are visited in SW interleaved sweeps (st_begin + k, + SW, + 2 SW, ...; k = 0 .. SW - 1)
+    // instead of left to right.  Nothing depends on the order -- every step stages its own operands and stores its own 256-B pieces, and
+    // the lists order their keys by (d, bin) whatever order they arrive in -- but the top-n gate does: walking left to right, EVERY tile on
+    // the way down to the range's first null holds a new minimum and takes the exact path; after one coarse sweep the lists already hold
+    // values from near every null, and the later sweeps take the exact path only where they pass a null's bottom.
+    const uint32_t nst = st_end - st_begin;
+    const uint32_t SW = (ABL & 256) ? 1u : (nst >= 64u ? 8u : (nst >= 16u ? 4u : (nst >= 6u ? 2u : 1u)));
+    uint32_t st = st_begin, sweep = 0;
+    for (uint32_t it = 0; it < nst; ++it) {
+        uint32_t st_next = st + SW, sweep_next = sweep;          // the step after this one in walk order (wave-uniform)
+        if (st_next >= st_end) { sweep_next = sweep + 1; st_next = st_begin + sweep_next; }
+        const bool has_next = it + 1 < nst;
         const uint32_t bin = st * 64 + 4 * (uint32_t)c;          // this lane's first bin of the step (tile t: bin + t)
         const bool tail_step = st * 64 + 64 > res;               // wave-uniform: the step reaches beyond the table
 #pragma unroll
         for (int p = 0; p < PPS; ++p) {
             const bool last_p = (p == PPS - 1);
-            const bool more = !last_p || (st + 1 < st_end);      // wave-uniform
+            const bool more = !last_p || has_next;               // wave-uniform
             if constexpr (!(ABL & 8)) {
-                if (more) stage_load(last_p ? st + 1 : st, last_p ? 0 : p + 1, buf ^ 1);
+                if (more) stage_load(last_p ? st_next : st, last_p ? 0 : p + 1, buf ^ 1);
             }
             if constexpr (ABL & 32) {
 #pragma unroll
@@ -390,35 +427,26 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
                         for (int s = 0; s < NS - 1; ++s) b0[s] = b[s];
                     }
                 }
-                // ---- four-digit form: V from two (three) int32 words, one comparison, one reciprocal per value ------------
-                v4f64 vd;
+                // ---- four-digit form: the float32 combination of two int32 words, one comparison, one reciprocal per value ------------
                 float fdv[4];
-                bool under = false;
-                if constexpr (ABL & 128) {
-#pragma unroll
-                    for (int l = 0; l < NS; ++l) asm volatile("" ::"v"(L[l]));
-                    vd = (v4f64){1.0, 1.0, 1.0, 1.0};
-                } else
+                unsigned long long under = 0ull;                           // lanes with a value at or below its row's threshold
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int hw = L[0][r] * 256 + L[1][r];
-                    if constexpr (PAIR23) vd[r] = __builtin_fma((double)hw, 65536.0, (double)(L[2][r] * 256 + L[3][r]));
-                    else vd[r] = __builtin_fma(__builtin_fma((double)hw, 256.0, (double)L[2][r]), 256.0, (double)L[3][r]);
-                    fdv[r] = fabsf((float)vd[r]) * ws_f;
-                    under |= (fdv[r] <= thr4[r]);
+                    fdv[r] = fabsf(i8_comb4<PAIR23>(L[0][r], L[1][r], L[2][r], L[3][r], ws_f));
+                    under |= __builtin_amdgcn_ballot_w64(fdv[r] <= thr4[r]);
                     if constexpr (SPEC) sv[r][t] = __builtin_amdgcn_rcpf(fdv[r]);
                 }
-                if (VAL || __any(under)) {
+                if (VAL || under) {
                     // ======== second tier (wave-uniform branch): the 5 NKB MFMAs of level 4; the values at or below T4 take the
                     // five-digit form d5 = d4 + floor(A_4 / 256) wt[3], per value ============================================
-                    [[maybe_unused]] const v4f64 d4 = {vd[0] * ws_d, vd[1] * ws_d, vd[2] * ws_d, vd[3] * ws_d};
-                    bool form4[4], need5 = false;
+                    bool form4[4];
+                    unsigned long long need5 = 0ull;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         form4[r] = !VAL && (fdv[r] > t4_f);                  // per VALUE: its own four-digit value decides
-                        need5 |= !form4[r];
+                        need5 |= __builtin_amdgcn_ballot_w64(!form4[r]);
                     }
-                    if (VAL || __any(need5)) {          // (a tile that only holds candidates of the top-n lists skips the MFMAs)
+                    if (VAL || need5) {                 // (a tile that only holds candidates of the top-n lists skips the MFMAs)
 #pragma unroll
                         for (int kb = 0; kb < NKB; ++kb) {
                             v4i32 b[NS];
@@ -432,22 +460,29 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const double v5 = vd[r] + (double)(L[4][r] >> 8);
-                            const float f5 = fabsf((float)v5) * ws_f;
-                            vd[r] = form4[r] ? vd[r] : v5;
+                            const float f5 = fabsf(i8_comb5<PAIR23>(L[0][r], L[1][r], L[2][r], L[3][r], L[4][r], ws_f));
                             fdv[r] = form4[r] ? fdv[r] : f5;
                             if constexpr (SPEC) sv[r][t] = __builtin_amdgcn_rcpf(fdv[r]);
                         }
                     }
-                    under = false;
+                    under = 0ull;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) under |= (fdv[r] <= thr5[r]);
-                if (VAL || __any(under)) {
-                    // ======== everything that is not the bulk of the values (wave-uniform branch) ========================
+                    for (int r = 0; r < 4; ++r) under |= __builtin_amdgcn_ballot_w64(fdv[r] <= thr5[r]);
+                if (VAL || under) {
+                    // ======== everything that is not the bulk of the values (wave-uniform branch): from here on in fp64, exactly ========
                     v4f64 d;
+                    [[maybe_unused]] v4f64 d4;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) d[r] = vd[r] * ws_d;                // d4 or d5, exactly
+                    for (int r = 0; r < 4; ++r) {
+                        const int hw = L[0][r] * 256 + L[1][r];
+                        double v4;
+                        if constexpr (PAIR23) v4 = __builtin_fma((double)hw, 65536.0, (double)(L[2][r] * 256 + L[3][r]));
+                        else v4 = __builtin_fma(__builtin_fma((double)hw, 256.0, (double)L[2][r]), 256.0, (double)L[3][r]);
+                        d4[r] = v4 * ws_d;
+                        d[r] = (form4[r] ? v4 : v4 + (double)(L[4][r] >> 8)) * ws_d;        // d4 or d5, exactly
+                    }
                     [[maybe_unused]] const v4f64 d5 = d;
+                    bool exact_r[4] = {false, false, false, false};         // values whose float is (float)|d| of an fp64 form below
                     // Five-digit values at or below T: two more digits of both operands (levels 5 and 6 on top of the accumulated
                     // ones: 13 NKB MFMAs) and the low byte of the level-4 sum; digits 5, 6 of q from this lane's LDS slot, of F
                     // from the image in L2.
@@ -492,6 +527,7 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
                             // on which items share its wave or on how a batch was cut (the rule of literal_tile()).
                             const bool take = VAL || (!form4[r] && !(fabs(d[r]) > tacc_d));
                             d[r] = take ? d7 : d[r];
+                            exact_r[r] = take;
                         }
                     }
                     // items whose coefficients are not a projector's (non-finite or garbage covariance): scan_mfma_kernel's fp64
@@ -510,30 +546,26 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
                                 if (counts && r4 > worst4) worst4 = r4;
                             }
                             d[r] = (VAL || !sane_r[r]) ? ex[r] : d[r];
+                            exact_r[r] = exact_r[r] || VAL || !sane_r[r];
                         }
                     }
                     // bins outside the table (last step of a row): zero digits gave d = 0; they must never be selected
                     const bool inside = in_table;
                     if (tail_step) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) d[r] = inside ? d[r] : 1e300;
+                        for (int r = 0; r < 4; ++r) {
+                            d[r] = inside ? d[r] : 1e300;
+                            exact_r[r] = exact_r[r] || !inside;
+                        }
                     }
-                    // Top-n gate and near-null vote of scan_mfma_kernel, per tile
+                    // Top-n gate and near-null vote of scan_mfma_kernel, per tile -- in fp64 (exact: the float comparisons above only
+                    // decided that this path runs).  A value that kept an integer form keeps its float32 combination as its float.
                     bool hit = false, low = false;
-                    if constexpr (SPEC) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float fd = fabsf((float)d[r]);
-                            hit |= (fd <= gate_f[r]);
-                            low |= (fd <= below_f);
-                            sv[r][t] = __builtin_amdgcn_rcpf(fd);
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            hit |= (fabs(d[r]) <= gate_d[r]);
-                            low |= (fabs(d[r]) <= below_d);
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        hit |= (fabs(d[r]) <= gate_d[r]);
+                        low |= (fabs(d[r]) <= below_d);
+                        if constexpr (SPEC) sv[r][t] = __builtin_amdgcn_rcpf(exact_r[r] ? fabsf((float)d[r]) : fdv[r]);
                     }
                     if (__any(hit)) {
                         if (refine_on && __any(low)) {          // near-null values: the reference's literal form, per value
@@ -543,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
                                 const bool redo = (fabs(d[r]) <= rf.below) && inside;
                                 d[r] = redo ? lit[r] : d[r];
                                 refined += (redo && row_ok[r]) ? 1u : 0u;
-                                if constexpr (SPEC) sv[r][t] = strength_f32(fabs(d[r]));
+                                if constexpr (SPEC) sv[r][t] = redo ? strength_f32(fabs(d[r])) : sv[r][t];   // (per VALUE: the others keep their float)
                             }
                         }
 #pragma unroll
@@ -551,12 +583,12 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
                             key_insert_new<NMAX>(key[r], make_key(d[r], inside ? bin + t : nobin, keep_mask));
                             const uint64_t kb = __builtin_bit_cast(uint64_t, key[r][NMAX - 1]) | (uint64_t)(~keep_mask);
                             gate_d[r] = fmax(__builtin_bit_cast(double, kb), below_d);
-                            gate_f[r] = (float)gate_d[r];
-                            // the bulk paths' thresholds: at least the gate (rounded up where the gate is kept in fp64), at least T4 / T
-                            float gu = gate_f[r];
-                            if constexpr (!SPEC) gu = ((double)gu < gate_d[r]) ? __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, gu) + 1u) : gu;   // (gu >= 0, finite here)
+                            // the bulk paths' thresholds: at least the gate (rounded UP to a float, times the combination's slack), at least T4 / T
+                            float gu = (float)gate_d[r];
+                            gu = ((double)gu < gate_d[r]) ? __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, gu) + 1u) : gu;   // (gu >= 0, finite here)
+                            gu *= SLACK;
                             thr4[r] = fmaxf(gu, t4_f);
-                            thr5[r] = fmaxf(gu, ip.t_acc_f);
+                            thr5[r] = fmaxf(gu, ip.t_acc_f * SLACK);
                         }
                     }
                 }
@@ -586,6 +618,8 @@ __global__ __launch_bounds__(256, 2) void scan_i8_kernel(const double* __restric
             }
             buf ^= 1;
         }
+        st = st_next;
+        sweep = sweep_next;
     }
     if constexpr ((ABL & 8192) != 0) {
         if (stat && lane == 0) {

@@ -11,15 +11,10 @@ from gr_baz_amd import capi, synth
 from gr_baz_amd.baz.music_doa_helper import calculate_antenna_array_response
 
 dev = torch.device("cuda:0")
-NAMES = {0: "product", 1: "no stores", 4: "no MFMAs", 5: "no MFMAs, no stores", 8: "first phase staged only: no staging / waits / barriers",
-         9: "the same without stores: the tiles' arithmetic alone", 16: "stores in flight across the next wait (scrap loads, vmcnt(4))",
-         17: "the same without the stores", 32: "staging + barriers + stores, no arithmetic", 40: "stores alone", 64: "plain stores (no nt / sc)",
-         96: "staging + barriers + plain stores, no arithmetic", 1024: "workgroups start up to one step apart", 16384: "stores nt only", 32768: "stores sc0 nt", 65536: "stores sc1 only",
-         16424: "stores alone, nt only", 65576: "stores alone, sc1 only", 2048: "rows 256-B aligned (stride rounded down to 64 bins)",
-         2088: "stores alone, rows 256-B aligned", 4096: "every step stores to the row's first 256 B",
-         4104: "the same without staging / waits / barriers", 4136: "stores alone, to the row's first 256 B", 137: "arithmetic alone: LDS reads + MFMAs, no per-value work",
-         265: "arithmetic alone: LDS reads + per-value work, no MFMAs", 393: "arithmetic alone: LDS reads only", 521: "arithmetic alone with 10 MFMAs per tile"}
-ABLS = [int(v) for v in sys.argv[1:]] or [0, 1, 8, 9, 32, 40, 64, 96]
+NAMES = {0: "product", 1: "no stores", 4: "no MFMAs", 5: "no MFMAs, no stores", 9: "first phase staged only, no stores: the tiles' arithmetic alone",
+         32: "staging + barriers + stores, no arithmetic", 33: "staging + barriers alone", 256: "steps left to right (round 4's walk)",
+         257: "steps left to right, no stores"}
+ABLS = [int(v) for v in sys.argv[1:]] or [0, 1, 256, 257, 32]
 for M, NE, N, RES, B in ((8, 2, 4096, 36000, 16384), (16, 2, 4096, 3600, 16384)):
     arr = synth.array_geometry(M)
     table = np.array(calculate_antenna_array_response([[0.5 * x, 0.5 * y] for x, y in arr], RES, 1.0)).astype(np.complex64)

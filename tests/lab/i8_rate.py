@@ -17,7 +17,9 @@ from gr_baz_amd.baz.music_doa_helper import calculate_antenna_array_response
 dev = torch.device("cuda:0")
 quick = "quick" in sys.argv[1:]
 CASES = [(8, 2, 4096, 36000, 16384, "coherent", 20.0), (16, 2, 4096, 3600, 16384, "coherent", 20.0)]
-if not quick:
+if "ab" in sys.argv[1:]:          # same-box A/B of two builds of the library (BAZ_MUSIC_LAB_LIB=quick / lab): four shapes
+    CASES += [(8, 2, 4096, 36000, 16384, "incoherent", 20.0), (8, 2, 1024, 3600, 65536, "coherent", 20.0)]
+elif not quick:
     CASES += [(8, 2, 4096, 36000, 16384, "incoherent", 20.0), (8, 2, 4096, 36000, 16384, "coherent", 60.0),
               (16, 2, 4096, 3600, 16384, "incoherent", 20.0), (8, 2, 1024, 3600, 65536, "coherent", 20.0),
               (6, 2, 6 * 128, 3600, 65536, "coherent", 20.0), (12, 2, 12 * 128, 3600, 16384, "coherent", 20.0)]
