@@ -104,6 +104,8 @@ struct baz_music_ctx {
     float* hRaw = nullptr;           // its page-locked staging copy (the caller's vector may be pageable and short-lived)
     void* dTabStats = nullptr;       // baztab::TableStats
     void* hTabStats = nullptr;       // ... page-locked
+    float* h_al_big = nullptr;                          // host-fed zero-copy calls: page-locked ang / lvl image of a whole call
+    size_t h_al_big_cap = 0;                            // floats
     double last_retune_ms = 0.0;     // wall time of the last baz_music_set_table, of which ...
     double last_swap_wait_ms = 0.0;  // ... waiting for and holding `mtx`
     int profiling = 0;      // 0 off, 1 every stage, 2 only the dominant (scan) stage
@@ -138,6 +140,7 @@ struct baz_music_ctx {
     int sub_evd = 1;               // signal subspace by orthogonal iteration where n <= 4 (run-time-m kernels: n <= 8) (lab: BAZ_MUSIC_SUB_EVD=0)
     int fused_covevd = 0;          // m = 4, K % 256 == 0: covariance + EVD in one kernel (BAZ_MUSIC_FUSE=0: lab, two kernels)
     uint32_t covevd_blocks = 512u; // grid of cov4_evd_kernel: the workgroups resident at once (2 per CU)
+    int covevd_task_items = 0;     // lab (BAZ_MUSIC_COVEVD_TASK_ITEMS = 64 / 32 / 16): items per wave task of cov4_evd_kernel, 0 = by batch size
     uint32_t cov4_resident_blocks = 256u;        // grid of cov4_x4_kernel (persistent waves): one workgroup per CU
     // coarse-gated scan (scan_coarse_kernels.hip.h): m <= 8, spectrum port not wired
     uint4* dCS = nullptr;          // per 16-bin tile: f16 hi/lo pieces of the scaled table (B32, B16) + the fp64 B operand (X)
@@ -647,10 +650,13 @@ int launch_covevd(baz_music_ctx* c, const float* d_in, uint32_t batch, double* d
                   double2* d_R_dbg = nullptr)
 {
     ProfScope ps(c, BAZ_MUSIC_STAGE_COV);
-    const uint32_t ntasks = (batch + 63) / 64;
+    // items per wave task: 64 where that still makes >= 256 tasks (one per CU), else 32 / 16 -- a small batch needs more waves reading than
+    // lanes rotating (a host-fed 1,024-item call read its input over PCIe at 40 GB/s with 16 waves; cov4_evd_kernel)
+    const uint32_t ti = c->covevd_task_items ? (uint32_t)c->covevd_task_items : (batch >= 16384u ? 64u : (batch >= 8192u ? 32u : 16u));
+    const uint32_t ntasks = (batch + ti - 1) / ti;
     const uint32_t blocks = std::min<uint32_t>((ntasks + 3) / 4, c->covevd_blocks);
     hipLaunchKernelGGL(cov4_evd_kernel, dim3(blocks), dim3(256), 0, c->stream, d_in, dQ, dG, d_R_dbg, batch, c->K, c->n,
-                       qstride);
+                       qstride, ti);
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
 }
@@ -1692,6 +1698,17 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
     return BAZ_MUSIC_OK;
 }
 
+int ensure_h_al_big(baz_music_ctx* c, size_t floats)
+{
+    if (floats <= c->h_al_big_cap) return BAZ_MUSIC_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_al_big) (void)hipHostFree(c->h_al_big);
+    c->h_al_big = nullptr; c->h_al_big_cap = 0;
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_al_big, floats * sizeof(float), hipHostMallocDefault));
+    c->h_al_big_cap = floats;
+    return BAZ_MUSIC_OK;
+}
+
 // baz_music_create's last step: both table sets, the builders' side stream and staging buffers, then the first table
 int create_tables(baz_music_ctx* c, const float* table_ri)
 {
@@ -1712,7 +1729,12 @@ int create_tables(baz_music_ctx* c, const float* table_ri)
     if (r == BAZ_MUSIC_OK) r = alloc_table_set(c, c->shadow);
     if (r != BAZ_MUSIC_OK) return r;
     std::lock_guard<std::mutex> tl(c->tab_mtx);
-    return retune(c, table_ri, true);
+    r = retune(c, table_ri, true);
+    if (r != BAZ_MUSIC_OK) return r;
+    // first touch of the SHADOW set here, not in the first retune (fresh device allocations are mapped on first use: one retune in twenty
+    // took 7 - 12 ms and held the submitting thread up by 0.9 ms, tests/test_retune.py): build the same table into it once
+    r = build_tables_device(c, c->shadow);
+    return r;
 }
 
 }  // namespace
@@ -1839,6 +1861,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (const char* v = getenv("BAZ_MUSIC_EXACT")) c->i8_on = atoi(v) ? 0 : 1;                // A/B: 1 = the fp64 scan everywhere
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8_ABL")) c->i8_abl = atoi(v);                  // lab
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SEQ_WALK")) c->seq_walk = atoi(v) ? 1 : 0;        // lab
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COVEVD_TASK_ITEMS")) { const int t = atoi(v); c->covevd_task_items = (t == 64 || t == 32 || t == 16) ? t : 0; }
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8P")) c->i8p_on = atoi(v) ? 1 : 0;             // lab: 1 = the level-packed int8 scan at m <= 4
         if (wants_i8_image(c) || (c->i8p_on && m <= 4 && n <= 4)) {
             if (hipMalloc((void**)&c->dI8Stat, 8 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
@@ -1892,6 +1915,7 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         for (auto& p : c->prof)
             for (auto e : p.ev) (void)hipEventDestroy(e);
+        if (c->h_al_big) (void)hipHostFree(c->h_al_big);
         if (c->s_tab) (void)hipStreamSynchronize(c->s_tab);
         {
             TableSet act = active_table_set(c);
@@ -2041,7 +2065,7 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
     //                               >= 8 MiB and <= 32 MiB each;
     //   pageable caller memory      one chunk up to 64 MiB, 64-MiB chunks beyond (profiles/r01h_hostfed_chunk_sweep.txt);
     //   BAZ_MUSIC_CHUNK_MIB         forces the chunk size (tests, lab).
-    const size_t per_item = (size_t)c->nsamples * 8 + (size_t)c->res * 4 + (size_t)c->n * 8;
+    const size_t per_item = (size_t)c->nsamples * 8 + (spectrum ? (size_t)c->res * 4 : 0) + (size_t)c->n * 8;   // what this call moves per item
     // "locked" is a statement about the WHOLE of both ranges (the first byte alone is not enough)
     const bool locked = range_is_pinned(in_ri, (size_t)batch * c->nsamples * 8) &&
                         (!spectrum || range_is_pinned(spectrum, (size_t)batch * c->res * 4));
@@ -2059,40 +2083,53 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
     }
     const bool single = chunk >= batch;
     const bool want_spec = spectrum != nullptr;
-    int r = ensure_slots(c, chunk, want_spec);
-    if (r) return r;
-    if (!c->wide) {
-        r = ensure_workspace(c, chunk);
-        if (r) return r;
-        r = reserve_candidates(c, chunk);
-        if (r) return r;
-    }
+    int r = BAZ_MUSIC_OK;
 
     // Small call on page-locked caller memory: no copies at all.  The kernels address the caller's buffers over PCIe
     // (hipHostGetDevicePointer): the covariance kernel reads every input byte once, the scan stores every spectrum value
-    // once, ang / lvl land in the slot's page-locked image -- each byte crosses the link once, inside the three launches,
-    // instead of through two or three DMA transfers with their submission and completion latencies.  Larger calls keep
-    // the pipelined copies (there the DMA engines overlap both directions with the kernels).
+    // once, ang / lvl land in a page-locked image -- each byte crosses the link once, inside the launches, instead of
+    // through two or three DMA transfers with their submission and completion latencies.  Larger calls keep the pipelined
+    // copies below (there the DMA engines overlap both directions with the kernels).
+    // A launch sequence uses the link in one direction at a time (a 1,024-item config-2 call: 0.21 ms in, then 0.26 ms out), and round 5
+    // tried twice to overlap the two inside a call -- sub-chunks alternating between two contexts with event-staggered kernels, and the
+    // input of sub-chunk i + 1 by DMA on a side stream beside the kernels of sub-chunk i.  Both LOSE at every call size: each sub-chunk
+    // costs 0.1 - 0.17 ms of copy start-up and cross-stream event hops on this stack (profiles/r05_hostfed_calls.txt).  What pays is a
+    // larger call (the host block's look-back) and more, shorter covariance tasks for small batches (launch_covevd).
     if (single && locked && c->zero_copy) {
         void *z_in = nullptr, *z_spec = nullptr, *z_al = nullptr;
-        bool ok = hipHostGetDevicePointer(&z_in, (void*)in_ri, 0) == hipSuccess;
+        bool ok = ensure_h_al_big(c, (size_t)batch * c->n * 2) == BAZ_MUSIC_OK;
+        ok = ok && hipHostGetDevicePointer(&z_in, (void*)in_ri, 0) == hipSuccess;
         if (ok && want_spec) ok = hipHostGetDevicePointer(&z_spec, (void*)spectrum, 0) == hipSuccess;
-        if (ok) ok = hipHostGetDevicePointer(&z_al, (void*)c->slot[0].h_al, 0) == hipSuccess;
+        if (ok) ok = hipHostGetDevicePointer(&z_al, (void*)c->h_al_big, 0) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();           // not addressable from the device after all: the copy path below
         } else {
             float* z_ang = static_cast<float*>(z_al);
-            int zr = begin_statistic(c);
+            int zr = BAZ_MUSIC_OK;
+            if (!c->wide) {
+                zr = ensure_workspace(c, batch);
+                if (zr == BAZ_MUSIC_OK) zr = reserve_candidates(c, batch);
+            }
+            if (zr == BAZ_MUSIC_OK) zr = begin_statistic(c);
             if (zr == BAZ_MUSIC_OK)
                 zr = process_device_locked(c, z_in, batch, z_ang, z_ang + (size_t)batch * c->n, want_spec ? z_spec : nullptr);
             const hipError_t es = hipStreamSynchronize(c->stream);   // also after a failed launch
             if (zr == BAZ_MUSIC_OK && es != hipSuccess) zr = hip_fail(c, es, "hipStreamSynchronize");
             if (zr != BAZ_MUSIC_OK) return zr;
             const size_t cnt = (size_t)batch * c->n;
-            memcpy(ang, c->slot[0].h_al, cnt * 4);
-            if (lvl) memcpy(lvl, c->slot[0].h_al + cnt, cnt * 4);
+            memcpy(ang, c->h_al_big, cnt * 4);
+            if (lvl) memcpy(lvl, c->h_al_big + cnt, cnt * 4);
             return (int)batch;
         }
+    }
+
+    r = ensure_slots(c, chunk, want_spec);
+    if (r) return r;
+    if (!c->wide) {
+        r = ensure_workspace(c, chunk);
+        if (r) return r;
+        r = reserve_candidates(c, chunk);
+        if (r) return r;
     }
 
     int rc = BAZ_MUSIC_OK;

@@ -584,8 +584,12 @@ __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict_
 // -------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cov4_evd_kernel(const float* __restrict__ in, double* __restrict__ Qs,
                                                        double* __restrict__ Gs, double2* __restrict__ Rdbg,
-                                                       uint32_t batch, uint32_t K, uint32_t n, uint32_t qstride)
+                                                       uint32_t batch, uint32_t K, uint32_t n, uint32_t qstride,
+                                                       uint32_t task_items = 64)
 {
+    // task_items (64, 32 or 16; round 5): items per wave task.  64 fills the lane-per-item EVD; a SMALL batch -- a host-fed work() call of
+    // 1,024 items is 16 tasks of 64 = 16 waves with 8 KiB in flight each, too little to keep a PCIe link (or HBM) busy -- is cut into more,
+    // shorter tasks (the EVD then runs on fewer lanes: its latency is what it was).  Items are independent: no result depends on it.
     constexpr int RSD = 34;                       // see cov4_x4_kernel
     constexpr int RING = 8;                       // chunk loads in flight per wave (8 KiB)
     __shared__ double stage[4][2][8 * RSD];       // per wave, double-buffered
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(256) void cov4_evd_kernel(const float* __restrict__
     double* const g2 = gram[wave][1];
     double(*const rt)[64] = rtab[wave];
     const double dK = (double)K;
-    const uint32_t ntasks = (batch + 63) >> 6;
+    const uint32_t ntasks = (batch + task_items - 1) / task_items;
     const uint32_t tstride = gridDim.x * 4;
     // slot of the upper-triangle entry this lane (< 16: a = lane>>2, b = lane&3) produces: diagonal a -> a;
     // pair (a < b) -> 4 + 2p (re), 5 + 2p (im), p = index of (a, b) in (0,1)(0,2)(0,3)(1,2)(1,3)(2,3)
@@ -611,8 +615,8 @@ __global__ __launch_bounds__(256) void cov4_evd_kernel(const float* __restrict__
 
     for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += tstride) {
         __builtin_amdgcn_s_setprio(3);
-        const uint32_t item0 = task * 64;
-        const uint32_t nit = (batch - item0 < 64u) ? batch - item0 : 64u;
+        const uint32_t item0 = task * task_items;
+        const uint32_t nit = (batch - item0 < task_items) ? batch - item0 : task_items;
         // the stream of this task: nit items x chunks, contiguous in HBM; ring slot u holds the chunks q = u (mod 8)
         const v4f32* __restrict__ src = reinterpret_cast<const v4f32*>(in + (size_t)item0 * K * 8) + lane;
         const uint32_t total = nit * chunks;                 // multiple of 8

@@ -108,16 +108,19 @@ baz_music_doa::baz_music_doa(unsigned int m, unsigned int n, unsigned int nsampl
      *                              a single item is still a valid call, and nothing is lost at the end of a stream: the
      *                              runtime preloads the H look-back items as zeros (buffer_add_reader(.., history - 1)),
      *                              output i is computed from input i + H, i.e. from real item i.
-     * The block uses the second: BAZ_MUSIC_INPUT_LOOKBACK = H (0 = none; default 1024 items, fewer where items are large:
-     * H = 16 MiB / the larger of an input item and a spectrum row, between 8 and 1024 -- the doubly mapped circular buffers
-     * are 2 (H + 2) items and must fit /dev/shm: config 2 keeps 1024 (16.8 MB in, 29.5 MB spectrum), config 3 (144 KB rows)
-     * gets 116, 64 antennas x 256 columns (128 KiB items) 128 instead of a 268 MB buffer), output multiple 1,
+     * The block uses the second: BAZ_MUSIC_INPUT_LOOKBACK = H (0 = none; default 2048 items, fewer where items are large:
+     * H = 32 MiB / the larger of an input item and a spectrum row, between 8 and 2048 -- the doubly mapped circular buffers
+     * are 2 (H + 2) items and must fit /dev/shm: config 2 gets 2048 (33.6 MB in, 59 MB spectrum), config 3 (144 KB rows)
+     * 233, 64 antennas x 256 columns (128 KiB items) 256.  Round 5 doubled it: a host-fed call is one launch sequence that reads
+     * its input over the link and then writes its spectrum over it, and its fixed costs shrink with the call -- config 2 with port 2 on
+     * page-locked buffers: 2.05e6 items/s in 1,024-item calls, 2.24e6 in 2,048-item calls; without port 2 4.9e6 / 5.7e6
+     * (profiles/r05_hostfed_calls.txt; cutting a call into overlapped sub-chunks LOSES on this stack, same file)), output multiple 1,
      * set_min_output_buffer(2 H) so that the output side admits the same calls (a call takes at most half a buffer).
      * BAZ_MUSIC_OUTPUT_MULTIPLE (1), BAZ_MUSIC_MIN_OUTPUT_BUFFER, BAZ_MUSIC_MAX_NOUTPUT (0 = no cap) override.
      * What the runtime makes of them (call sizes per work()) is modelled in gr_shim/gnuradio/flowgraph_model.h;
      * INTEGRATION.md 5 has the memory these requests cost and the measured rates. */
     const size_t big_item = std::max<size_t>((size_t)nsamples * sizeof(gr_complex), (size_t)resolution * sizeof(float));
-    const long lookback_dflt = (long)std::max<size_t>(8, std::min<size_t>(1024, ((size_t)16 << 20) / big_item));
+    const long lookback_dflt = (long)std::max<size_t>(8, std::min<size_t>(2048, ((size_t)32 << 20) / big_item));
     const long lookback = env_long("BAZ_MUSIC_INPUT_LOOKBACK", lookback_dflt, 0, 1 << 20);
     const long multiple = env_long("BAZ_MUSIC_OUTPUT_MULTIPLE", 1, 1, 1 << 20);
     const long min_buffer = env_long("BAZ_MUSIC_MIN_OUTPUT_BUFFER", std::max(2 * lookback, multiple > 1 ? 8 * multiple : 0L), 0, 1L << 30);

@@ -116,7 +116,7 @@ def test_scheduler_hints_are_requests_not_caps(gpu_device, monkeypatch):
     for k in ("BAZ_MUSIC_OUTPUT_MULTIPLE", "BAZ_MUSIC_MIN_OUTPUT_BUFFER", "BAZ_MUSIC_MAX_NOUTPUT", "BAZ_MUSIC_INPUT_LOOKBACK"):
         monkeypatch.delenv(k, raising=False)
     blk = _baz().music_doa(4, 2, 16, tab, 8)
-    assert blk.output_multiple() == 1 and blk.history() == 1025 and blk.min_output_buffer() == 2048 and blk.max_noutput_items() == 0
+    assert blk.output_multiple() == 1 and blk.history() == 2049 and blk.min_output_buffer() == 4096 and blk.max_noutput_items() == 0
     monkeypatch.setenv("BAZ_MUSIC_OUTPUT_MULTIPLE", "256")       # the round-2 way stays available (a minimum call size)
     monkeypatch.setenv("BAZ_MUSIC_INPUT_LOOKBACK", "0")
     monkeypatch.setenv("BAZ_MUSIC_MAX_NOUTPUT", "4096")
@@ -149,7 +149,7 @@ def test_finite_stream_is_processed_to_its_last_item(gpu_device, monkeypatch):
         p, a1, l1, s1 = blk.work(items, 3)
         assert p == count and np.array_equal(a1, ang) and np.array_equal(l1, lvl) and np.array_equal(s1, spec)
         if count == 2500:
-            assert max(st["call_sizes"]) == 1024 and st["in_bufsize"] >= 2 * 1026       # calls of H items, input sized by the look-back
+            assert max(st["call_sizes"]) == 2048 and st["in_bufsize"] >= 2 * 2050       # calls of H items, input sized by the look-back
     monkeypatch.setenv("BAZ_MUSIC_OUTPUT_MULTIPLE", "64")
     monkeypatch.setenv("BAZ_MUSIC_INPUT_LOOKBACK", "0")
     blk = baz.music_doa(g["m"], g["n"], g["nsamples"], table, g["res"])

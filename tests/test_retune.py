@@ -221,7 +221,8 @@ def test_retune_does_not_stall_the_submitting_thread(gpu_device):
     busy = np.array(busy)
     walls_ms = np.array(walls) * 1e3
     gap_ms = (float(busy.max()) - base) * 1e3
-    print("\nretune at cfg3, %d-item batches: undisturbed call %.3f ms (worst %.3f), during 20 retunes worst %.3f ms -> extra gap %.3f ms; "
+    print("\nretune walls (ms):", " ".join("%.2f" % w for w in walls_ms), "| worst busy call #%d of %d" % (int(busy.argmax()), len(busy)))
+    print("retune at cfg3, %d-item batches: undisturbed call %.3f ms (worst %.3f), during 20 retunes worst %.3f ms -> extra gap %.3f ms; "
           "set_table wall: median %.3f ms, worst %.3f ms; lock wait+hold worst %.4f ms; tables seen %s"
           % (B, base * 1e3, quiet_worst * 1e3, busy.max() * 1e3, gap_ms, np.median(walls_ms), walls_ms.max(),
              max(s[1] for s in swaps), sorted(seen)))
