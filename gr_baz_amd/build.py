@@ -55,7 +55,7 @@ def build_hip(force=False, verbose=False):
     music_srcs = [os.path.join(CSRC, "baz_music_hip.hip"), os.path.join(CSRC, "music_kernels.hip.h"),
                   os.path.join(CSRC, "music_wide_kernels.hip.h"), os.path.join(CSRC, "scan_coarse_kernels.hip.h"),
                   os.path.join(CSRC, "scan_i8_kernels.hip.h"), os.path.join(CSRC, "scan_i8p_kernels.hip.h"),
-                  os.path.join(CSRC, "table_kernels.hip.h"), os.path.join(INCLUDE, "baz_music_hip.h")]
+                  os.path.join(CSRC, "table_kernels.hip.h"), os.path.join(CSRC, "sort_kernels.hip.h"), os.path.join(INCLUDE, "baz_music_hip.h")]
     agc_srcs = [os.path.join(CSRC, "baz_agc_hip.hip"), os.path.join(CSRC, "agc_kernels.hip.h"),
                 os.path.join(INCLUDE, "baz_agc_hip.h")]
     rs_srcs = [os.path.join(CSRC, "baz_resamp_hip.hip"), os.path.join(CSRC, "resamp_kernels.hip.h"),

@@ -33,7 +33,7 @@ SYMBOLS = [
     "baz_music_refined_values", "baz_music_debug_coarse_margin", "baz_music_debug_coarse_fired",
     "baz_music_host_register", "baz_music_set_host_pinning", "baz_music_host_unregister_all", "baz_music_host_pinned_bytes",
     "baz_music_debug_i8_margin", "baz_music_debug_i8_stats", "baz_music_uses_i8_scan", "baz_music_debug_i8_image",
-    "baz_music_debug_i8_nsplit", "baz_music_last_retune_ms", "baz_music_debug_table_image", "baz_music_debug_host_table_image",
+    "baz_music_debug_i8_nsplit", "baz_music_debug_sort_state", "baz_music_last_retune_ms", "baz_music_debug_table_image", "baz_music_debug_host_table_image",
 ]
 
 _vp = ctypes.c_void_p
@@ -149,6 +149,8 @@ def _bind(L):
     L.baz_music_debug_i8_image.restype = ctypes.c_size_t
     L.baz_music_debug_i8_image.argtypes = [_u32, _u32, _f32p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t,
                                            ctypes.POINTER(ctypes.c_double)]
+    L.baz_music_debug_sort_state.restype = ctypes.c_int
+    L.baz_music_debug_sort_state.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64)]
     L.baz_music_last_retune_ms.restype = ctypes.c_int
     L.baz_music_last_retune_ms.argtypes = [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     L.baz_music_debug_table_image.restype = ctypes.c_size_t
@@ -206,6 +208,12 @@ class Context:
         t = _table_f32(table, self.res, self.m)
         self._chk(self._L.baz_music_set_table(self._h, t.view(np.float32).ctypes.data_as(_f32p)),
                   "baz_music_set_table")
+
+    def debug_sort_state(self):
+        """{"sorted_calls", "unsorted_calls", "fired", "walked", "last_sorted"} of the gated scan's sorting policy (synchronises)."""
+        v = (ctypes.c_uint64 * 5)()
+        self._chk(self._L.baz_music_debug_sort_state(self._h, v), "baz_music_debug_sort_state")
+        return {"sorted_calls": int(v[0]), "unsorted_calls": int(v[1]), "fired": int(v[2]), "walked": int(v[3]), "last_sorted": bool(v[4])}
 
     def last_retune_ms(self):
         """(wall milliseconds of the last set_table, milliseconds of it spent waiting for / holding the lock shared with process)."""

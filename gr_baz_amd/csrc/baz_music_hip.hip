@@ -10,6 +10,7 @@
 #include "scan_coarse_kernels.hip.h"
 #include "scan_i8_kernels.hip.h"
 #include "scan_i8p_kernels.hip.h"
+#include "sort_kernels.hip.h"
 #include "table_kernels.hip.h"
 
 #include <algorithm>
@@ -91,6 +92,7 @@ struct baz_music_ctx {
         double2* dFB = nullptr; double2* dTB = nullptr; uint4* dCS = nullptr; uint4* dIB = nullptr; double* dA2p = nullptr;
         float2* dTA = nullptr; double* dA2 = nullptr;
         uint4* dIP = nullptr;            // level-packed int8 operands (m <= 4; shares i8 / i8_ok with dIB: a configuration has one of the two)
+        float* dKT = nullptr;            // float32 table at the sort key's sample bins (sort_kernels.hip.h; m <= 8)
         CoarseParams cs = {0.0f, 0.0f, 0.0, 0.0, 1};
         I8Params i8 = {};
         bool cs_ok = false, i8_ok = false;
@@ -156,6 +158,26 @@ struct baz_music_ctx {
     // int8-matrix-core scan (scan_i8_kernels.hip.h): 6 <= m <= 16, n <= 4
     uint4* dIB = nullptr;          // digit image of the table (build_i8_image)
     uint4* dIP = nullptr;          // level-packed digit operands, 2 .. 4 antennas (build_i8p_kernel); parameters in `i8` as well
+    float* dKT = nullptr;          // sort-key table (sort_kernels.hip.h)
+    // Sorting the items of a batch by their nulls in front of the gated scan (sort_kernels.hip.h), while that scan reports many fired tiles
+    uint16_t* dKeys = nullptr;
+    uint32_t* dHist = nullptr;     // items per key (KEY_BUCKETS)
+    uint32_t* dCursor = nullptr;   // items per range of keys (KEY_BLOCKS)
+    uint32_t* dPerm = nullptr;
+    uint32_t sort_cap = 0;         // items dKeys / dPerm hold
+    unsigned long long* dFire = nullptr;        // [2] exact evaluations / (row group, tile) pairs walked by the gated scan of the call in flight
+    unsigned long long* hFire = nullptr;        // page-locked [4]: the same of a FINISHED call, [2] = its tag (call number << 1 | sorted), written by its merge
+    unsigned long long* hFireDev = nullptr;     // ... its device address
+    unsigned long long fire_calls = 0, fire_seen = 0;
+    int sort_mode = 0;             // 0 never (the product), 1 always, -1 adaptive -- LAB builds only (BAZ_MUSIC_SORT).  Measured and not shipped:
+                                   // the order cuts the exact evaluations of an incoherent batch from 22 % to 4.6 % of the tile pairs, but key + sort cost
+                                   // 0.17 ms (0.08 with a library radix sort) of the 0.22 ms the scan gains (profiles/r05_sort_negative.txt)
+    bool sort_on = false;
+    uint32_t sort_streak = 0;
+    uint64_t sort_clock = 0, sort_retry_at = 0;
+    double rate_unsorted = 0.0;
+    uint64_t sorted_calls = 0, unsorted_calls = 0;     // (tap: baz_music_debug_sort_state)
+    bool last_gated_sorted = false;
     int seq_walk = 0;              // lab (BAZ_MUSIC_SEQ_WALK=1): scan_mfma_kernel walks its steps left to right (round 4's order; A/B of the strided walk)
     int i8p_on = 0;                // LAB builds only (BAZ_MUSIC_I8P=1): the level-packed int8 scan at m <= 4.  Measured and not shipped
                                    // (profiles/r05_i8p_negative.txt): its arithmetic is 0.31 ms against the fp64 scan's 0.56, but the spectrum
@@ -768,6 +790,93 @@ CoarseGeom coarse_geometry(const baz_music_ctx* c, uint32_t batch)
     return G;
 }
 
+// ---- sorting in front of the gated scan (sort_kernels.hip.h) --------------------------------------------------------------------------
+constexpr uint32_t SORT_MIN_BATCH = 4096;      // below this a launch is a handful of workgroups either way
+constexpr double SORT_ON_RATE = 0.06;          // share of (row group, tile) pairs an UNSORTED call evaluated exactly above which sorting pays
+constexpr uint32_t SORT_PROBE_EVERY = 64;      // while sorting: every so many calls one call unsorted, whose statistic decides anew
+
+int ensure_sort_workspace(baz_music_ctx* c, uint32_t batch)
+{
+    if (!c->dFire) {
+        HIP_TRY(c, hipMalloc((void**)&c->dFire, 2 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemset(c->dFire, 0, 2 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipHostMalloc((void**)&c->hFire, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+        std::memset(c->hFire, 0, 4 * sizeof(unsigned long long));
+        HIP_TRY(c, hipHostGetDevicePointer((void**)&c->hFireDev, c->hFire, 0));
+    }
+    if (c->sort_mode == 0 || !c->dKT) return BAZ_MUSIC_OK;       // the product never sorts: only the fire statistic above
+    if (!c->dHist) {
+        HIP_TRY(c, hipMalloc((void**)&c->dHist, bazsort::KEY_BUCKETS * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void**)&c->dCursor, bazsort::KEY_BUCKETS * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemset(c->dHist, 0, bazsort::KEY_BUCKETS * sizeof(uint32_t)));
+    }
+    if (batch > c->sort_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->dKeys) (void)hipFree(c->dKeys);
+        if (c->dPerm) (void)hipFree(c->dPerm);
+        c->dKeys = nullptr; c->dPerm = nullptr; c->sort_cap = 0;
+        const uint32_t cap = round_up(batch, 4096);
+        HIP_TRY(c, hipMalloc((void**)&c->dKeys, (size_t)cap * sizeof(uint16_t)));
+        HIP_TRY(c, hipMalloc((void**)&c->dPerm, (size_t)cap * sizeof(uint32_t)));
+        c->sort_cap = cap;
+    }
+    return BAZ_MUSIC_OK;
+}
+
+// Sort this call's items?  The gated scan's merge leaves, in page-locked memory, how many of its (row group, tile) pairs were evaluated exactly and
+// whether that call was sorted; the answer of some EARLIER call is there when this one is launched (nothing waits for it).
+//   * an unsorted call with a high share starts a trial (sorting on);
+//   * a sorted call must bring the share clearly below the unsorted one (x 0.6), else sorting goes off again and is not tried for a while
+//     (a small coherent batch cut into many bin ranges has a high share that no order improves);
+//   * while sorting, every SORT_PROBE_EVERY-th call runs unsorted: a low share there (the stream turned coherent) switches it off.
+// Up to 4 antennas (the rows' coefficients sit in registers; from 5 on the exact tiles fetch them from L2, where an index list costs gathers).
+bool sort_decide(baz_music_ctx* c, uint32_t batch)
+{
+    if (batch < SORT_MIN_BATCH || !c->dKT || !c->hFire || c->m > 4 || c->n > 2 || c->coarse_rg == 2 || c->coarse_lab) return false;
+    if (c->sort_mode >= 0) return c->sort_mode != 0;
+    ++c->sort_clock;
+    const unsigned long long tag = reinterpret_cast<volatile unsigned long long*>(c->hFire)[2];
+    if (tag != c->fire_seen) {
+        c->fire_seen = tag;
+        const unsigned long long fired = reinterpret_cast<volatile unsigned long long*>(c->hFire)[0];
+        const unsigned long long walked = reinterpret_cast<volatile unsigned long long*>(c->hFire)[1];
+        const double rate = walked ? (double)fired / (double)walked : 0.0;
+        if (tag & 1ull) {                              // a sorted call
+            if (c->sort_on && rate > 0.6 * c->rate_unsorted) {
+                c->sort_on = false;
+                c->sort_retry_at = c->sort_clock + 512;
+            }
+        } else {
+            c->rate_unsorted = rate;
+            if (rate <= SORT_ON_RATE) c->sort_on = false;
+            else if (!c->sort_on && c->sort_clock >= c->sort_retry_at) c->sort_on = true;
+        }
+    }
+    if (c->sort_on && ++c->sort_streak >= SORT_PROBE_EVERY) {
+        c->sort_streak = 0;
+        return false;                                  // the probe
+    }
+    return c->sort_on;
+}
+
+template <int M>
+int launch_sort_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t batch)
+{
+    if constexpr (M <= 8) {
+        const uint32_t ns = bazsort::key_samples(c->res);
+        const uint32_t padded = round_up(batch, 256);          // whole workgroups of the key kernel = whole 8-key loads of the sweeps
+        hipLaunchKernelGGL((bazsort::coarse_key_kernel<M>), dim3(padded / 256), dim3(256), 0, c->stream, dQ, c->dKT, ns, batch, qstride, c->dKeys);
+        HIP_TRY(c, hipGetLastError());
+        hipLaunchKernelGGL((bazsort::key_sweep_kernel<false>), dim3(bazsort::KEY_BLOCKS), dim3(256), 0, c->stream, c->dKeys, padded / 8, c->dHist,
+                           c->dCursor, c->dPerm);
+        HIP_TRY(c, hipGetLastError());
+        hipLaunchKernelGGL((bazsort::key_sweep_kernel<true>), dim3(bazsort::KEY_BLOCKS), dim3(256), 0, c->stream, c->dKeys, padded / 8, c->dHist,
+                           c->dCursor, c->dPerm);
+        HIP_TRY(c, hipGetLastError());
+    }
+    return BAZ_MUSIC_OK;
+}
+
 template <int M, int NMAX>
 int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t batch, float* d_ang,
                   float* d_lvl, float* d_spec)
@@ -783,8 +892,26 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             rf.count = c->refine_nocount ? nullptr : c->dRefined + c->stat_parity;
             rf.A2 = nullptr;
             unsigned long long* stats = c->coarse_stats ? c->dMargin : nullptr;     // lab: exact tile evaluations, summed over launches
+            // the items in an order in which neighbours share their nulls, while the scan's own statistic says that pays (sort_decide)
+            int sr = ensure_sort_workspace(c, batch);
+            if (sr) return sr;
+            const bool sorted = sort_decide(c, batch);
+            if (sorted) {
+                sr = launch_sort_t<M>(c, dQ, qstride, batch);
+                if (sr) return sr;
+                ++c->sorted_calls;
+            } else {
+                ++c->unsorted_calls;
+            }
+            c->last_gated_sorted = sorted;
+            const uint32_t* perm = sorted ? c->dPerm : nullptr;
 #define BAZ_COARSE_ARGS dim3(CG.groups * CG.nsplit), dim3(256), 0, c->stream, dQ, c->dCS, c->dCS + (size_t)(c->cs_tiles + 1) * cs_c_units(M), \
-                        c->dCand, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, stats, nullptr
+                        c->dCand, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, stats, nullptr, perm, c->dFire
+#ifdef BAZ_MUSIC_LAB
+            if (c->sort_mode != 0 && M <= 4 && CG.tpp != 4 && !c->coarse_lab) {        // lab (BAZ_MUSIC_SORT): the index list and the fire statistic
+                if constexpr (M <= 4) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8, false, 0, true>), BAZ_COARSE_ARGS);
+            } else
+#endif
             if constexpr (M > 4) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, coarse_rg_wide(M, NMAX), 4>), BAZ_COARSE_ARGS);
             else if (CG.tpp == 4) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 2, 4>), BAZ_COARSE_ARGS);
 #ifdef BAZ_MUSIC_LAB
@@ -974,8 +1101,11 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
 template <int NMAX>
 int launch_merge_t(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl, float* d_spec)
 {
+    const bool gated = c->scan_kind == 2 && c->dFire && c->hFireDev;       // the gated scan just ran: its fire statistic travels with this merge
+    const unsigned long long tag = gated ? ((++c->fire_calls) << 1) | (c->last_gated_sorted ? 1ull : 0ull) : 0ull;
     hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream, c->dCand,
-                       d_spec, d_ang, d_lvl, batch, c->res, c->n, c->last_nsplit, c->keep_mask, c->dRefined + (c->stat_parity ^ 1));
+                       d_spec, d_ang, d_lvl, batch, c->res, c->n, c->last_nsplit, c->keep_mask, c->dRefined + (c->stat_parity ^ 1),
+                       gated ? c->dFire : nullptr, gated ? c->hFireDev : nullptr, tag);
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
 }
@@ -1275,6 +1405,8 @@ int alloc_table_set(baz_music_ctx* c, TableSet& T)
     if (hipMalloc((void**)&T.dFB, pad_steps * c->fb_step_elems * sizeof(double2)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     if (hipMalloc((void**)&T.dTB, pad_steps * c->tb_step_elems * sizeof(double2)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     if (c->m <= 8 && hipMalloc((void**)&T.dCS, coarse_image_bytes(c)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (c->m <= 8 && c->sort_mode != 0 &&            // (lab: the sort key's table)
+        hipMalloc((void**)&T.dKT, (size_t)bazsort::key_samples(c->res) * c->m * c->m * sizeof(float)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     if (wants_i8_image(c) && hipMalloc((void**)&T.dIB, i8_image_bytes(c->m, c->fb_steps)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     if (c->i8p_on && c->m <= 4 && c->n <= 4 && hipMalloc((void**)&T.dIP, i8p_image_bytes(c->fb_steps)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     if (short_form_applies(c->m, c->n) && hipMalloc((void**)&T.dA2p, pad_steps * 64 * sizeof(double)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
@@ -1288,6 +1420,7 @@ void free_table_set(TableSet& T)
     if (T.dCS) (void)hipFree(T.dCS);
     if (T.dIB) (void)hipFree(T.dIB);
     if (T.dIP) (void)hipFree(T.dIP);
+    if (T.dKT) (void)hipFree(T.dKT);
     if (T.dA2p) (void)hipFree(T.dA2p);
     if (T.dTA) (void)hipFree(T.dTA);
     if (T.dA2) (void)hipFree(T.dA2);
@@ -1300,6 +1433,7 @@ TableSet active_table_set(const baz_music_ctx* c)
     TableSet T;
     T.dFB = c->dFB; T.dTB = c->dTB; T.dCS = c->dCS; T.dIB = c->dIB; T.dA2p = c->dA2p; T.dTA = c->dTA; T.dA2 = c->dA2;
     T.dIP = c->dIP;
+    T.dKT = c->dKT;
     T.cs = c->cs; T.i8 = c->i8; T.cs_ok = c->cs_ok; T.i8_ok = c->i8_ok; T.refine_below = c->refine_below;
     return T;
 }
@@ -1307,6 +1441,7 @@ void install_table_set(baz_music_ctx* c, const TableSet& T)
 {
     c->dFB = T.dFB; c->dTB = T.dTB; c->dCS = T.dCS; c->dIB = T.dIB; c->dA2p = T.dA2p; c->dTA = T.dTA; c->dA2 = T.dA2;
     c->dIP = T.dIP;
+    c->dKT = T.dKT;
     c->cs = T.cs; c->i8 = T.i8; c->cs_ok = T.cs_ok; c->i8_ok = T.i8_ok; c->refine_below = T.refine_below;
 }
 
@@ -1345,6 +1480,11 @@ int build_tables_device(baz_music_ctx* c, TableSet& T)
     }
     if (T.dTA) {
         hipLaunchKernelGGL(baztab::build_ta_kernel, grid_for((size_t)m * res), dim3(256), 0, s, reinterpret_cast<const float2*>(c->dRaw), m, res, T.dTA);
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (T.dKT) {
+        const uint32_t ns = bazsort::key_samples(res);
+        hipLaunchKernelGGL(bazsort::build_key_table_kernel, grid_for((size_t)ns * m * m), dim3(256), 0, s, c->dRaw, m, res, ns, T.dKT);
         HIP_TRY(c, hipGetLastError());
     }
     if (T.dCS) HIP_TRY(c, hipMemsetAsync(T.dCS, 0, coarse_image_bytes(c), s));
@@ -1861,6 +2001,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (const char* v = getenv("BAZ_MUSIC_EXACT")) c->i8_on = atoi(v) ? 0 : 1;                // A/B: 1 = the fp64 scan everywhere
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8_ABL")) c->i8_abl = atoi(v);                  // lab
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SEQ_WALK")) c->seq_walk = atoi(v) ? 1 : 0;        // lab
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SORT")) c->sort_mode = atoi(v) < 0 ? -1 : (atoi(v) ? 1 : 0);   // lab / tests: 0 never, 1 always
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COVEVD_TASK_ITEMS")) { const int t = atoi(v); c->covevd_task_items = (t == 64 || t == 32 || t == 16) ? t : 0; }
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8P")) c->i8p_on = atoi(v) ? 1 : 0;             // lab: 1 = the level-packed int8 scan at m <= 4
         if (wants_i8_image(c) || (c->i8p_on && m <= 4 && n <= 4)) {
@@ -1929,6 +2070,12 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->hTabStats) (void)hipHostFree(c->hTabStats);
         if (c->ev_swap) (void)hipEventDestroy(c->ev_swap);
         if (c->s_tab) (void)hipStreamDestroy(c->s_tab);
+        if (c->dKeys) (void)hipFree(c->dKeys);
+        if (c->dPerm) (void)hipFree(c->dPerm);
+        if (c->dHist) (void)hipFree(c->dHist);
+        if (c->dCursor) (void)hipFree(c->dCursor);
+        if (c->dFire) (void)hipFree(c->dFire);
+        if (c->hFire) (void)hipHostFree(c->hFire);
         if (c->dCand) (void)hipFree(c->dCand);
         if (c->dR) (void)hipFree(c->dR);
         if (c->dQ) (void)hipFree(c->dQ);
@@ -1996,6 +2143,7 @@ int baz_music_reserve(baz_music_ctx* c, uint32_t max_batch)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->wide) return ensure_wide_workspace(c, std::min(max_batch, wide_pass_items(c)));
     int r = ensure_workspace(c, max_batch);
+    if (r == BAZ_MUSIC_OK && c->dKT) r = ensure_sort_workspace(c, max_batch);
     return r ? r : reserve_candidates(c, max_batch);
 }
 
@@ -2697,6 +2845,19 @@ size_t baz_music_debug_host_table_image(uint32_t m, uint32_t n, uint32_t resolut
     }
     if (out && out_bytes >= bytes.size()) std::memcpy(out, bytes.data(), bytes.size());
     return bytes.size();
+}
+
+// The gated scan's sorting policy: out[0] / out[1] = gated-scan launches that sorted / did not sort their items first, out[2] / out[3] = exact
+// evaluations and (row group, tile) pairs walked of the most recent FINISHED gated launch, out[4] = 1 if that launch was sorted.  Synchronises.
+int baz_music_debug_sort_state(baz_music_ctx* c, uint64_t out[5])
+{
+    if (!c || !out) return BAZ_MUSIC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    out[0] = c->sorted_calls; out[1] = c->unsorted_calls;
+    out[2] = c->hFire ? c->hFire[0] : 0; out[3] = c->hFire ? c->hFire[1] : 0; out[4] = c->hFire ? (c->hFire[2] & 1ull) : 0;
+    return BAZ_MUSIC_OK;
 }
 
 int baz_music_debug_evd(baz_music_ctx* c, const void* d_R, uint32_t batch, void* d_Q)

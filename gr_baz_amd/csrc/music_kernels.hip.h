@@ -1900,12 +1900,25 @@ __global__ __launch_bounds__(256) void topn_merge_kernel(const double* __restric
                                                           const float* __restrict__ spec,
                                                           float* __restrict__ ang, float* __restrict__ lvl,
                                                           uint32_t batch, uint32_t res, uint32_t n, uint32_t nsplit,
-                                                          uint32_t keep_mask, unsigned long long* __restrict__ next_stat)
+                                                          uint32_t keep_mask, unsigned long long* __restrict__ next_stat,
+                                                          unsigned long long* __restrict__ fire_dev = nullptr,
+                                                          unsigned long long* __restrict__ fire_host = nullptr,
+                                                          unsigned long long fire_tag = 0ull)
 {
     const uint32_t it = blockIdx.x * 256 + threadIdx.x;
     // the refinement statistic is double-buffered by call: this launch clears the counter the NEXT call's scan adds to
     // (a hipMemsetAsync per call was a 5-us kernel of its own between two launches)
     if (it == 0 && next_stat) *next_stat = 0ull;
+    // the gated scan's fire statistic of THIS call (scan_coarse_kernel's fstat) goes to a page-locked host word the context's sorting
+    // policy reads at a later call without synchronising: counts first, then the tag (sorted or not, call number), a fence between
+    if (it == 0 && fire_dev && fire_host) {
+        fire_host[0] = fire_dev[0];
+        fire_host[1] = fire_dev[1];
+        fire_dev[0] = 0ull;
+        fire_dev[1] = 0ull;
+        __threadfence_system();
+        fire_host[2] = fire_tag;
+    }
     if (it >= batch) return;
     double key[NMAX];
 #pragma unroll

@@ -166,7 +166,8 @@ __device__ __forceinline__ float row_kth_smallest(float v, const uint32_t k)
 // single exact tile has run.  Without it the thresholds only tighten as the walk happens to pass the minima: on a
 // descending slope of the spectrum EVERY tile beats the list and fires (measured: 0.28 ms per 262,144 coherent cfg2 items,
 // and 0.93 ms -- slower than the full scan -- when every item of a wave has its own scene).  PASS 2: the gated walk.
-template <int M, int NMAX, int RG, int TPP, bool VAL = false, int LAB = 0>
+// PERM (lab builds only, sort_kernels.hip.h): rows through an index list and the fire statistic; the product's instantiation has neither.
+template <int M, int NMAX, int RG, int TPP, bool VAL = false, int LAB = 0, bool PERM = false>
 __global__ __launch_bounds__(256, (RG <= 2 && M <= 4) ? 3 : 2) void scan_coarse_kernel(const double* __restrict__ Qs,
                                                                              const uint4* __restrict__ imgC,
                                                                              const uint4* __restrict__ imgX,
@@ -175,8 +176,12 @@ __global__ __launch_bounds__(256, (RG <= 2 && M <= 4) ? 3 : 2) void scan_coarse_
                                                                              uint32_t nsplit, uint32_t keep_mask, uint32_t n,
                                                                              ScanRefine rf, CoarseParams cp,
                                                                              unsigned long long* __restrict__ margin,
-                                                                             float* __restrict__ val_dump = nullptr)
+                                                                             float* __restrict__ val_dump = nullptr,
+                                                                             const uint32_t* __restrict__ perm = nullptr,
+                                                                             unsigned long long* __restrict__ fstat = nullptr)
 {
+    // perm (round 5, sort_kernels.hip.h): row x of the launch is item perm[x] -- the items in an order in which the 16 rows of a group share
+    // their nulls; nullptr: row x is item x.  fstat: [0] += exact (row group, tile) evaluations, [1] += (row group, tile) pairs walked.
     constexpr int MM = M * M;
     constexpr int NGC = cs_groups(M);                  // groups of 16 terms (4 fp64 k-steps each)
     constexpr bool WIDE = MM > 16;                     // 5 <= m <= 8: the coarse operands in groups of 32 terms (see above)
@@ -198,7 +203,12 @@ __global__ __launch_bounds__(256, (RG <= 2 && M <= 4) ? 3 : 2) void scan_coarse_
     const int c = lane & 15, g = lane >> 4;
 
     const uint32_t split = blockIdx.x % nsplit;
-    const uint32_t item0 = ((blockIdx.x / nsplit) * 4 + wave) * (16 * RG);      // first item of the wave
+    const uint32_t item0 = ((blockIdx.x / nsplit) * 4 + wave) * (16 * RG);      // first ROW of the wave (= its item where perm is nullptr)
+    auto item_of = [&](uint32_t row) -> uint32_t {
+        row = (row < batch) ? row : (batch - 1);
+        if constexpr (PERM) return perm ? perm[row] : row;
+        else return row;
+    };
     const uint32_t ph_begin = (uint32_t)(((uint64_t)nphases * split) / nsplit);
     const uint32_t ph_end = (uint32_t)(((uint64_t)nphases * (split + 1)) / nsplit);
 
@@ -210,17 +220,24 @@ __global__ __launch_bounds__(256, (RG <= 2 && M <= 4) ? 3 : 2) void scan_coarse_
     v4f32 es[RG], negthr[RG];  // per accumulator register r (item g + 4 r): error allowance and -threshold, coarse units
     double key[VAL ? 1 : RG][4][NMAX];
     bool row_ok[RG][4];
+    [[maybe_unused]] uint32_t itn_q[RG];     // PERM: the item of natural row c of row group q (else it is recomputed where a rare path needs it)
+    auto row_item = [&](const int q) -> uint32_t {
+        if constexpr (PERM) return itn_q[q];
+        else {
+            const uint32_t it_n = item0 + 16 * (uint32_t)q + (uint32_t)c;
+            return (it_n < batch) ? it_n : (batch - 1);
+        }
+    };
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
-        const uint32_t it_n = item0 + 16 * q + (uint32_t)c;                          // natural row c
-        const uint32_t itn = (it_n < batch) ? it_n : (batch - 1);
+        const uint32_t itn = item_of(item0 + 16 * q + (uint32_t)c);                  // natural row c
+        if constexpr (PERM) itn_q[q] = itn;
 #pragma unroll
         for (int s = 0; s < (XLDS ? 4 : 1); ++s) {
             const int e = 4 * s + g;
             qa[q][s] = (XLDS && e < MM) ? Qs[(size_t)e * qstride + itn] : 0.0;
         }
-        const uint32_t it_p = item0 + 16 * q + (uint32_t)((c >> 2) + 4 * (c & 3));  // permuted row c
-        const uint32_t itp = (it_p < batch) ? it_p : (batch - 1);
+        const uint32_t itp = item_of(item0 + 16 * q + (uint32_t)((c >> 2) + 4 * (c & 3)));  // permuted row c (the MFMA layouts' pi(c))
         // this lane's 8 coefficients per group of the permuted item: m <= 4: e = (8 g + j) & 15 (lanes g = 0, 1 together cover
         // all 16); m >= 5: e = 32 G + 8 g + j (the four g cover a group)
         float qsf[NG2][8], asum = 0.0f;
@@ -440,8 +457,7 @@ __global__ __launch_bounds__(256, (RG <= 2 && M <= 4) ? 3 : 2) void scan_coarse_
                 }
             } else {
                 // both operands from L2: the item's coefficients (natural row c) and the tile's fp64 image
-                const uint32_t it_n = item0 + 16 * q + (uint32_t)c;
-                const double* __restrict__ qp = Qs + ((it_n < batch) ? it_n : (batch - 1)) + (size_t)g * qstride;
+                const double* __restrict__ qp = Qs + row_item(q) + (size_t)g * qstride;
 #pragma unroll
                 for (int s2 = 0; s2 < 2 * NGC; ++s2) {
                     const v2f64 x = *reinterpret_cast<const v2f64*>(X + s2 * 128 + lane * 2);
@@ -476,8 +492,7 @@ __global__ __launch_bounds__(256, (RG <= 2 && M <= 4) ? 3 : 2) void scan_coarse_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) low |= (fabs(acc[r]) <= below_d);
                 if (refine_on && __any(low)) {                  // near-null tile: the reference's literal form, per value
-                    const uint32_t it_n = item0 + 16 * q + (uint32_t)c;
-                    const v4f64 d = literal16<M>(rf.Gs, rf.TB, (it_n < batch) ? it_n : (batch - 1), g, qstride, (int)M - (int)n, bin);
+                    const v4f64 d = literal16<M>(rf.Gs, rf.TB, row_item(q), g, qstride, (int)M - (int)n, bin);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const bool redo = (fabs(acc[r]) <= rf.below) && (bin < res);
@@ -571,6 +586,10 @@ __global__ __launch_bounds__(256, (RG <= 2 && M <= 4) ? 3 : 2) void scan_coarse_
             if (lane == 0 && refined) atomicAdd(rf.count, (unsigned long long)refined);
         }
         if (margin && lane == 0) atomicAdd(margin, (unsigned long long)fired);      // lab (BAZ_MUSIC_COARSE_STATS)
+        if (PERM && fstat && lane == 0) {                                            // what the context's sorting policy reads
+            atomicAdd(fstat, (unsigned long long)fired);
+            atomicAdd(fstat + 1, (unsigned long long)(ph_end - ph_begin) * (unsigned long long)(TPP * RG));
+        }
         // merge the 16 lanes of an item row, emit this range's candidates (topn_merge_kernel folds the ranges)
 #pragma unroll
         for (int q = 0; q < RG; ++q)
@@ -580,8 +599,10 @@ __global__ __launch_bounds__(256, (RG <= 2 && M <= 4) ? 3 : 2) void scan_coarse_
                 key_merge_xor<NMAX>(key[q][r], 2);
                 key_merge_xor<NMAX>(key[q][r], 4);
                 key_merge_xor<NMAX>(key[q][r], 8);
-                const uint32_t it = item0 + 16 * q + (uint32_t)(g + 4 * r);
-                if (c == 0 && it < batch) {
+                const uint32_t row = item0 + 16 * q + (uint32_t)(g + 4 * r);
+                uint32_t it = row;
+                if constexpr (PERM) it = (uint32_t)__shfl((int)itn_q[q], g + 4 * r, 64);    // the item of that row: lane (0, g + 4 r) holds it
+                if (c == 0 && row < batch) {
 #pragma unroll
                     for (int i = 0; i < NMAX; ++i) cand[((size_t)it * nsplit + split) * NMAX + i] = key[q][r][i];
                 }
