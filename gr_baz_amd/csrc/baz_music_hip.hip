@@ -1082,6 +1082,10 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
                 case 6: BAZ_SCAN_LAUNCH(true, true, 1, (1 | 2 | 16)); break;              // everything but the spectrum stores
                 case 7: BAZ_SCAN_LAUNCH(true, true, (8 | 2 | 4), (1 | 2 | 16)); break;    // stores + staging + barriers only
                 case 8: BAZ_SCAN_LAUNCH(true, true, (1 | 2), (1 | 2 | 16)); break;        // MFMA + conversions, no top-n, no stores
+                // (9 - 11, round 5: A/B of the rotating LDS-DMA loader; results are right)
+                case 9: BAZ_SCAN_LAUNCH(true, true, 1024, (1 | 2 | 16)); break;           // rotating loader (negative: profiles/r05_loader_ab.txt)
+                case 10: BAZ_SCAN_LAUNCH(true, true, (1024 | 2048), (1 | 2 | 16)); break;  // rotating loader at 3 waves per SIMD (168 registers: no spills)
+                case 11: BAZ_SCAN_LAUNCH(true, true, 2048, (1 | 2 | 16)); break;          // register staging (the product's) at 3 waves per SIMD
                 default: BAZ_SCAN_LAUNCH(true, true, 0, (1 | 2 | 16)); break;
             }
             HIP_TRY(c, hipGetLastError());

@@ -1522,7 +1522,7 @@ __device__ __forceinline__ uint32_t literal_tile(v4f64 (&acc)[4], const ScanRefi
 // SIG = 2: n = 2 as described; SIG = 1: n = 1, two outputs per item, so a tile holds 8 items (row = item + 4 (2 half + out),
 // registers (0, 1) = item g, (2, 3) = item g + 4) and a wave's 16 items are two groups: a quarter of the work at m = 16.
 template <int M, int NMAX, bool SPEC, bool VEC4, int ABL = 0, int AUX = (1 | 2 | 16), int SIG = 0>
-__global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) void scan_mfma_kernel(const double* __restrict__ Qs,
+__global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? ((ABL & 2048) ? 3 : 4) : (M >= 9 ? 2 : 1)) void scan_mfma_kernel(const double* __restrict__ Qs,
                                                          const double2* __restrict__ FB,
                                                          float* __restrict__ spec,
                                                          double* __restrict__ cand,
@@ -1616,10 +1616,29 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
     const v2f64* __restrict__ fb = reinterpret_cast<const v2f64*>(FB) + (g * 16 + (cc < 0 ? cc + 16 : cc)) -
                                    (cc < 0 ? KS * 2 * 64 : 0);
     const int wave4 = wave & 3;             // 256-thread blocks: lets the compiler fold `chunk < chunks-per-phase`
+    // ROTATING LOADER (round 5, lab only: ABL & 1024).  Every wave fetches a quarter of the next phase into registers and waits for it -- and
+    // vmcnt retires in issue order, so that wait is also a wait for the spectrum stores the wave issued before: every wave drains its own
+    // stores once per step.  The lab form lets ONE wave per phase (they take turns) move the whole phase L2 -> LDS by LDS-DMA and be the only
+    // one that waits.  Measured on one box, 262,144 items: 0.728 - 0.737 ms against 0.724 - 0.725 ms coherent, 0.854 against 0.830 incoherent
+    // (profiles/r05_loader_ab.txt): the drain is not what bounds the walk.  Kept out of the product.
+    constexpr bool ROT = (ABL & 1024) != 0;
+    uint32_t turn = 0;                      // phases staged so far: wave (turn & 3) stages the next one
     v2f64 sreg0 = {0, 0}, sreg1 = {0, 0}, sreg2 = {0, 0}, sreg3 = {0, 0};
     static_assert(SPW <= 4, "a wave stages at most 4 chunks per phase");
     // (lab: ABL & 128 skips the table loads altogether, ABL & 256 issues them non-temporal)
 #define BAZ_FB_LD(IDX) ((ABL & 256) ? __builtin_nontemporal_load(fb + (IDX)) : fb[(IDX)])
+#define BAZ_STAGE_DMA(ST, P, BUF)                                                                \
+    do {                                                                                         \
+        if (wave4 == (int)(turn & 3u)) {                                                         \
+            const int nch__ = 2 * ((KS - (P) * SCH < SCH) ? (KS - (P) * SCH) : SCH);             \
+            const size_t ch0__ = ((size_t)(ST) * KS + (size_t)(P) * SCH) * 2;                    \
+            _Pragma("unroll")                                                                    \
+            for (int j__ = 0; j__ < CPP; ++j__)                                                  \
+                if (j__ < nch__)                                                                 \
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(fb + (ch0__ + j__) * 64), \
+                                                     (__attribute__((address_space(3))) void*)(&stage[(BUF)][j__ * 64]), 16, 0, 0); \
+        }                                                                                        \
+    } while (0)
 #define BAZ_STAGE_LOAD(ST, P)                                                                    \
     do {   /* unconditional loads, index clamped into the phase */                               \
         if constexpr (!(ABL & 128)) {                                                            \
@@ -1641,8 +1660,14 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
     } while (0)
 
     if (st_begin < st_end) {
-        BAZ_STAGE_LOAD(st_begin, 0);
-        BAZ_STAGE_STORE(0, 0);
+        if constexpr (ROT) {
+            BAZ_STAGE_DMA(st_begin, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ++turn;
+        } else {
+            BAZ_STAGE_LOAD(st_begin, 0);
+            BAZ_STAGE_STORE(0, 0);
+        }
     }
     __syncthreads();
 
@@ -1651,14 +1676,15 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
     // spectrum addressing: uniform base = the wave's first row + per-lane 32-bit byte offsets of row r (rows are
     // nclass items apart), minus the class shift; the step offset goes into the SGPR soffset
     float* __restrict__ spec_base = SPEC ? spec + (size_t)item0 * res - sh : nullptr;   // (sh > 0 only for classes k >= 1: item0 >= 1)
-    uint32_t soff[4];
+    uint32_t soff0 = 0;                                              // row g's byte offset; rows g + 4 r add r * row4 through the scalar offset
+    const uint32_t row4 = 4u * nclass * res * 4u;
     // raw buffer over this wave's rows: offsets stay < 16*nclass*res*4 <= 64 MiB (nclass <= 16, res <= 65536)
     [[maybe_unused]] __amdgpu_buffer_rsrc_t spec_rsrc = __builtin_amdgcn_make_buffer_rsrc(spec_base, 0, 0x7FFFFFFF, 0x00020000);
     bool row_ok[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         // BYTE offset, from the shifted base, of bin (64*st - sh + 4c) at st = 0 (lanes with negative bins never store)
-        soff[r] = ((uint32_t)(g + 4 * r) * nclass * res + 4u * (uint32_t)c) * 4u;
+        if (r == 0) soff0 = ((uint32_t)g * nclass * res + 4u * (uint32_t)c) * 4u;
         row_ok[r] = (item0 + nclass * (uint32_t)(g + 4 * r)) < batch;
     }
     // STRIDED WALK (round 5; scan_i8_kernels.hip.h has the measurement): the range's steps in SW interleaved sweeps instead of left to
@@ -1682,7 +1708,8 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
             // 1. fetch this wave's quarter of the NEXT phase from L2 (lands in registers while the MFMAs run)
             const bool last_p = (p == PPS - 1);
             const bool more = !last_p || has_next;                          // wave-uniform
-            if (more) BAZ_STAGE_LOAD(last_p ? st_next : st, last_p ? 0 : p + 1);
+            if constexpr (ROT) { if (more) BAZ_STAGE_DMA(last_p ? st_next : st, last_p ? 0 : p + 1, buf ^ 1); }
+            else { if (more) BAZ_STAGE_LOAD(last_p ? st_next : st, last_p ? 0 : p + 1); }
 
             // 2. this phase: B operands from LDS, MFMAs
             if constexpr (SIG) {
@@ -1788,6 +1815,13 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
                             const v2f64* __restrict__ tbl = reinterpret_cast<const v2f64*>(rf.TB) +
                                 (g * 16 + (cr < 0 ? cr + 16 : cr)) - (cr < 0 ? ((2 * M + 3) / 4) * 2 * 64 : 0);
                             uint32_t cnt = literal_tile<M>(acc, rf, tbl, st, itc, g, qstride, (int)M - (int)n, bin, res, row_ok);
+                            // Round 5: literal_tile() is inlined and its loads land in registers that later hold the store data.  Its values
+                            // are all consumed in there -- but hipcc's wait-count pass merges control flow conservatively, and on the COMMON path
+                            // (no literal tile) it put `s_waitcnt vmcnt(0)` in front of the step's LAST spectrum store: every wave drained its
+                            // first three stores of EVERY step before issuing the fourth (seen in the ISA of rounds 2 - 4).  An explicit wait at the
+                            // end of the rare path tells the pass that nothing is pending when the paths join: the four stores issue back to back
+                            // and drain behind the next step's arithmetic.  (0x0F70: vmcnt(0), gfx9 encoding.)
+                            __builtin_amdgcn_s_waitcnt(0x0F70);
                             if constexpr (SPEC && !(ABL & 4)) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r)
@@ -1824,7 +1858,13 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
             }
 
             // 4. publish the next phase (waits only for the stage loads and the previous step's stores) ...
-            if (more) BAZ_STAGE_STORE(buf ^ 1, last_p ? 0 : p + 1);
+            if constexpr (ROT) {
+                // the loader of this phase waits for its LDS-DMA (and, in passing, for its own earlier stores); nobody else waits
+                if (more && wave4 == (int)(turn & 3u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (more) ++turn;
+            } else {
+                if (more) BAZ_STAGE_STORE(buf ^ 1, last_p ? 0 : p + 1);
+            }
 
             // 5. ... then this step's spectrum stores, then the barrier
             if (last_p) {
@@ -1844,11 +1884,11 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
                         if ((st > 0 || sh == 0) && st * 64 + 64 - sh <= res) { // wave-uniform: whole step inside the row
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                if (row_ok[r]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, AUX);
+                                if (row_ok[r]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff0, step_off + (int)(row4 * (uint32_t)r), AUX);
                         } else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                if (row_ok[r] && bin < res) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff[r], step_off, AUX);
+                                if (row_ok[r] && bin < res) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, sv[r]), spec_rsrc, (int)soff0, step_off + (int)(row4 * (uint32_t)r), AUX);
                         }
                     } else {
 #pragma unroll
@@ -1857,12 +1897,20 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
 #pragma unroll
                             for (int t = 0; t < 4; ++t)
                                 if (row_ok[r] && bin + t < res)
-                                    __builtin_amdgcn_raw_buffer_store_b32(u[t], spec_rsrc, (int)(soff[r] + 4u * t), step_off, AUX);
+                                    __builtin_amdgcn_raw_buffer_store_b32(u[t], spec_rsrc, (int)(soff0 + 4u * t), step_off + (int)(row4 * (uint32_t)r), AUX);
                         }
                     }
                 }
             }
-            __syncthreads();
+            if constexpr (ROT) {
+                // (a raw barrier: __syncthreads() would put a vmcnt(0) in front of it -- the LDS-DMA writes are LDS writes to the compiler --
+                // and make every wave wait for the stores it has just issued; this phase's ds_reads have been consumed by its MFMAs)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            } else {
+                __syncthreads();
+            }
             buf ^= 1;
         }
         st = st_next;
@@ -1889,6 +1937,7 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? 4 : (M >= 9 ? 2 : 1)) 
 }
 
 #undef BAZ_STAGE_LOAD
+#undef BAZ_STAGE_DMA
 #undef BAZ_FB_LD
 #undef BAZ_STAGE_STORE
 
