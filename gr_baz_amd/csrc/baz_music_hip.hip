@@ -203,17 +203,6 @@ struct baz_music_ctx {
     int auto_pin = 0;                                    // baz_music_set_host_pinning
     int zero_copy = 1;                                   // small calls on page-locked memory: no copies (BAZ_MUSIC_ZERO_COPY=0: lab)
     int single_limit_mib = 64;                           // page-locked calls below this much traffic run as ONE chunk (BAZ_MUSIC_SINGLE_MIB)
-    // Host-fed zero-copy calls with port 2 at m = 4 (process_zero_copy_overlapped): the scan of the first items writes over the link while
-    // cov4_evd_kernel still reads the later ones
-    int hostfed_overlap = 1;                             // BAZ_MUSIC_HOSTFED_OVERLAP=0: one launch sequence per call (round 4's form; A/B)
-    uint32_t overlap_cov_blocks = 8;                     // grid of cov4_evd_kernel in such a call: 32 waves keep the link busy and finish 512 items per round
-    uint32_t overlap_group_rounds = 1;                   // rounds of tasks per group of items (one flag, one scan launch)
-    uint32_t overlap_min_items = 1024;                   // smaller calls: one launch sequence
-    hipStream_t s_scan2 = nullptr;                       // the second stream (gate, scan, merge of every group)
-    uint32_t* dDone = nullptr;                           // [OVERLAP_MAX_GROUPS] finished tasks per group, ever-growing
-    uint32_t done_target[64] = {0};                      // what each counter reads once the call in flight has finished its group
-    uint32_t* hGaveUp = nullptr;                         // page-locked: a gate ran into its time limit
-    uint32_t* hGaveUpDev = nullptr;
     StageProf prof[BAZ_MUSIC_NUM_STAGES];
     std::string stage_name[BAZ_MUSIC_NUM_STAGES];
     int scan_kind = -1;     // the scan kernel the LAST launch took: 0 scan_mfma_kernel, 1 scan_i8_kernel, 2 scan_coarse_kernel, 3 scan_i8p_kernel (-1: none yet)
@@ -680,15 +669,9 @@ int launch_evd_t(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ
 
 // m = 4, K % 256 == 0: covariance and EVD in one kernel (cov4_evd_kernel); d_R_dbg optionally receives R (test tap)
 int launch_covevd(baz_music_ctx* c, const float* d_in, uint32_t batch, double* dQ, uint32_t qstride, double* dG,
-                  double2* d_R_dbg = nullptr, uint32_t ordered_blocks = 0, uint32_t* done = nullptr, uint32_t tasks_per_flag = 1)
+                  double2* d_R_dbg = nullptr)
 {
     ProfScope ps(c, BAZ_MUSIC_STAGE_COV);
-    if (ordered_blocks) {   // process_zero_copy_overlapped: 16-item tasks on a small grid, finished groups counted in `done`
-        hipLaunchKernelGGL(cov4_evd_kernel, dim3(ordered_blocks), dim3(256), 0, c->stream, d_in, dQ, dG, d_R_dbg, batch, c->K, c->n,
-                           qstride, 16u, done, tasks_per_flag);
-        HIP_TRY(c, hipGetLastError());
-        return BAZ_MUSIC_OK;
-    }
     // items per wave task: 64 where that still makes >= 256 tasks (one per CU), else 32 / 16 -- a small batch needs more waves reading than
     // lanes rotating (a host-fed 1,024-item call read its input over PCIe at 40 GB/s with 16 waves; cov4_evd_kernel)
     const uint32_t ti = c->covevd_task_items ? (uint32_t)c->covevd_task_items : (batch >= 16384u ? 64u : (batch >= 8192u ? 32u : 16u));
@@ -1859,90 +1842,6 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
     return BAZ_MUSIC_OK;
 }
 
-// A host-fed call on page-locked buffers at m = 4 with port 2 (cfg2's shape): the kernels address the caller's memory over PCIe.  One launch
-// sequence uses the link one direction at a time -- cov4_evd_kernel reads 8 KiB per item, then the scan writes 14.4 KB per item -- and the call
-// takes the sum.  Here the two overlap WITHOUT cross-stream events (two attempts with events lost: each hop costs ~50 us on this stack):
-//   stream 1   cov4_evd_kernel over the whole call on a SMALL grid (overlap_cov_blocks x 4 waves: enough loads in flight for the link), so the
-//              16-item tasks finish in item order, a round of grid x 4 tasks at a time; every finished task counts into its group's flag
-//   stream 2   per group of items: wait_tasks_kernel (one wave spinning on the group's flag), the scan and the merge of the group's items
-// Items are independent (an item's bits never depend on its batch), so the outputs are those of the single sequence bit for bit.
-constexpr uint32_t OVERLAP_MAX_GROUPS = 64;
-
-bool overlap_applies(const baz_music_ctx* c, uint32_t batch, bool want_spec)
-{
-    return c->hostfed_overlap && want_spec && c->fused_covevd && !c->wide && !c->peak_mode && !c->lab_variant && batch >= c->overlap_min_items;
-}
-
-int ensure_overlap_state(baz_music_ctx* c)
-{
-    if (c->s_scan2) return BAZ_MUSIC_OK;
-    HIP_TRY(c, hipMalloc((void**)&c->dDone, OVERLAP_MAX_GROUPS * sizeof(uint32_t)));
-    HIP_TRY(c, hipMemset(c->dDone, 0, OVERLAP_MAX_GROUPS * sizeof(uint32_t)));
-    HIP_TRY(c, hipHostMalloc((void**)&c->hGaveUp, sizeof(uint32_t), hipHostMallocDefault));
-    *c->hGaveUp = 0;
-    HIP_TRY(c, hipHostGetDevicePointer((void**)&c->hGaveUpDev, c->hGaveUp, 0));
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->s_scan2, hipStreamNonBlocking));
-    return BAZ_MUSIC_OK;
-}
-
-// after a call that failed half-way: nothing in flight, counters and targets agree again
-void reset_overlap_state(baz_music_ctx* c)
-{
-    (void)hipStreamSynchronize(c->stream);
-    if (c->s_scan2) (void)hipStreamSynchronize(c->s_scan2);
-    if (c->dDone) (void)hipMemset(c->dDone, 0, OVERLAP_MAX_GROUPS * sizeof(uint32_t));
-    std::memset(c->done_target, 0, sizeof(c->done_target));
-    if (c->hGaveUp) *c->hGaveUp = 0;
-    (void)hipGetLastError();
-}
-
-int process_zero_copy_overlapped(baz_music_ctx* c, const void* z_in, uint32_t batch, float* z_ang, float* z_lvl, float* z_spec)
-{
-    int r = ensure_overlap_state(c);
-    if (r) return r;
-    r = ensure_workspace(c, batch);
-    if (r) return r;
-    r = reserve_candidates(c, batch);
-    if (r) return r;
-    const uint32_t qstride = baz_music_q_stride(batch);
-    const uint32_t ti = 16u;
-    uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>(c->overlap_cov_blocks, c->covevd_blocks));
-    uint32_t group_tasks = blocks * 4u * std::max<uint32_t>(1u, c->overlap_group_rounds);
-    const uint32_t ntasks = (batch + ti - 1u) / ti;
-    while ((ntasks + group_tasks - 1u) / group_tasks > OVERLAP_MAX_GROUPS) group_tasks *= 2u;
-    const uint32_t ngroups = (ntasks + group_tasks - 1u) / group_tasks;
-    r = launch_covevd(c, static_cast<const float*>(z_in), batch, c->dQ, qstride, c->dG, nullptr, blocks, c->dDone, group_tasks);
-    if (r) { reset_overlap_state(c); return r; }
-    // the groups' scans: on the second stream, with the workspace pointers moved to the group's first item
-    hipStream_t const s1 = c->stream;
-    double* const dG0 = c->dG;
-    for (uint32_t g = 0; g < ngroups && r == BAZ_MUSIC_OK; ++g) {
-        const uint32_t item0 = g * group_tasks * ti;
-        const uint32_t nb = std::min<uint32_t>(batch - item0, group_tasks * ti);
-        c->done_target[g] += (nb + ti - 1u) / ti;
-        hipLaunchKernelGGL(wait_tasks_kernel, dim3(1), dim3(64), 0, c->s_scan2, c->dDone + g, c->done_target[g], 200000000ull /* 2 s */,
-                           c->hGaveUpDev);
-        if (hipGetLastError() != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
-        c->stream = c->s_scan2;
-        c->dG = dG0 + item0;
-        r = launch_scan(c, c->dQ + item0, qstride, nb, z_ang + (size_t)item0 * c->n, z_lvl + (size_t)item0 * c->n, z_spec + (size_t)item0 * c->res);
-        if (r == BAZ_MUSIC_OK)
-            r = launch_merge(c, nb, z_ang + (size_t)item0 * c->n, z_lvl + (size_t)item0 * c->n, z_spec + (size_t)item0 * c->res);
-        c->stream = s1;
-        c->dG = dG0;
-    }
-    if (r == BAZ_MUSIC_OK) c->stat_next_clean = true;
-    const hipError_t e2 = hipStreamSynchronize(c->s_scan2), e1 = hipStreamSynchronize(c->stream);
-    if (r == BAZ_MUSIC_OK && e2 != hipSuccess) r = hip_fail(c, e2, "hipStreamSynchronize(scan stream)");
-    if (r == BAZ_MUSIC_OK && e1 != hipSuccess) r = hip_fail(c, e1, "hipStreamSynchronize");
-    if (r == BAZ_MUSIC_OK && *c->hGaveUp) {
-        snprintf(c->hip_err, sizeof(c->hip_err), "host-fed call: a group of items was not finished by cov4_evd_kernel within 2 s");
-        r = BAZ_MUSIC_E_HIP;
-    }
-    if (r != BAZ_MUSIC_OK) reset_overlap_state(c);
-    return r;
-}
-
 int ensure_h_al_big(baz_music_ctx* c, size_t floats)
 {
     if (floats <= c->h_al_big_cap) return BAZ_MUSIC_OK;
@@ -2016,10 +1915,6 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     if (const char* v = getenv("BAZ_MUSIC_CHUNK_MIB")) c->chunk_bytes = (size_t)std::max(1, std::min(1024, atoi(v))) << 20;
     if (const char* v = getenv("BAZ_MUSIC_PIN_LIMIT_MIB")) c->pin_limit = (uint64_t)std::max(0, atoi(v)) << 20;
     if (const char* v = getenv("BAZ_MUSIC_ZERO_COPY")) c->zero_copy = atoi(v) != 0;
-    if (const char* v = getenv("BAZ_MUSIC_HOSTFED_OVERLAP")) c->hostfed_overlap = atoi(v) != 0;
-    if (const char* v = getenv("BAZ_MUSIC_OVERLAP_COV_BLOCKS")) c->overlap_cov_blocks = (uint32_t)std::max(1, atoi(v));
-    if (const char* v = getenv("BAZ_MUSIC_OVERLAP_GROUP_ROUNDS")) c->overlap_group_rounds = (uint32_t)std::max(1, atoi(v));
-    if (const char* v = getenv("BAZ_MUSIC_OVERLAP_MIN_ITEMS")) c->overlap_min_items = (uint32_t)std::max(1, atoi(v));
     if (const char* v = getenv("BAZ_MUSIC_SINGLE_MIB")) c->single_limit_mib = std::max(1, std::min(1024, atoi(v)));
     DeviceGuard guard(dev);
     int r = BAZ_MUSIC_OK;
@@ -2166,9 +2061,6 @@ void baz_music_destroy(baz_music_ctx* c)
         for (auto& p : c->prof)
             for (auto e : p.ev) (void)hipEventDestroy(e);
         if (c->h_al_big) (void)hipHostFree(c->h_al_big);
-        if (c->s_scan2) { (void)hipStreamSynchronize(c->s_scan2); (void)hipStreamDestroy(c->s_scan2); }
-        if (c->dDone) (void)hipFree(c->dDone);
-        if (c->hGaveUp) (void)hipHostFree(c->hGaveUp);
         if (c->s_tab) (void)hipStreamSynchronize(c->s_tab);
         {
             TableSet act = active_table_set(c);
@@ -2353,7 +2245,10 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
     // A launch sequence uses the link in one direction at a time (a 1,024-item config-2 call: 0.21 ms in, then 0.26 ms out), and round 5
     // tried twice to overlap the two inside a call -- sub-chunks alternating between two contexts with event-staggered kernels, and the
     // input of sub-chunk i + 1 by DMA on a side stream beside the kernels of sub-chunk i.  Both LOSE at every call size: each sub-chunk
-    // costs 0.1 - 0.17 ms of copy start-up and cross-stream event hops on this stack (profiles/r05_hostfed_calls.txt).  What pays is a
+    // costs 0.1 - 0.17 ms of copy start-up and cross-stream event hops on this stack (profiles/r05_hostfed_calls.txt).  A third form without
+    // events (finished groups of items counted by cov4_evd_kernel, their scans on a second stream behind a spinning one-wave gate) ran the
+    // two side by side and gained nothing: kernel-issued reads and writes of host memory share most of one budget (75.8 GB/s in + out
+    // against 56 / 53 alone; the covariance took twice as long beside a scan; profiles/r05_hostfed_overlap_negative.txt).  What pays is a
     // larger call (the host block's look-back) and more, shorter covariance tasks for small batches (launch_covevd).
     if (single && locked && c->zero_copy) {
         void *z_in = nullptr, *z_spec = nullptr, *z_al = nullptr;
@@ -2371,16 +2266,11 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
                 if (zr == BAZ_MUSIC_OK) zr = reserve_candidates(c, batch);
             }
             if (zr == BAZ_MUSIC_OK) zr = begin_statistic(c);
-            if (zr == BAZ_MUSIC_OK && overlap_applies(c, batch, want_spec)) {
-                zr = process_zero_copy_overlapped(c, z_in, batch, z_ang, z_ang + (size_t)batch * c->n, static_cast<float*>(z_spec));
-                if (zr != BAZ_MUSIC_OK) return zr;
-            } else {
             if (zr == BAZ_MUSIC_OK)
                 zr = process_device_locked(c, z_in, batch, z_ang, z_ang + (size_t)batch * c->n, want_spec ? z_spec : nullptr);
             const hipError_t es = hipStreamSynchronize(c->stream);   // also after a failed launch
             if (zr == BAZ_MUSIC_OK && es != hipSuccess) zr = hip_fail(c, es, "hipStreamSynchronize");
             if (zr != BAZ_MUSIC_OK) return zr;
-            }
             const size_t cnt = (size_t)batch * c->n;
             memcpy(ang, c->h_al_big, cnt * 4);
             if (lvl) memcpy(lvl, c->h_al_big + cnt, cnt * 4);

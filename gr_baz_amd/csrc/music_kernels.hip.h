@@ -585,13 +585,8 @@ __global__ __launch_bounds__(64) void evd_proj_kernel(const double2* __restrict_
 __global__ __launch_bounds__(256) void cov4_evd_kernel(const float* __restrict__ in, double* __restrict__ Qs,
                                                        double* __restrict__ Gs, double2* __restrict__ Rdbg,
                                                        uint32_t batch, uint32_t K, uint32_t n, uint32_t qstride,
-                                                       uint32_t task_items = 64, uint32_t* __restrict__ done = nullptr,
-                                                       uint32_t tasks_per_flag = 1)
+                                                       uint32_t task_items = 64)
 {
-    // done (round 5, host-fed calls only; nullptr otherwise): after a task's Q / G are written its wave adds 1 to done[task / tasks_per_flag].
-    // With a grid of FEW waves the tasks finish in item order, round by round (gridDim.x * 4 tasks at a time), and a second stream scans the
-    // items of flag k -- writing their spectrum rows over the link -- while this kernel still reads the later items over it
-    // (wait_tasks_kernel; baz_music_hip.hip: process_zero_copy_overlapped).
     // task_items (64, 32 or 16; round 5): items per wave task.  64 fills the lane-per-item EVD; a SMALL batch -- a host-fed work() call of
     // 1,024 items is 16 tasks of 64 = 16 waves with 8 KiB in flight each, too little to keep a PCIe link (or HBM) busy -- is cut into more,
     // shorter tasks (the EVD then runs on fewer lanes: its latency is what it was).  Items are independent: no result depends on it.
@@ -693,28 +688,6 @@ __global__ __launch_bounds__(256) void cov4_evd_kernel(const float* __restrict__
             evd_project_lane<4>(getR, (uint32_t)lane < nit, item0 + lane, n, qstride, Qs, Gs);
         }
         wave_lds_fence();
-        if (done) {                                              // (wave-uniform)
-            __threadfence();                                     // the wave's Q / G stores are visible device-wide before the count
-            if (lane == 0) atomicAdd(done + task / tasks_per_flag, 1u);
-        }
-    }
-}
-
-// One wave that returns once `*done` has reached `target` (counters only grow; the comparison survives their wrap-around): put in FRONT of the
-// scan of a group of items on a second stream, it holds that stream back until cov4_evd_kernel -- running on the first -- has finished
-// the group.  No cross-stream event: those cost ~50 us each on this stack (profiles/r05_hostfed_two_lanes_negative.txt), a spinning wave notices
-// within a microsecond.  A wait that lasts longer than `timeout_ticks` of the 100-MHz clock gives up and reports (the host then fails the call).
-__global__ __launch_bounds__(64) void wait_tasks_kernel(const uint32_t* __restrict__ done, uint32_t target, unsigned long long timeout_ticks,
-                                                        uint32_t* __restrict__ gave_up)
-{
-    if (threadIdx.x != 0) return;
-    const unsigned long long t0 = wall_clock64();
-    while ((int32_t)(__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-        __builtin_amdgcn_s_sleep(16);
-        if (wall_clock64() - t0 > timeout_ticks) {
-            __hip_atomic_store(gave_up, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            return;
-        }
     }
 }
 
