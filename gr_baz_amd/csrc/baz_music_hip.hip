@@ -1086,6 +1086,8 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
                 case 9: BAZ_SCAN_LAUNCH(true, true, 1024, (1 | 2 | 16)); break;           // rotating loader (negative: profiles/r05_loader_ab.txt)
                 case 10: BAZ_SCAN_LAUNCH(true, true, (1024 | 2048), (1 | 2 | 16)); break;  // rotating loader at 3 waves per SIMD (168 registers: no spills)
                 case 11: BAZ_SCAN_LAUNCH(true, true, 2048, (1 | 2 | 16)); break;          // register staging (the product's) at 3 waves per SIMD
+                case 12: BAZ_SCAN_LAUNCH(true, true, 4096, (1 | 2 | 16)); break;          // blocks in the compact order (negative: profiles/r05_write_order.txt)
+                case 13: BAZ_SCAN_LAUNCH(true, true, (8 | 2 | 4 | 4096), (1 | 2 | 16)); break;   // stores + staging + barriers only, compact order
                 default: BAZ_SCAN_LAUNCH(true, true, 0, (1 | 2 | 16)); break;
             }
             HIP_TRY(c, hipGetLastError());

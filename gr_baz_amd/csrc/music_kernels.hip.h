@@ -1547,7 +1547,15 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? ((ABL & 2048) ? 3 : 4)
     // wave task = (16 rows of one class, range of 64-bin steps); the 4 waves of a block take 4 consecutive row groups
     // of the SAME class (rows_per_class is a multiple of 64) and the same step range.
     const uint32_t split = blockIdx.x % nsplit;
-    const uint32_t p0 = ((blockIdx.x / nsplit) * 4 + wave) * 16;     // first row of the wave in class-major order
+    // ORDER of the blocks: class by class -- the first quarter of a launch writes every fourth row of the WHOLE spectrum, the next quarter the rows
+    // between them.  Round 5 tried the compact order (consecutive blocks = the nclass classes of the same 64 x nclass items; ABL & 4096, lab) on
+    // the evidence of scripts/ubench_write_order.hip (a plain fill written in a compact moving window runs at 6.8 - 7.0 TB/s, the same bytes
+    // grid-strided at 4.9 - 5.9): THIS kernel's stores alone take 0.566 ms class by class and 0.68 ms in the compact order, the whole scan
+    // 0.706 against 0.712 (profiles/r05_write_order.txt).  Class by class stays.
+    const uint32_t blk = blockIdx.x / nsplit;
+    uint32_t p0;                                                     // first row of the wave in class-major numbering
+    if constexpr ((ABL & 4096) == 0) p0 = (blk * 4 + wave) * 16;
+    else p0 = (blk % nclass) * rows_per_class + ((blk / nclass) * 4 + wave) * 16;
     const uint32_t cls = __builtin_amdgcn_readfirstlane(p0 / rows_per_class);
     const uint32_t j0 = p0 - cls * rows_per_class;
     const uint32_t sh = ((res & 63u) * cls) & 63u;                   // bins: row start of the class inside its 256-B window

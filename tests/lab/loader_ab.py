@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 M, NE, N, RES, B = 4, 2, 1024, 3600, 262144
 arr = synth.array_geometry(M)
 table = np.array(calculate_antenna_array_response([[0.5 * x, 0.5 * y] for x, y in arr], RES, 1.0)).astype(np.complex64)
-NAMES = {0: "register staging (product)", 9: "rotating LDS-DMA loader", 10: "rotating loader, 3 waves/SIMD", 11: "register staging, 3 waves/SIMD"}
+NAMES = {6: "everything but the stores", 7: "stores + staging only", 13: "stores + staging only, compact order", 12: "blocks in the compact order", 0: "the product (class by class)", 9: "rotating LDS-DMA loader", 10: "rotating loader, 3 waves/SIMD", 11: "register staging, 3 waves/SIMD"}
 for scene, snr in (("coherent", 20.0), ("incoherent", 20.0)):
     if scene == "incoherent":
         x = synth.synth_scenes(torch, dev, B, M, N, arr, synth.C_LIGHT, 0.5, NE, snr_db=snr, seed=1007)
@@ -25,7 +25,7 @@ for scene, snr in (("coherent", 20.0), ("incoherent", 20.0)):
     spec = torch.zeros(B, RES, dtype=torch.float32, device=dev)
     ref = None
     for rep in range(2):
-        for var in (0, 9, 11, 10):
+        for var in [int(v) for v in os.environ.get('AB_VARIANTS', '0,9,11,10').split(',')]:
             os.environ["BAZ_MUSIC_SCAN_VARIANT"] = str(var)
             with capi.Context(M, NE, N, RES, table, lab=True) as ctx:
                 ctx.reserve(B)
