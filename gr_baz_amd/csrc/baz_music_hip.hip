@@ -21,6 +21,7 @@
 #include <cstring>
 #include <unistd.h>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <string>
 #include <vector>
@@ -1453,6 +1454,23 @@ void install_table_set(baz_music_ctx* c, const TableSet& T)
 
 inline dim3 grid_for(size_t threads) { return dim3((unsigned)((threads + 255) / 256)); }
 
+// Waits for a short piece of work on `s` by polling: a blocking hipStreamSynchronize sleeps on an interrupt after a brief spin, and on this stack
+// such a sleep now and then lasts 5 - 11 ms when another thread of the process is waiting for its own stream at the same time (1 retune in ~100
+// at config 3).  The table builders take 0.1 - 0.3 ms: poll for up to 3 ms, then fall back to the blocking wait.
+hipError_t wait_stream_polling(hipStream_t s)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) {
+            (void)hipGetLastError();
+            return hipStreamSynchronize(s);
+        }
+        std::this_thread::yield();
+    }
+}
+
 // Builds every image of the table in c->hRaw into `T` on c->s_tab and WAITS for them (the caller holds c->tab_mtx, not c->mtx):
 // raw table H2D, the three scalars (table_stats_kernel, one small D2H), the parameters on the host, the image kernels.
 int build_tables_device(baz_music_ctx* c, TableSet& T)
@@ -1460,12 +1478,20 @@ int build_tables_device(baz_music_ctx* c, TableSet& T)
     hipStream_t s = c->s_tab;
     const uint32_t m = c->m, res = c->res, steps = c->fb_steps;
     const size_t raw_bytes = (size_t)res * m * 2 * sizeof(float);
-    HIP_TRY(c, hipMemcpyAsync(c->dRaw, c->hRaw, raw_bytes, hipMemcpyHostToDevice, s));
+    // (no copy engines on this path: copy_words_kernel reads the page-locked staging copy over the link, see table_kernels.hip.h)
+    void *zRaw = nullptr, *zStats = nullptr;
+    HIP_TRY(c, hipHostGetDevicePointer(&zRaw, c->hRaw, 0));
+    HIP_TRY(c, hipHostGetDevicePointer(&zStats, c->hTabStats, 0));
+    hipLaunchKernelGGL(baztab::copy_words_kernel, dim3((unsigned)std::min<size_t>(512, (raw_bytes / 8 + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const unsigned long long*>(zRaw), reinterpret_cast<unsigned long long*>(c->dRaw), raw_bytes / 8);
+    HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemsetAsync(c->dTabStats, 0, sizeof(baztab::TableStats), s));
     hipLaunchKernelGGL(baztab::table_stats_kernel, grid_for(res), dim3(256), 0, s, c->dRaw, m, res, c->wide ? 0 : 1,
                        static_cast<baztab::TableStats*>(c->dTabStats));
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->hTabStats, c->dTabStats, sizeof(baztab::TableStats), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(baztab::copy_words_kernel, dim3(1), dim3(256), 0, s, static_cast<const unsigned long long*>(c->dTabStats),
+                       static_cast<unsigned long long*>(zStats), sizeof(baztab::TableStats) / 8);
+    HIP_TRY(c, hipGetLastError());
     // (meanwhile: the images that need no scalar)
     const size_t pad_steps = (size_t)steps + 2;
     if (T.dFB) {
@@ -1495,7 +1521,7 @@ int build_tables_device(baz_music_ctx* c, TableSet& T)
     }
     if (T.dCS) HIP_TRY(c, hipMemsetAsync(T.dCS, 0, coarse_image_bytes(c), s));
     if (T.dIB) HIP_TRY(c, hipMemsetAsync(T.dIB, 0, i8_image_bytes(m, steps), s));
-    HIP_TRY(c, hipStreamSynchronize(s));                 // the scalars are on the host
+    HIP_TRY(c, wait_stream_polling(s));                  // the scalars are on the host
     const baztab::TableStats st = *static_cast<const baztab::TableStats*>(c->hTabStats);
     double fmax, amax2;
     std::memcpy(&fmax, &st.fmax_bits, sizeof(double));
@@ -1541,7 +1567,7 @@ int build_tables_device(baz_music_ctx* c, TableSet& T)
             T.i8_ok = true;
         }
     }
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, wait_stream_polling(s));
     return BAZ_MUSIC_OK;
 }
 

@@ -89,6 +89,14 @@ __host__ __device__ inline double tab_a2(const float* __restrict__ a, uint32_t m
 }
 
 // the three scalars every image's parameters follow from
+// 8-byte words from one buffer to another, either of which may be page-locked HOST memory addressed over the link: the retune path moves its
+// 2.3 MB table and its 24-byte statistic with this kernel instead of hipMemcpyAsync -- once per process the runtime spent 6.6 ms INSIDE that call
+// (a copy-engine queue set up on first contention with another thread's copies), which a stream that must not stall cannot afford.
+__global__ __launch_bounds__(256) void copy_words_kernel(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 struct TableStats {
     unsigned long long fmax_bits;    // bits of max |F| over the finite entries (>= 0: the bits order like the values)
     unsigned long long amax2_bits;   // bits of max ||a||^2 over the bins with ||a||^2 < 1e300
