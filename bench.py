@@ -196,6 +196,9 @@ def time_retunes(np, synth, ctx, table, m, res, arr, step, sync, count=5):
     from gr_baz_amd.baz.music_doa_helper import calculate_antenna_array_response
     t2 = np.array(calculate_antenna_array_response([[SPACING * x, SPACING * y] for x, y in arr], res, lam2)).astype(np.complex64)
     walls, locks = [], []
+    for _ in range(8):          # (the device idled through the oracle check: steps at ramping clocks are not what a retune is measured beside)
+        step()
+    sync()
     for k in range(2 * count):
         step()
         step()
@@ -204,6 +207,8 @@ def time_retunes(np, synth, ctx, table, m, res, arr, step, sync, count=5):
         walls.append((time.perf_counter() - t0) * 1e3)
         locks.append(ctx.last_retune_ms()[1])
     sync()
+    if os.environ.get("BAZ_BENCH_TRACE_RETUNE"):
+        print("retune walls ms:", [round(w, 3) for w in walls], file=sys.stderr)
     return statistics.median(walls), max(walls), max(locks)
 
 
