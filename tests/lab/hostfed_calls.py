@@ -1,6 +1,8 @@
 """Lab (GPU box, lab build): host-fed calls of baz_music_process on PAGE-LOCKED buffers (what work() does under a scheduler whose stream buffers
-the block has locked), cfg2, by call size, one zero-copy launch sequence (0) against the hybrid form (input by DMA per sub-chunk, outputs zero-copy; BAZ_MUSIC_HYBRID_CHUNK_ITEMS).  PCIe-inclusive: not the metric.
-usage: hostfed_calls.py [chunk_items ...]"""
+the block has locked), cfg2, by call size.  Columns: 0 = the library's zero-copy launch sequence; -64 = the same with round 4's 64-item covariance
+tasks (BAZ_MUSIC_COVEVD_TASK_ITEMS, lab build).  (Positive values selected the sub-chunk size of the rejected hybrid form -- input by DMA per sub-chunk,
+outputs zero-copy -- whose code is not kept: profiles/r05_hostfed_calls.txt has its numbers; they now run the library's form.)  PCIe-inclusive: not the metric.
+usage: hostfed_calls.py [0 | -64 ...]"""
 import os
 import sys
 import time
@@ -11,7 +13,7 @@ import torch
 from gr_baz_amd import capi
 from oracle import music_oracle as mo
 
-chunks = [int(v) for v in sys.argv[1:]] or [0, 256, 512, 1024]
+chunks = [int(v) for v in sys.argv[1:]] or [0, -64]
 c = mo.make_config("cfg2", 512)
 m, n, N, res = c["m"], c["n"], c["nsamples"], c["res"]
 BMAX = 8192
@@ -24,7 +26,6 @@ for spec_on in (True, False):
     for B in (256, 512, 1024, 2048, 4096, 8192):
         line = "cfg2 %-12s %5d-item calls:" % ("with port 2" if spec_on else "ang/lvl only", B)
         for ch in chunks:
-            os.environ["BAZ_MUSIC_HYBRID_CHUNK_ITEMS"] = str(max(ch, 0))
             os.environ.pop("BAZ_MUSIC_COVEVD_TASK_ITEMS", None)
             if ch < 0:                       # -64: one zero-copy launch sequence with round 4's 64-item covariance tasks
                 os.environ["BAZ_MUSIC_COVEVD_TASK_ITEMS"] = str(-ch)
