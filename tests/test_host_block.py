@@ -43,6 +43,32 @@ def test_helper_table_is_bit_identical_to_the_reference_loop():
     assert np.array_equal(h.unit_vect(0.3), mo.unit_vect(0.3))
 
 
+def test_helper_table_fast_path_and_its_fallback(monkeypatch):
+    """One numpy.inner over all (step, antenna) pairs forms the phases (a retune at config 3: 0.4 - 1.1 s -> 0.03 - 0.09 s); a sample is recomputed the
+    reference's way and a single differing bit sends the whole table through the per-element loop: either way the complex128 table equals the loop's."""
+    h = _baz().music_doa_helper
+    rng = np.random.default_rng(77)
+    cases = [((rng.random((m, 2)) * 3.0).tolist(), res, float(rng.uniform(0.3, 2.0))) for m, res in ((4, 3600), (8, 9000), (16, 360), (5, 1000), (3, 361), (2, 1), (4, 2))]
+    want = [np.array(mo.calculate_antenna_array_response(arr, res, l)) for arr, res, l in cases]
+    calls = []
+    loop = h._phase_by_element
+    monkeypatch.setattr(h, "_phase_by_element", lambda a, r, l, steps=None: (calls.append(steps is None), loop(a, r, l, steps))[1])
+    for (arr, res, l), w in zip(cases, want):
+        got = np.array(h.calculate_antenna_array_response(arr, res, l))
+        assert np.array_equal(got.view(np.float64), w.view(np.float64))
+    fell_back = any(calls)       # legitimate on a BLAS whose blocked product rounds differently (the table is right either way); not seen so far
+    # a BLAS that rounds the blocked product differently: the sample check notices, the loop takes over
+    real_inner = np.inner
+    monkeypatch.setattr(h.numpy, "inner", lambda a, b: real_inner(a, b) * (1.0 + 2.0 ** -52) if np.ndim(a) == 2 else real_inner(a, b))
+    calls.clear()
+    for (arr, res, l), w in zip(cases[:3], want[:3]):
+        got = np.array(h.calculate_antenna_array_response(arr, res, l))
+        assert np.array_equal(got.view(np.float64), w.view(np.float64))
+    assert calls.count(True) == 3
+    if fell_back:
+        pytest.skip("this BLAS rounds numpy.inner over a matrix differently from the per-element call: the helper used its per-element loop")
+
+
 @pytest.mark.parametrize("args", [
     dict(m=0, n=1, nsamples=8, res=4), dict(m=4, n=0, nsamples=8, res=4), dict(m=4, n=4, nsamples=8, res=4),
     dict(m=4, n=2, nsamples=10, res=4), dict(m=4, n=2, nsamples=0, res=4), dict(m=4, n=2, nsamples=8, res=0),
