@@ -179,6 +179,8 @@ struct baz_music_ctx {
     double rate_unsorted = 0.0;
     uint64_t sorted_calls = 0, unsorted_calls = 0;     // (tap: baz_music_debug_sort_state)
     bool last_gated_sorted = false;
+    uint32_t scan_lds_pad = 0;     // lab (BAZ_MUSIC_SCAN_LDS_PAD bytes): dynamic LDS the fp64 scan asks for and never touches -- caps its workgroups per CU
+                                   // (tests/lab/two_ctx_split.py: does a low-register covariance of ANOTHER context fit beside three of them?)
     int seq_walk = 0;              // lab (BAZ_MUSIC_SEQ_WALK=1): scan_mfma_kernel walks its steps left to right (round 4's order; A/B of the strided walk)
     int i8p_on = 0;                // LAB builds only (BAZ_MUSIC_I8P=1): the level-packed int8 scan at m <= 4.  Measured and not shipped
                                    // (profiles/r05_i8p_negative.txt): its arithmetic is 0.31 ms against the fp64 scan's 0.56, but the spectrum
@@ -1069,7 +1071,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
     }
 #define BAZ_SCAN_ARGS dQ, fb0, d_spec, cand, batch, c->res, qstride, G.nsplit, c->nclass, G.rows_per_class, c->keep_mask, c->n, rf, (uint32_t)c->seq_walk
 #define BAZ_SCAN_LAUNCH(SPEC, VEC4, ABLV, AUXV)                                                                    \
-    hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4, ABLV, AUXV>), dim3(G.blocks), dim3(256), 0, c->stream, \
+    hipLaunchKernelGGL((scan_mfma_kernel<M, NMAX, SPEC, VEC4, ABLV, AUXV>), dim3(G.blocks), dim3(256), (size_t)c->scan_lds_pad, c->stream, \
                        BAZ_SCAN_ARGS)
 #ifdef BAZ_MUSIC_LAB
     if constexpr (M == 4 && NMAX == 2) {   // lab switches for the A/Bs in profiles/HISTORY_r01_r02.md 5.3 (BAZ_MUSIC_SCAN_VARIANT)
@@ -2014,6 +2016,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         {   // covariance + EVD fused (cov4_evd_kernel) wherever the dwordx4 covariance applies
             int fuse = 1;
             if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_FUSE")) fuse = atoi(v);                        // lab: 0 = two kernels
+            if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SCAN_LDS_PAD")) c->scan_lds_pad = (uint32_t)std::max(0, atoi(v));
             c->fused_covevd = (fuse > 0 && m == 4 && (c->K % 256u) == 0 && !c->lab_cov_old) ? 1 : 0;
             int per_cu = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cov4_evd_kernel, 256, 0) == hipSuccess && per_cu > 0)

@@ -82,6 +82,25 @@ __global__ __launch_bounds__(256) void rows_class(char* __restrict__ base, uint3
     }
 }
 
+// A bench step's whole traffic in ONE pass of short-lived workgroups in address order: workgroup b writes 4 KiB x U of the spectrum and reads the matching share
+// of the 2.1 GB input (8,192 B per 14,400 B written): what the memory system takes for these bytes when both streams are compact moving windows.
+template <int U>
+__global__ __launch_bounds__(256) void mixed_once(const v4f* __restrict__ src, size_t nr16, v4f* __restrict__ dst, size_t nw16, float* __restrict__ sink)
+{
+    const size_t wbase = (size_t)blockIdx.x * 256 * U;
+    // reads: the same fraction of the input as this workgroup's fraction of the output
+    const size_t r0 = (size_t)((double)wbase / (double)nw16 * (double)nr16), r1 = (size_t)((double)(wbase + 256 * U) / (double)nw16 * (double)nr16);
+    float acc = 0.f;
+    for (size_t i = r0 + threadIdx.x; i < r1 && i < nr16; i += 256) { const v4f v = __builtin_nontemporal_load(src + i); acc += v.x + v.y + v.z + v.w; }
+    const v4f v = {1.0f, 2.0f, 3.0f, acc};
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = wbase + threadIdx.x + (size_t)u * 256;
+        if (i < nw16) dst[i] = v;
+    }
+    if (acc == 123.456f) sink[0] = acc;
+}
+
 template <class F>
 void timeit(const char* name, double bytes, F launch)
 {
@@ -106,6 +125,14 @@ int main()
     const size_t WR = (size_t)rows * pitch, n16 = WR / 16;
     char* dst; CK(hipMalloc((void**)&dst, WR + 65536)); CK(hipMemset(dst, 0, WR));
     char nm[200];
+    {
+        const size_t RD = 2147483648ull;
+        char* src; float* sink; CK(hipMalloc((void**)&src, RD)); CK(hipMalloc((void**)&sink, 64)); CK(hipMemset(src, 0, RD));
+#define MIXED(U) snprintf(nm, sizeof nm, "a step's traffic, read 2.1 GB + write 3.8 GB, one workgroup per %d KiB written", 4 * U); \
+        timeit(nm, (double)RD + (double)WR, [&] { hipLaunchKernelGGL((mixed_once<U>), dim3((unsigned)((n16 + 256 * U - 1) / (256 * U))), dim3(256), 0, 0, (const v4f*)src, RD / 16, (v4f*)dst, n16, sink); });
+        MIXED(1) MIXED(4) MIXED(16)
+        CK(hipFree(src));
+    }
 #define FILL(U, NT) snprintf(nm, sizeof nm, "fill, one workgroup per %d KiB, %s", 4 * U, NT ? "nt" : "plain"); \
     timeit(nm, (double)WR, [&] { hipLaunchKernelGGL((fill_once<U, NT>), dim3((unsigned)((n16 + 256 * U - 1) / (256 * U))), dim3(256), 0, 0, (v4f*)dst, n16); });
     FILL(1, false) FILL(1, true) FILL(4, false) FILL(4, true) FILL(16, false) FILL(16, true)
