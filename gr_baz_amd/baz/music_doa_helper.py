@@ -10,6 +10,8 @@ With GNU Radio installed the class is a gr.hier_block2 wired exactly like the re
 Without it (this container) it is a plain object with the same attributes plus work(items), so the
 helper -> baz.music_doa -> host block -> C-ABI -> HIP chain can be exercised end to end.
 """
+import os
+
 import numpy
 
 try:                                    # real GNU Radio host
@@ -24,6 +26,28 @@ C_LIGHT = 299792458.0                   # python/music_doa_helper.py:55
 
 def unit_vect(theta):
     return numpy.array([numpy.cos(theta), numpy.sin(theta)])
+
+
+def _fma(a, b, c):
+    """round(a * b + c) in float64 without an fma instruction: the product exactly as p + e (Veltkamp / Dekker), the sum of the
+    three terms by a compensated addition.  (Not correctly rounded in every halfway case; it is only ever used to CONFIRM a table
+    bit for bit, so an error here can only send the helper to its per-element loop.)"""
+    p = a * b
+    ta, tb = 134217729.0 * a, 134217729.0 * b
+    ah = ta - (ta - a)
+    bh = tb - (tb - b)
+    al, bl = a - ah, b - bh
+    e = ((ah * bh - p) + ah * bl + al * bh) + al * bl
+    s = p + c
+    bb = s - p
+    t = (p - (s - bb)) + (c - bb)
+    return s + (t + e)
+
+
+# u0 a0 + u1 a1 as a BLAS dot of length two may round it: the second product fused onto the first, the first onto the second, or unfused
+_TWO_TERM_FORMS = (lambda u0, a0, u1, a1: _fma(u1, a1, u0 * a0),
+                   lambda u0, a0, u1, a1: _fma(u0, a0, u1 * a1),
+                   lambda u0, a0, u1, a1: u0 * a0 + u1 * a1)
 
 
 def _phase_by_element(antennas, angular_resolution, l, steps=None):
@@ -46,19 +70,32 @@ def calculate_antenna_array_response(antenna_array, angular_resolution, l):
     The reference forms every phase with its own numpy.inner call: 288,000 of them at 8 antennas x 36,000 bins, 0.4 - 1.1 s
     per retune -- next to a set_array_response that takes 0.24 ms.  Here ONE numpy.inner over all steps and
     antennas forms them (the same two-term dot product per element, by the same BLAS: bit-identical wherever it was tried,
-    20 x faster), a sample of the elements is recomputed the reference's way, and if a single bit differs -- another BLAS
-    may round a blocked product differently -- the whole table is formed per element after all.  (An explicit
-    multiply-add is NOT identical: the BLAS dot fuses, which shows as 1-ulp differences in 15 % of the phases.)"""
+    20 x faster).  It is accepted only when (i) a sample of 64 rows recomputed the reference's way agrees bit for bit and (ii)
+    EVERY element agrees bit for bit with a deterministic restatement of the rounding the sample shows (fused either way, or
+    unfused: _TWO_TERM_FORMS) -- a BLAS whose blocked product, thread partition or tail rounds some rows differently fails
+    (ii); in every other case the whole table is formed per element.  BAZ_MUSIC_HELPER_PER_ELEMENT=1 forces that loop."""
     antennas = [numpy.asarray(a, dtype=numpy.float64) for a in antenna_array]
     res = int(angular_resolution)
     phase = None
-    if res > 0 and len(antennas) > 0 and all(a.shape == (2,) for a in antennas):
+    if (res > 0 and len(antennas) > 0 and all(a.shape == (2,) for a in antennas)
+            and os.environ.get("BAZ_MUSIC_HELPER_PER_ELEMENT", "0") in ("", "0")):     # (=1: the reference's loop, whatever it costs)
         angle = (numpy.arange(res) * 360.0 / res) * (numpy.pi / 180.0)
         u = numpy.stack([numpy.cos(angle), numpy.sin(angle)], axis=1)
-        fast = numpy.inner(u, numpy.stack(antennas)) / l
+        A = numpy.stack(antennas)
+        fast = numpy.inner(u, A) / l
         sample = sorted(set([0, res - 1] + [(k * 2654435761) % res for k in range(1, 63)]))
-        if numpy.array_equal(fast[sample].view(numpy.int64), _phase_by_element(antennas, res, l, sample).view(numpy.int64)):
-            phase = fast
+        by_element = _phase_by_element(antennas, res, l, sample)
+        if numpy.array_equal(fast[sample].view(numpy.int64), by_element.view(numpy.int64)):
+            # The sample says what ONE dot product of this BLAS rounds like.  The matrix product may still round some block,
+            # thread partition or tail differently (ADVICE r5): the WHOLE table is therefore compared with a deterministic
+            # restatement of that rounding -- whichever of the three two-term forms reproduces the sample -- and any differing
+            # element sends the table through the per-element loop.
+            for form in _TWO_TERM_FORMS:
+                cand = form(u[:, 0:1], A[None, :, 0], u[:, 1:2], A[None, :, 1]) / l
+                if numpy.array_equal(cand[sample].view(numpy.int64), by_element.view(numpy.int64)):
+                    if numpy.array_equal(cand.view(numpy.int64), fast.view(numpy.int64)):
+                        phase = fast
+                    break
     if phase is None:
         phase = _phase_by_element(antennas, res, l)
     response = numpy.exp(-1j * 2.0 * numpy.pi * phase)

@@ -34,6 +34,7 @@ SYMBOLS = [
     "baz_music_host_register", "baz_music_set_host_pinning", "baz_music_host_unregister_all", "baz_music_host_pinned_bytes",
     "baz_music_debug_i8_margin", "baz_music_debug_i8_stats", "baz_music_uses_i8_scan", "baz_music_debug_i8_image",
     "baz_music_debug_i8_nsplit", "baz_music_debug_sort_state", "baz_music_last_retune_ms", "baz_music_debug_table_image", "baz_music_debug_host_table_image",
+    "baz_music_debug_guard_check", "baz_music_debug_guard_active",
 ]
 
 _vp = ctypes.c_void_p
@@ -149,6 +150,10 @@ def _bind(L):
     L.baz_music_debug_i8_image.restype = ctypes.c_size_t
     L.baz_music_debug_i8_image.argtypes = [_u32, _u32, _f32p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t,
                                            ctypes.POINTER(ctypes.c_double)]
+    L.baz_music_debug_guard_check.restype = ctypes.c_int
+    L.baz_music_debug_guard_check.argtypes = []
+    L.baz_music_debug_guard_active.restype = ctypes.c_int
+    L.baz_music_debug_guard_active.argtypes = []
     L.baz_music_debug_sort_state.restype = ctypes.c_int
     L.baz_music_debug_sort_state.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64)]
     L.baz_music_last_retune_ms.restype = ctypes.c_int
@@ -387,8 +392,12 @@ def debug_i8_image(m, resolution, table):
 TABLE_IMAGES = {0: "FB", 1: "TB", 2: "coarse", 3: "i8", 4: "a2p", 5: "TA", 6: "a2", 7: "params", 8: "i8 packed (m <= 4)"}
 
 
-def debug_host_table_image(m, n, resolution, table, which, lab=False):
-    """HOST-ONLY: image `which` of `table` as the round-4 host routines build it (uint8 array), or None.  Needs no device."""
+def debug_host_table_image(m, n, resolution, table, which, lab=None):
+    """HOST-ONLY: image `which` of `table` as the round-4 host routines build it (uint8 array), or None.  Needs no device.
+    lab=None: the lab form of the library where BAZ_MUSIC_LAB_LIB is set (like Context); image 8 -- the level-packed int8 operands of
+    2 .. 4 antennas -- exists in the lab form only."""
+    if lab is None:
+        lab = bool(os.environ.get("BAZ_MUSIC_LAB_LIB"))
     t = _table_f32(table, int(resolution), int(m))
     tp = t.view(np.float32).ctypes.data_as(_f32p)
     L = lib(lab)
@@ -398,6 +407,16 @@ def debug_host_table_image(m, n, resolution, table, which, lab=False):
     out = np.zeros(nb, np.uint8)
     L.baz_music_debug_host_table_image(int(m), int(n), int(resolution), tp, int(which), _vp(out.ctypes.data), nb)
     return out
+
+
+def guard_active(lab=True):
+    """True when the (lab) library allocates with guard zones: lab build and BAZ_MUSIC_GUARD=1 in the environment at load time."""
+    return bool(lib(lab).baz_music_debug_guard_active())
+
+
+def guard_check(lab=True):
+    """Guard zones found overwritten since the process started (lab library under BAZ_MUSIC_GUARD=1; synchronises the device); 0 otherwise."""
+    return int(lib(lab).baz_music_debug_guard_check())
 
 
 def q_stride(batch):

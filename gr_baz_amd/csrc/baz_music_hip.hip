@@ -9,8 +9,10 @@
 #include "music_wide_kernels.hip.h"
 #include "scan_coarse_kernels.hip.h"
 #include "scan_i8_kernels.hip.h"
+#ifdef BAZ_MUSIC_LAB       // measured and NOT shipped (profiles/r05_i8p_negative.txt, r05_sort_negative.txt): the release library has none of their kernels
 #include "scan_i8p_kernels.hip.h"
 #include "sort_kernels.hip.h"
+#endif
 #include "table_kernels.hip.h"
 
 #include <algorithm>
@@ -38,6 +40,83 @@ using namespace bazmusic;
 #else
 #define BAZ_LAB_ENV(NAME) (static_cast<const char*>(nullptr))
 #endif
+
+// ---- device allocations ---------------------------------------------------------------------------------------------------------
+// Every device buffer of this library comes from dev_malloc / dev_free.  Release build: hipMalloc / hipFree.  Lab build with
+// BAZ_MUSIC_GUARD=1 (round 6, after a GPU memory fault the driver saw and no test did): every buffer lies between two 64-KiB guard
+// zones filled with a pattern; baz_music_debug_guard_check() -- and every dev_free -- compares the zones with the pattern, so a
+// kernel that writes outside its buffer is caught at the buffer it ran over, not at whatever was allocated next to it.
+namespace {
+#ifdef BAZ_MUSIC_LAB
+constexpr size_t GUARD_BYTES = 64u << 10;
+constexpr int GUARD_PATTERN = 0xA5;
+struct GuardRec { void* base; size_t bytes; };
+std::mutex g_guard_mtx;
+std::vector<std::pair<void*, GuardRec>> g_guards;     // user pointer -> allocation (a handful of buffers per context)
+unsigned long long g_guard_damaged = 0;               // zones found overwritten so far (at a free or at a check)
+bool guard_on()
+{
+    static const bool on = [] { const char* v = getenv("BAZ_MUSIC_GUARD"); return v && atoi(v) != 0; }();
+    return on;
+}
+// compares both zones of one allocation with the pattern (synchronises the device); returns the damaged zones (0 .. 2)
+int guard_check_one(void* user, const GuardRec& g)
+{
+    static thread_local std::vector<unsigned char> host(GUARD_BYTES);
+    int bad = 0;
+    (void)hipDeviceSynchronize();
+    for (int z = 0; z < 2; ++z) {
+        const unsigned char* zone = static_cast<const unsigned char*>(g.base) + (z ? GUARD_BYTES + ((g.bytes + 255) & ~(size_t)255) : 0);
+        if (hipMemcpy(host.data(), zone, GUARD_BYTES, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); ++bad; continue; }
+        size_t first = GUARD_BYTES;
+        for (size_t i = 0; i < GUARD_BYTES; ++i)
+            if (host[i] != (unsigned char)GUARD_PATTERN) { first = i; break; }
+        if (first != GUARD_BYTES) {
+            ++bad;
+            fprintf(stderr, "[baz_music_hip] GUARD ZONE DAMAGED: buffer %p (%zu bytes), zone %s it, first damaged byte at %+lld from the buffer's %s\n",
+                    user, g.bytes, z ? "behind" : "in front of", z ? (long long)first : (long long)first - (long long)GUARD_BYTES, z ? "end (rounded up to 256)" : "start");
+        }
+    }
+    return bad;
+}
+#endif
+
+hipError_t dev_malloc(void** p, size_t bytes)
+{
+#ifdef BAZ_MUSIC_LAB
+    if (guard_on()) {
+        const size_t body = (bytes + 255) & ~(size_t)255;
+        void* base = nullptr;
+        hipError_t e = hipMalloc(&base, body + 2 * GUARD_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipMemset(base, GUARD_PATTERN, body + 2 * GUARD_BYTES);     // (the body too: a read of an uninitialised buffer shows up as 0xA5A5...)
+        if (e != hipSuccess) { (void)hipFree(base); return e; }
+        *p = static_cast<unsigned char*>(base) + GUARD_BYTES;
+        std::lock_guard<std::mutex> lk(g_guard_mtx);
+        g_guards.emplace_back(*p, GuardRec{base, bytes});
+        return hipSuccess;
+    }
+#endif
+    return hipMalloc(p, bytes);
+}
+
+hipError_t dev_free(void* p)
+{
+#ifdef BAZ_MUSIC_LAB
+    if (guard_on() && p) {
+        std::lock_guard<std::mutex> lk(g_guard_mtx);
+        for (size_t i = 0; i < g_guards.size(); ++i)
+            if (g_guards[i].first == p) {
+                const GuardRec g = g_guards[i].second;
+                g_guard_damaged += (unsigned long long)guard_check_one(p, g);
+                g_guards.erase(g_guards.begin() + (long)i);
+                return hipFree(g.base);
+            }
+    }
+#endif
+    return hipFree(p);
+}
+}  // namespace
 
 namespace {
 
@@ -92,8 +171,10 @@ struct baz_music_ctx {
     struct TableSet {
         double2* dFB = nullptr; double2* dTB = nullptr; uint4* dCS = nullptr; uint4* dIB = nullptr; double* dA2p = nullptr;
         float2* dTA = nullptr; double* dA2 = nullptr;
+#ifdef BAZ_MUSIC_LAB
         uint4* dIP = nullptr;            // level-packed int8 operands (m <= 4; shares i8 / i8_ok with dIB: a configuration has one of the two)
         float* dKT = nullptr;            // float32 table at the sort key's sample bins (sort_kernels.hip.h; m <= 8)
+#endif
         CoarseParams cs = {0.0f, 0.0f, 0.0, 0.0, 1};
         I8Params i8 = {};
         bool cs_ok = false, i8_ok = false;
@@ -158,6 +239,7 @@ struct baz_music_ctx {
     unsigned long long* dMargin = nullptr;   // baz_music_debug_coarse_margin: worst error / allowance (float bits << 32 | where)
     // int8-matrix-core scan (scan_i8_kernels.hip.h): 6 <= m <= 16, n <= 4
     uint4* dIB = nullptr;          // digit image of the table (build_i8_image)
+#ifdef BAZ_MUSIC_LAB
     uint4* dIP = nullptr;          // level-packed digit operands, 2 .. 4 antennas (build_i8p_kernel); parameters in `i8` as well
     float* dKT = nullptr;          // sort-key table (sort_kernels.hip.h)
     // Sorting the items of a batch by their nulls in front of the gated scan (sort_kernels.hip.h), while that scan reports many fired tiles
@@ -179,12 +261,15 @@ struct baz_music_ctx {
     double rate_unsorted = 0.0;
     uint64_t sorted_calls = 0, unsorted_calls = 0;     // (tap: baz_music_debug_sort_state)
     bool last_gated_sorted = false;
+#endif
     uint32_t scan_lds_pad = 0;     // lab (BAZ_MUSIC_SCAN_LDS_PAD bytes): dynamic LDS the fp64 scan asks for and never touches -- caps its workgroups per CU
                                    // (tests/lab/two_ctx_split.py: does a low-register covariance of ANOTHER context fit beside three of them?)
     int seq_walk = 0;              // lab (BAZ_MUSIC_SEQ_WALK=1): scan_mfma_kernel walks its steps left to right (round 4's order; A/B of the strided walk)
+#ifdef BAZ_MUSIC_LAB
     int i8p_on = 0;                // LAB builds only (BAZ_MUSIC_I8P=1): the level-packed int8 scan at m <= 4.  Measured and not shipped
                                    // (profiles/r05_i8p_negative.txt): its arithmetic is 0.31 ms against the fp64 scan's 0.56, but the spectrum
                                    // stores alone take what the fp64 scan takes (0.59 - 0.73 ms by box), and incoherent batches run 2.4 x slower
+#endif
     I8Params i8 = {};
     bool i8_ok = false;            // image built (finite table, scale representable, size within I8_IMAGE_LIMIT)
     int i8_on = 1;                 // BAZ_MUSIC_EXACT=1: every value on the fp64 matrix core (A/B; the round-3 scan)
@@ -208,6 +293,7 @@ struct baz_music_ctx {
     int single_limit_mib = 64;                           // page-locked calls below this much traffic run as ONE chunk (BAZ_MUSIC_SINGLE_MIB)
     StageProf prof[BAZ_MUSIC_NUM_STAGES];
     std::string stage_name[BAZ_MUSIC_NUM_STAGES];
+    char scan_names[4][64] = {{0}, {0}, {0}, {0}};   // baz_music_stage_name(SCAN) by scan_kind, written once by baz_music_create
     int scan_kind = -1;     // the scan kernel the LAST launch took: 0 scan_mfma_kernel, 1 scan_i8_kernel, 2 scan_coarse_kernel, 3 scan_i8p_kernel (-1: none yet)
     char hip_err[256] = {0};
 };
@@ -473,6 +559,7 @@ bool build_i8_image(const std::vector<double>& F, uint32_t m, uint32_t res, uint
     return true;
 }
 
+#ifdef BAZ_MUSIC_LAB
 // Level-packed digit operands for 2 .. 4 antennas (scan_i8p_kernels.hip.h), host checker of baztab::build_i8p_kernel:
 //     B [((st + 1) * 4 + t) * 64 + 16 s + c][j]  = digit s (0 .. 3) of Fi[bin = 64 st + 4 c + t][e = j]       (16 bytes per entry)
 //     B'[ ...                     16 s + c][j]  = digit 4 + s (s = 0 .. 2), slot 3 zero;  B' follows B (i8p_operand_units each)
@@ -509,6 +596,7 @@ bool build_i8p_image(const std::vector<double>& F, uint32_t m, uint32_t res, uin
     }
     return true;
 }
+#endif
 
 // the scan's short form (scan_mfma_kernel, SIG) needs fewer MFMAs than the projector GEMM
 bool short_form_applies(uint32_t m, uint32_t n) { return (n == 2 && m >= 9 && m <= 16) || (n == 1 && m >= 6 && m <= 16); }
@@ -517,11 +605,15 @@ bool i8_active(const baz_music_ctx* c)
 {
     return c->i8_on && c->i8_ok && c->dIB && c->m >= 6 && c->m <= 16 && c->n <= 4 && !c->lab_variant;
 }
-// ... and its level-packed form for 2 .. 4 antennas (scan_i8p_kernels.hip.h), with the spectrum port
+// ... and its level-packed form for 2 .. 4 antennas (scan_i8p_kernels.hip.h), with the spectrum port: lab builds only
+#ifdef BAZ_MUSIC_LAB
 bool i8p_active(const baz_music_ctx* c)
 {
     return c->i8_on && c->i8p_on && c->i8_ok && c->dIP && c->m <= 4 && c->n <= 4 && !c->lab_variant;
 }
+#else
+constexpr bool i8p_active(const baz_music_ctx*) { return false; }
+#endif
 bool short_form_in_use(const baz_music_ctx* c)
 {
     // (the integer form evaluates the projector form: the EVD must write its coefficients)
@@ -533,19 +625,22 @@ int ensure_workspace(baz_music_ctx* c, uint32_t batch)
     if (batch <= c->cap) return BAZ_MUSIC_OK;
     const uint32_t cap = round_up(batch, 64);
     const size_t mm = (size_t)c->m * c->m;
-    if (c->dR) { (void)hipFree(c->dR); c->dR = nullptr; }
-    if (c->dQ) { (void)hipFree(c->dQ); c->dQ = nullptr; }
-    if (c->dG) { (void)hipFree(c->dG); c->dG = nullptr; }
-    if (c->dRedo) { (void)hipFree(c->dRedo); c->dRedo = nullptr; }
-    if (c->dSs) { (void)hipFree(c->dSs); c->dSs = nullptr; }
+    // batches launched earlier may still use the buffers freed below: drain them first (hipFree happens to synchronise the device
+    // today; nothing here relies on it)
+    if (c->cap) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->dR) { (void)dev_free(c->dR); c->dR = nullptr; }
+    if (c->dQ) { (void)dev_free(c->dQ); c->dQ = nullptr; }
+    if (c->dG) { (void)dev_free(c->dG); c->dG = nullptr; }
+    if (c->dRedo) { (void)dev_free(c->dRedo); c->dRedo = nullptr; }
+    if (c->dSs) { (void)dev_free(c->dSs); c->dSs = nullptr; }
     c->cap = 0;
-    HIP_TRY(c, hipMalloc((void**)&c->dR, (size_t)cap * mm * sizeof(double2)));
-    HIP_TRY(c, hipMalloc((void**)&c->dQ, (size_t)cap * mm * sizeof(double)));
-    HIP_TRY(c, hipMalloc((void**)&c->dG, (size_t)cap * mm * 2 * sizeof(double)));
-    if (c->dRedo) { (void)hipFree(c->dRedo); c->dRedo = nullptr; }
-    HIP_TRY(c, hipMalloc((void**)&c->dRedo, (size_t)cap));
-    if (c->dSs) { (void)hipFree(c->dSs); c->dSs = nullptr; }
-    if (short_form_applies(c->m, c->n)) HIP_TRY(c, hipMalloc((void**)&c->dSs, (size_t)cap * 4 * c->n * c->m * sizeof(double)));
+    HIP_TRY(c, dev_malloc((void**)&c->dR, (size_t)cap * mm * sizeof(double2)));
+    HIP_TRY(c, dev_malloc((void**)&c->dQ, (size_t)cap * mm * sizeof(double)));
+    HIP_TRY(c, dev_malloc((void**)&c->dG, (size_t)cap * mm * 2 * sizeof(double)));
+    if (c->dRedo) { (void)dev_free(c->dRedo); c->dRedo = nullptr; }
+    HIP_TRY(c, dev_malloc((void**)&c->dRedo, (size_t)cap));
+    if (c->dSs) { (void)dev_free(c->dSs); c->dSs = nullptr; }
+    if (short_form_applies(c->m, c->n)) HIP_TRY(c, dev_malloc((void**)&c->dSs, (size_t)cap * 4 * c->n * c->m * sizeof(double)));
     c->cap = cap;
     return BAZ_MUSIC_OK;
 }
@@ -755,9 +850,13 @@ uint32_t i8_nsplit(uint32_t batch, uint32_t nsteps, uint32_t slots, int force_ns
 int ensure_candidates(baz_music_ctx* c, size_t entries)
 {
     if (entries <= c->cand_cap) return BAZ_MUSIC_OK;
-    if (c->dCand) { (void)hipFree(c->dCand); c->dCand = nullptr; }
+    if (c->dCand) {                                        // (see ensure_workspace: drain what may still write the old lists)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        (void)dev_free(c->dCand);
+        c->dCand = nullptr;
+    }
     c->cand_cap = 0;
-    HIP_TRY(c, hipMalloc((void**)&c->dCand, entries * sizeof(double)));
+    HIP_TRY(c, dev_malloc((void**)&c->dCand, entries * sizeof(double)));
     c->cand_cap = entries;
     return BAZ_MUSIC_OK;
 }
@@ -793,34 +892,36 @@ CoarseGeom coarse_geometry(const baz_music_ctx* c, uint32_t batch)
     return G;
 }
 
-// ---- sorting in front of the gated scan (sort_kernels.hip.h) --------------------------------------------------------------------------
+// ---- sorting in front of the gated scan (sort_kernels.hip.h): LAB builds only --------------------------------------------------------
+#ifdef BAZ_MUSIC_LAB
 constexpr uint32_t SORT_MIN_BATCH = 4096;      // below this a launch is a handful of workgroups either way
 constexpr double SORT_ON_RATE = 0.06;          // share of (row group, tile) pairs an UNSORTED call evaluated exactly above which sorting pays
 constexpr uint32_t SORT_PROBE_EVERY = 64;      // while sorting: every so many calls one call unsorted, whose statistic decides anew
 
 int ensure_sort_workspace(baz_music_ctx* c, uint32_t batch)
 {
+    if (c->sort_mode == 0) return BAZ_MUSIC_OK;                   // (nothing of the sorting exists unless it was asked for)
     if (!c->dFire) {
-        HIP_TRY(c, hipMalloc((void**)&c->dFire, 2 * sizeof(unsigned long long)));
+        HIP_TRY(c, dev_malloc((void**)&c->dFire, 2 * sizeof(unsigned long long)));
         HIP_TRY(c, hipMemset(c->dFire, 0, 2 * sizeof(unsigned long long)));
         HIP_TRY(c, hipHostMalloc((void**)&c->hFire, 4 * sizeof(unsigned long long), hipHostMallocDefault));
         std::memset(c->hFire, 0, 4 * sizeof(unsigned long long));
         HIP_TRY(c, hipHostGetDevicePointer((void**)&c->hFireDev, c->hFire, 0));
     }
-    if (c->sort_mode == 0 || !c->dKT) return BAZ_MUSIC_OK;       // the product never sorts: only the fire statistic above
+    if (!c->dKT) return BAZ_MUSIC_OK;
     if (!c->dHist) {
-        HIP_TRY(c, hipMalloc((void**)&c->dHist, bazsort::KEY_BUCKETS * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc((void**)&c->dCursor, bazsort::KEY_BUCKETS * sizeof(uint32_t)));
+        HIP_TRY(c, dev_malloc((void**)&c->dHist, bazsort::KEY_BUCKETS * sizeof(uint32_t)));
+        HIP_TRY(c, dev_malloc((void**)&c->dCursor, bazsort::KEY_BUCKETS * sizeof(uint32_t)));
         HIP_TRY(c, hipMemset(c->dHist, 0, bazsort::KEY_BUCKETS * sizeof(uint32_t)));
     }
     if (batch > c->sort_cap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->dKeys) (void)hipFree(c->dKeys);
-        if (c->dPerm) (void)hipFree(c->dPerm);
+        if (c->dKeys) (void)dev_free(c->dKeys);
+        if (c->dPerm) (void)dev_free(c->dPerm);
         c->dKeys = nullptr; c->dPerm = nullptr; c->sort_cap = 0;
         const uint32_t cap = round_up(batch, 4096);
-        HIP_TRY(c, hipMalloc((void**)&c->dKeys, (size_t)cap * sizeof(uint16_t)));
-        HIP_TRY(c, hipMalloc((void**)&c->dPerm, (size_t)cap * sizeof(uint32_t)));
+        HIP_TRY(c, dev_malloc((void**)&c->dKeys, (size_t)cap * sizeof(uint16_t)));
+        HIP_TRY(c, dev_malloc((void**)&c->dPerm, (size_t)cap * sizeof(uint32_t)));
         c->sort_cap = cap;
     }
     return BAZ_MUSIC_OK;
@@ -879,6 +980,7 @@ int launch_sort_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
     }
     return BAZ_MUSIC_OK;
 }
+#endif   // BAZ_MUSIC_LAB
 
 template <int M, int NMAX>
 int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t batch, float* d_ang,
@@ -895,7 +997,8 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             rf.count = c->refine_nocount ? nullptr : c->dRefined + c->stat_parity;
             rf.A2 = nullptr;
             unsigned long long* stats = c->coarse_stats ? c->dMargin : nullptr;     // lab: exact tile evaluations, summed over launches
-            // the items in an order in which neighbours share their nulls, while the scan's own statistic says that pays (sort_decide)
+#ifdef BAZ_MUSIC_LAB
+            // lab (BAZ_MUSIC_SORT): the items in an order in which neighbours share their nulls, while the scan's own statistic says that pays
             int sr = ensure_sort_workspace(c, batch);
             if (sr) return sr;
             const bool sorted = sort_decide(c, batch);
@@ -908,8 +1011,13 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             }
             c->last_gated_sorted = sorted;
             const uint32_t* perm = sorted ? c->dPerm : nullptr;
+            unsigned long long* fstat = c->dFire;
+#else
+            const uint32_t* perm = nullptr;                 // the product walks the items in their own order and keeps no fire statistic
+            unsigned long long* fstat = nullptr;
+#endif
 #define BAZ_COARSE_ARGS dim3(CG.groups * CG.nsplit), dim3(256), 0, c->stream, dQ, c->dCS, c->dCS + (size_t)(c->cs_tiles + 1) * cs_c_units(M), \
-                        c->dCand, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, stats, nullptr, perm, c->dFire
+                        c->dCand, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, stats, nullptr, perm, fstat
 #ifdef BAZ_MUSIC_LAB
             if (c->sort_mode != 0 && M <= 4 && CG.tpp != 4 && !c->coarse_lab) {        // lab (BAZ_MUSIC_SORT): the index list and the fire statistic
                 if constexpr (M <= 4) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8, false, 0, true>), BAZ_COARSE_ARGS);
@@ -1110,11 +1218,18 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
 template <int NMAX>
 int launch_merge_t(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl, float* d_spec)
 {
-    const bool gated = c->scan_kind == 2 && c->dFire && c->hFireDev;       // the gated scan just ran: its fire statistic travels with this merge
+#ifdef BAZ_MUSIC_LAB
+    // lab (BAZ_MUSIC_SORT): the gated scan just ran with its fire statistic on -- it travels to page-locked memory with this merge
+    const bool gated = c->scan_kind == 2 && c->sort_mode != 0 && c->dFire && c->hFireDev;
     const unsigned long long tag = gated ? ((++c->fire_calls) << 1) | (c->last_gated_sorted ? 1ull : 0ull) : 0ull;
     hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream, c->dCand,
                        d_spec, d_ang, d_lvl, batch, c->res, c->n, c->last_nsplit, c->keep_mask, c->dRefined + (c->stat_parity ^ 1),
                        gated ? c->dFire : nullptr, gated ? c->hFireDev : nullptr, tag);
+#else
+    hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream, c->dCand,
+                       d_spec, d_ang, d_lvl, batch, c->res, c->n, c->last_nsplit, c->keep_mask, c->dRefined + (c->stat_parity ^ 1),
+                       nullptr, nullptr, 0ull);
+#endif
     HIP_TRY(c, hipGetLastError());
     return BAZ_MUSIC_OK;
 }
@@ -1226,22 +1341,43 @@ uint32_t wide_pass_items(const baz_music_ctx* c)
     return (uint32_t)std::max<size_t>(1, std::min<size_t>(8192, ((size_t)256 << 20) / per_item));
 }
 
+// launch geometry of scan_wide_mfma_kernel for a pass of nb items (one place: process_wide_locked launches with it, baz_music_reserve sizes for it)
+struct WideScanGeom { uint32_t ipw, nk, groups, nsplit; };
+WideScanGeom wide_scan_geometry(const baz_music_ctx* c, uint32_t nb)
+{
+    WideScanGeom W;
+    W.ipw = (c->n <= 2) ? 4u : (c->n <= 4 ? 2u : 1u);                          // items per wave (tile = ipw items x 16 / ipw outputs)
+    W.nk = 8u / W.ipw;                                                         // list length
+    W.groups = (nb + 4u * W.ipw - 1) / (4u * W.ipw);                           // workgroups of 4 waves
+    W.nsplit = std::max(1u, std::min((1024u + W.groups - 1) / W.groups, std::min(c->fb_steps, 16u)));
+    return W;
+}
+// candidate keys of ANY pass of up to `pass` items: nb * nsplit(nb) is not monotonic in nb (see cand_entries_upto)
+size_t wide_cand_entries(const baz_music_ctx* c, uint32_t pass)
+{
+    const WideScanGeom W = wide_scan_geometry(c, pass);
+    const size_t cap_split = std::min<uint32_t>(c->fb_steps, 16u);
+    // nsplit <= 1024 / groups + 1 and groups >= nb / (4 ipw): nb * nsplit <= 4096 ipw + nb; and <= nb * cap_split
+    const size_t worst = std::min<size_t>((size_t)pass * cap_split, (size_t)4096u * W.ipw + (size_t)pass);
+    return std::max<size_t>(worst, (size_t)pass * W.nsplit) * W.nk;
+}
+
 int ensure_wide_workspace(baz_music_ctx* c, uint32_t items)
 {
     if (items <= c->wide_cap) return BAZ_MUSIC_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->dR) { (void)hipFree(c->dR); c->dR = nullptr; }
-    if (c->dGw) { (void)hipFree(c->dGw); c->dGw = nullptr; }
-    if (c->dWS) { (void)hipFree(c->dWS); c->dWS = nullptr; }
-    if (c->dSw) { (void)hipFree(c->dSw); c->dSw = nullptr; }
+    if (c->dR) { (void)dev_free(c->dR); c->dR = nullptr; }
+    if (c->dGw) { (void)dev_free(c->dGw); c->dGw = nullptr; }
+    if (c->dWS) { (void)dev_free(c->dWS); c->dWS = nullptr; }
+    if (c->dSw) { (void)dev_free(c->dSw); c->dSw = nullptr; }
     c->wide_cap = 0;
     const size_t mm = (size_t)c->m * c->m;
-    HIP_TRY(c, hipMalloc((void**)&c->dR, (size_t)items * mm * sizeof(double2)));
-    HIP_TRY(c, hipMalloc((void**)&c->dGw, (size_t)items * (c->m - c->n) * c->m * sizeof(double2)));
-    HIP_TRY(c, hipMalloc((void**)&c->dWS, (size_t)items * c->res * sizeof(double)));
-    HIP_TRY(c, hipMalloc((void**)&c->dSw, (size_t)items * c->n * c->m * sizeof(double2)));
-    if (c->dRedo) { (void)hipFree(c->dRedo); c->dRedo = nullptr; }
-    HIP_TRY(c, hipMalloc((void**)&c->dRedo, (size_t)items));
+    HIP_TRY(c, dev_malloc((void**)&c->dR, (size_t)items * mm * sizeof(double2)));
+    HIP_TRY(c, dev_malloc((void**)&c->dGw, (size_t)items * (c->m - c->n) * c->m * sizeof(double2)));
+    HIP_TRY(c, dev_malloc((void**)&c->dWS, (size_t)items * c->res * sizeof(double)));
+    HIP_TRY(c, dev_malloc((void**)&c->dSw, (size_t)items * c->n * c->m * sizeof(double2)));
+    if (c->dRedo) { (void)dev_free(c->dRedo); c->dRedo = nullptr; }
+    HIP_TRY(c, dev_malloc((void**)&c->dRedo, (size_t)items));
     c->wide_cap = items;
     return BAZ_MUSIC_OK;
 }
@@ -1271,10 +1407,15 @@ int launch_cov_wide(baz_music_ctx* c, const float* d_in, uint32_t nb, double2* d
     return BAZ_MUSIC_OK;
 }
 
+int check_launch_pointers(baz_music_ctx* c);       // (below, next to process_device_locked)
+int refuse_null(baz_music_ctx* c, const void* p, const char* name);
+
 int process_wide_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void* d_ang, void* d_lvl, void* d_spec)
 {
     const uint32_t pass = std::min(batch, wide_pass_items(c));
     int r = ensure_wide_workspace(c, pass);
+    if (r) return r;
+    r = check_launch_pointers(c);
     if (r) return r;
     const float* in = static_cast<const float*>(d_in);
     float* ang = static_cast<float*>(d_ang);
@@ -1317,11 +1458,11 @@ int process_wide_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void
         }
         if (c->wide_mfma && !c->wide_literal_only) {
             // 17 <= m <= 64, n <= 8: the short form on the fp64 matrix core, candidates per bin range, bazmusic's merge
-            const uint32_t ipw = (c->n <= 2) ? 4u : (c->n <= 4 ? 2u : 1u);              // items per wave (tile = ipw items x 16 / ipw outputs)
-            const uint32_t nk = 8u / ipw;                                               // list length
-            const uint32_t groups = (nb + 4u * ipw - 1) / (4u * ipw);                   // workgroups of 4 waves
-            const uint32_t nsplit = std::max(1u, std::min((1024u + groups - 1) / groups, std::min(c->fb_steps, 16u)));
-            r = ensure_candidates(c, (size_t)nb * nsplit * nk);
+            const WideScanGeom W = wide_scan_geometry(c, nb);
+            const uint32_t nk = W.nk, groups = W.groups, nsplit = W.nsplit;
+            r = ensure_candidates(c, std::max(wide_cand_entries(c, pass), (size_t)nb * nsplit * nk));
+            if (r) return r;
+            r = refuse_null(c, c->dCand, "dCand");
             if (r) return r;
             float* sp = spec ? spec + (size_t)off * c->res : nullptr;
             {
@@ -1403,36 +1544,40 @@ int alloc_table_set(baz_music_ctx* c, TableSet& T)
 {
     const size_t pad_steps = (size_t)c->fb_steps + 2;
     if (c->wide) {
-        if (hipMalloc((void**)&T.dTA, (size_t)c->m * c->res * sizeof(float2)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
-        if (hipMalloc((void**)&T.dA2, (size_t)c->res * sizeof(double)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+        if (dev_malloc((void**)&T.dTA, (size_t)c->m * c->res * sizeof(float2)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+        if (dev_malloc((void**)&T.dA2, (size_t)c->res * sizeof(double)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
         if (c->wide_mfma) {
-            if (hipMalloc((void**)&T.dTB, pad_steps * c->tb_step_elems * sizeof(double2)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
-            if (hipMalloc((void**)&T.dA2p, pad_steps * 64 * sizeof(double)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+            if (dev_malloc((void**)&T.dTB, pad_steps * c->tb_step_elems * sizeof(double2)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+            if (dev_malloc((void**)&T.dA2p, pad_steps * 64 * sizeof(double)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
         }
         return BAZ_MUSIC_OK;
     }
-    if (hipMalloc((void**)&T.dFB, pad_steps * c->fb_step_elems * sizeof(double2)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
-    if (hipMalloc((void**)&T.dTB, pad_steps * c->tb_step_elems * sizeof(double2)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
-    if (c->m <= 8 && hipMalloc((void**)&T.dCS, coarse_image_bytes(c)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (dev_malloc((void**)&T.dFB, pad_steps * c->fb_step_elems * sizeof(double2)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (dev_malloc((void**)&T.dTB, pad_steps * c->tb_step_elems * sizeof(double2)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (c->m <= 8 && dev_malloc((void**)&T.dCS, coarse_image_bytes(c)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+#ifdef BAZ_MUSIC_LAB
     if (c->m <= 8 && c->sort_mode != 0 &&            // (lab: the sort key's table)
-        hipMalloc((void**)&T.dKT, (size_t)bazsort::key_samples(c->res) * c->m * c->m * sizeof(float)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
-    if (wants_i8_image(c) && hipMalloc((void**)&T.dIB, i8_image_bytes(c->m, c->fb_steps)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
-    if (c->i8p_on && c->m <= 4 && c->n <= 4 && hipMalloc((void**)&T.dIP, i8p_image_bytes(c->fb_steps)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
-    if (short_form_applies(c->m, c->n) && hipMalloc((void**)&T.dA2p, pad_steps * 64 * sizeof(double)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+        dev_malloc((void**)&T.dKT, (size_t)bazsort::key_samples(c->res) * c->m * c->m * sizeof(float)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (c->i8p_on && c->m <= 4 && c->n <= 4 && dev_malloc((void**)&T.dIP, i8p_image_bytes(c->fb_steps)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+#endif
+    if (wants_i8_image(c) && dev_malloc((void**)&T.dIB, i8_image_bytes(c->m, c->fb_steps)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (short_form_applies(c->m, c->n) && dev_malloc((void**)&T.dA2p, pad_steps * 64 * sizeof(double)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     return BAZ_MUSIC_OK;
 }
 
 void free_table_set(TableSet& T)
 {
-    if (T.dFB) (void)hipFree(T.dFB);
-    if (T.dTB) (void)hipFree(T.dTB);
-    if (T.dCS) (void)hipFree(T.dCS);
-    if (T.dIB) (void)hipFree(T.dIB);
-    if (T.dIP) (void)hipFree(T.dIP);
-    if (T.dKT) (void)hipFree(T.dKT);
-    if (T.dA2p) (void)hipFree(T.dA2p);
-    if (T.dTA) (void)hipFree(T.dTA);
-    if (T.dA2) (void)hipFree(T.dA2);
+    if (T.dFB) (void)dev_free(T.dFB);
+    if (T.dTB) (void)dev_free(T.dTB);
+    if (T.dCS) (void)dev_free(T.dCS);
+    if (T.dIB) (void)dev_free(T.dIB);
+#ifdef BAZ_MUSIC_LAB
+    if (T.dIP) (void)dev_free(T.dIP);
+    if (T.dKT) (void)dev_free(T.dKT);
+#endif
+    if (T.dA2p) (void)dev_free(T.dA2p);
+    if (T.dTA) (void)dev_free(T.dTA);
+    if (T.dA2) (void)dev_free(T.dA2);
     T = TableSet();
 }
 
@@ -1441,16 +1586,20 @@ TableSet active_table_set(const baz_music_ctx* c)
 {
     TableSet T;
     T.dFB = c->dFB; T.dTB = c->dTB; T.dCS = c->dCS; T.dIB = c->dIB; T.dA2p = c->dA2p; T.dTA = c->dTA; T.dA2 = c->dA2;
+#ifdef BAZ_MUSIC_LAB
     T.dIP = c->dIP;
     T.dKT = c->dKT;
+#endif
     T.cs = c->cs; T.i8 = c->i8; T.cs_ok = c->cs_ok; T.i8_ok = c->i8_ok; T.refine_below = c->refine_below;
     return T;
 }
 void install_table_set(baz_music_ctx* c, const TableSet& T)
 {
     c->dFB = T.dFB; c->dTB = T.dTB; c->dCS = T.dCS; c->dIB = T.dIB; c->dA2p = T.dA2p; c->dTA = T.dTA; c->dA2 = T.dA2;
+#ifdef BAZ_MUSIC_LAB
     c->dIP = T.dIP;
     c->dKT = T.dKT;
+#endif
     c->cs = T.cs; c->i8 = T.i8; c->cs_ok = T.cs_ok; c->i8_ok = T.i8_ok; c->refine_below = T.refine_below;
 }
 
@@ -1516,11 +1665,13 @@ int build_tables_device(baz_music_ctx* c, TableSet& T)
         hipLaunchKernelGGL(baztab::build_ta_kernel, grid_for((size_t)m * res), dim3(256), 0, s, reinterpret_cast<const float2*>(c->dRaw), m, res, T.dTA);
         HIP_TRY(c, hipGetLastError());
     }
+#ifdef BAZ_MUSIC_LAB
     if (T.dKT) {
         const uint32_t ns = bazsort::key_samples(res);
         hipLaunchKernelGGL(bazsort::build_key_table_kernel, grid_for((size_t)ns * m * m), dim3(256), 0, s, c->dRaw, m, res, ns, T.dKT);
         HIP_TRY(c, hipGetLastError());
     }
+#endif
     if (T.dCS) HIP_TRY(c, hipMemsetAsync(T.dCS, 0, coarse_image_bytes(c), s));
     if (T.dIB) HIP_TRY(c, hipMemsetAsync(T.dIB, 0, i8_image_bytes(m, steps), s));
     HIP_TRY(c, wait_stream_polling(s));                  // the scalars are on the host
@@ -1550,6 +1701,7 @@ int build_tables_device(baz_music_ctx* c, TableSet& T)
             T.cs_ok = true;
         }
     }
+#ifdef BAZ_MUSIC_LAB
     if (T.dIP) HIP_TRY(c, hipMemsetAsync(T.dIP, 0, i8p_image_bytes(steps), s));
     if (T.dIP && finite) {    // 2 .. 4 antennas: level-packed digit operands
         double sf = 0.0;
@@ -1559,6 +1711,7 @@ int build_tables_device(baz_music_ctx* c, TableSet& T)
             T.i8_ok = true;
         }
     }
+#endif
     if (T.dIB && finite) {    // int8-matrix-core scan: the table's digit image
         double sf = 0.0;
         if (i8_params_from(fmax, m, T.i8, sf)) {
@@ -1610,10 +1763,10 @@ int retune(baz_music_ctx* c, const float* table_ri, bool first)
 void free_slots(baz_music_ctx* c)
 {
     for (auto& sl : c->slot) {
-        if (sl.in) (void)hipFree(sl.in);
-        if (sl.al) (void)hipFree(sl.al);
+        if (sl.in) (void)dev_free(sl.in);
+        if (sl.al) (void)dev_free(sl.al);
         if (sl.h_al) (void)hipHostFree(sl.h_al);
-        if (sl.spec) (void)hipFree(sl.spec);
+        if (sl.spec) (void)dev_free(sl.spec);
         if (sl.h2d) (void)hipEventDestroy(sl.h2d);
         if (sl.comp) (void)hipEventDestroy(sl.comp);
         if (sl.d2h) (void)hipEventDestroy(sl.d2h);
@@ -1633,10 +1786,10 @@ int ensure_slots(baz_music_ctx* c, uint32_t chunk, bool want_spec)
     if (!c->s_h2d) HIP_TRY(c, hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
     if (!c->s_d2h) HIP_TRY(c, hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
     for (auto& sl : c->slot) {
-        HIP_TRY(c, hipMalloc((void**)&sl.in, (size_t)cap * c->nsamples * 8));
-        HIP_TRY(c, hipMalloc((void**)&sl.al, (size_t)cap * c->n * 8));
+        HIP_TRY(c, dev_malloc((void**)&sl.in, (size_t)cap * c->nsamples * 8));
+        HIP_TRY(c, dev_malloc((void**)&sl.al, (size_t)cap * c->n * 8));
         HIP_TRY(c, hipHostMalloc((void**)&sl.h_al, (size_t)cap * c->n * 8, hipHostMallocDefault));
-        if (spec) HIP_TRY(c, hipMalloc((void**)&sl.spec, (size_t)cap * c->res * 4));
+        if (spec) HIP_TRY(c, dev_malloc((void**)&sl.spec, (size_t)cap * c->res * 4));
         HIP_TRY(c, hipEventCreateWithFlags(&sl.h2d, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&sl.comp, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&sl.d2h, hipEventDisableTiming));
@@ -1829,6 +1982,37 @@ int begin_statistic(baz_music_ctx* c)
     return BAZ_MUSIC_OK;
 }
 
+// A launch sequence is REFUSED (BAZ_MUSIC_E_HIP, message in baz_music_last_hip_error) when a device pointer it is about to hand to a
+// kernel -- or to offset -- is null: a bug of that kind must come back as an error code, never as a GPU memory fault that takes the
+// process down (BENCH_r05: "Memory access fault ... on address 0x10000").  Host-side, a dozen compares per call.
+int refuse_null(baz_music_ctx* c, const void* p, const char* name)
+{
+    if (p) return BAZ_MUSIC_OK;
+    snprintf(c->hip_err, sizeof(c->hip_err), "internal: device pointer %s is null at launch (m=%u n=%u res=%u): launch refused", name, c->m, c->n, c->res);
+    return BAZ_MUSIC_E_HIP;
+}
+#define BAZ_REQUIRE(c, ptr)                                  \
+    do {                                                     \
+        if (const int rn__ = refuse_null((c), (c)->ptr, #ptr)) return rn__; \
+    } while (0)
+
+int check_launch_pointers(baz_music_ctx* c)
+{
+    BAZ_REQUIRE(c, dRefined);
+    BAZ_REQUIRE(c, dR);
+    BAZ_REQUIRE(c, dRedo);
+    if (c->wide) {
+        BAZ_REQUIRE(c, dGw); BAZ_REQUIRE(c, dWS); BAZ_REQUIRE(c, dSw); BAZ_REQUIRE(c, dTA); BAZ_REQUIRE(c, dA2);
+        if (c->wide_mfma) { BAZ_REQUIRE(c, dTB); BAZ_REQUIRE(c, dA2p); }
+        return BAZ_MUSIC_OK;
+    }
+    BAZ_REQUIRE(c, dQ); BAZ_REQUIRE(c, dG); BAZ_REQUIRE(c, dCand); BAZ_REQUIRE(c, dFB); BAZ_REQUIRE(c, dTB);
+    if (short_form_applies(c->m, c->n)) { BAZ_REQUIRE(c, dSs); BAZ_REQUIRE(c, dA2p); }
+    if (c->cs_ok) BAZ_REQUIRE(c, dCS);
+    if (c->i8_ok && wants_i8_image(c)) BAZ_REQUIRE(c, dIB);
+    return BAZ_MUSIC_OK;
+}
+
 int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void* d_ang, void* d_lvl,
                           void* d_spec)
 {
@@ -1840,6 +2024,8 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
     int r = ensure_workspace(c, batch);
     if (r) return r;
     r = reserve_candidates(c, batch);
+    if (r) return r;
+    r = check_launch_pointers(c);
     if (r) return r;
     const uint32_t qstride = baz_music_q_stride(batch);
     if (c->fused_covevd) {
@@ -1856,9 +2042,9 @@ int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, vo
         const size_t need = (size_t)batch * c->res;
         if (need > c->peak_spec_cap) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (c->dPeakSpec) (void)hipFree(c->dPeakSpec);
+            if (c->dPeakSpec) (void)dev_free(c->dPeakSpec);
             c->dPeakSpec = nullptr; c->peak_spec_cap = 0;
-            HIP_TRY(c, hipMalloc((void**)&c->dPeakSpec, need * sizeof(float)));
+            HIP_TRY(c, dev_malloc((void**)&c->dPeakSpec, need * sizeof(float)));
             c->peak_spec_cap = need;
         }
         spec = c->dPeakSpec;
@@ -1893,9 +2079,9 @@ int create_tables(baz_music_ctx* c, const float* table_ri)
     if (hipStreamCreateWithPriority(&c->s_tab, hipStreamNonBlocking, prio) != hipSuccess) return BAZ_MUSIC_E_HIP;
     if (hipEventCreateWithFlags(&c->ev_swap, hipEventDisableTiming) != hipSuccess) return BAZ_MUSIC_E_HIP;
     const size_t raw_bytes = (size_t)c->res * c->m * 2 * sizeof(float);
-    if (hipMalloc((void**)&c->dRaw, raw_bytes) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (dev_malloc((void**)&c->dRaw, raw_bytes) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     if (hipHostMalloc((void**)&c->hRaw, raw_bytes, hipHostMallocDefault) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
-    if (hipMalloc(&c->dTabStats, sizeof(baztab::TableStats)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
+    if (dev_malloc(&c->dTabStats, sizeof(baztab::TableStats)) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     if (hipHostMalloc(&c->hTabStats, sizeof(baztab::TableStats), hipHostMallocDefault) != hipSuccess) return BAZ_MUSIC_E_NOMEM;
     TableSet first;
     int r = alloc_table_set(c, first);
@@ -1978,7 +2164,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
             }
             if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SUB_EVD")) c->sub_evd = atoi(v);                   // lab / tests
             if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_WIDE_LITERAL")) c->wide_literal_only = atoi(v);   // lab / tests
-            if (hipMalloc((void**)&c->dRefined, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+            if (dev_malloc((void**)&c->dRefined, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMemset(c->dRefined, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
             c->wide_cov_mfma = 1;
             c->wide_cov_blocks = 2u * (uint32_t)std::max(1, prop.multiProcessorCount);
@@ -2030,17 +2216,23 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COARSE_STATS")) c->coarse_stats = atoi(v);          // lab
         if (m <= 8) {
             c->cs_tiles = round_up((resolution + 15) / 16, 8);
-            if (hipMalloc((void**)&c->dMargin, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+            if (dev_malloc((void**)&c->dMargin, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMemset(c->dMargin, 0, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         }
         if (const char* v = getenv("BAZ_MUSIC_EXACT")) c->i8_on = atoi(v) ? 0 : 1;                // A/B: 1 = the fp64 scan everywhere
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8_ABL")) c->i8_abl = atoi(v);                  // lab
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SEQ_WALK")) c->seq_walk = atoi(v) ? 1 : 0;        // lab
+#ifdef BAZ_MUSIC_LAB
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SORT")) c->sort_mode = atoi(v) < 0 ? -1 : (atoi(v) ? 1 : 0);   // lab / tests: 0 never, 1 always
-        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COVEVD_TASK_ITEMS")) { const int t = atoi(v); c->covevd_task_items = (t == 64 || t == 32 || t == 16) ? t : 0; }
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8P")) c->i8p_on = atoi(v) ? 1 : 0;             // lab: 1 = the level-packed int8 scan at m <= 4
-        if (wants_i8_image(c) || (c->i8p_on && m <= 4 && n <= 4)) {
-            if (hipMalloc((void**)&c->dI8Stat, 8 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+#endif
+        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COVEVD_TASK_ITEMS")) { const int t = atoi(v); c->covevd_task_items = (t == 64 || t == 32 || t == 16) ? t : 0; }
+        bool wants_i8_stat = wants_i8_image(c);
+#ifdef BAZ_MUSIC_LAB
+        wants_i8_stat = wants_i8_stat || (c->i8p_on && m <= 4 && n <= 4);
+#endif
+        if (wants_i8_stat) {
+            if (dev_malloc((void**)&c->dI8Stat, 8 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
             if (hipMemset(c->dI8Stat, 0, 8 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         }
         {
@@ -2052,7 +2244,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
             if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COV_BLOCKS_PER_CU"))    // lab: grid of the covariance kernel
                 if (atoi(v) > 0) c->cov4_resident_blocks = (uint32_t)atoi(v) * (uint32_t)std::max(1, prop.multiProcessorCount);
         }
-        if (hipMalloc((void**)&c->dRefined, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
+        if (dev_malloc((void**)&c->dRefined, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
         if (hipMemset(c->dRefined, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         r = create_tables(c, table_ri);
     } while (0);
@@ -2079,6 +2271,10 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     c->stage_name[BAZ_MUSIC_STAGE_SCAN] = buf;
     snprintf(buf, sizeof(buf), "bazmusic::topn_merge_kernel<%u>", topn_list_len(n));
     c->stage_name[BAZ_MUSIC_STAGE_MERGE] = buf;
+    snprintf(c->scan_names[0], sizeof(c->scan_names[0]), "bazmusic::scan_mfma_kernel<%u,", m);
+    snprintf(c->scan_names[1], sizeof(c->scan_names[1]), "bazmusic::scan_i8_kernel<%u,", m);
+    snprintf(c->scan_names[2], sizeof(c->scan_names[2]), "bazmusic::scan_coarse_kernel<%u,", m);
+    snprintf(c->scan_names[3], sizeof(c->scan_names[3]), "bazmusic::scan_i8p_kernel<%u,", m);
     *out = c;
     return BAZ_MUSIC_OK;
 }
@@ -2099,31 +2295,33 @@ void baz_music_destroy(baz_music_ctx* c)
             install_table_set(c, act);
             free_table_set(c->shadow);
         }
-        if (c->dRaw) (void)hipFree(c->dRaw);
+        if (c->dRaw) (void)dev_free(c->dRaw);
         if (c->hRaw) (void)hipHostFree(c->hRaw);
-        if (c->dTabStats) (void)hipFree(c->dTabStats);
+        if (c->dTabStats) (void)dev_free(c->dTabStats);
         if (c->hTabStats) (void)hipHostFree(c->hTabStats);
         if (c->ev_swap) (void)hipEventDestroy(c->ev_swap);
         if (c->s_tab) (void)hipStreamDestroy(c->s_tab);
-        if (c->dKeys) (void)hipFree(c->dKeys);
-        if (c->dPerm) (void)hipFree(c->dPerm);
-        if (c->dHist) (void)hipFree(c->dHist);
-        if (c->dCursor) (void)hipFree(c->dCursor);
-        if (c->dFire) (void)hipFree(c->dFire);
+#ifdef BAZ_MUSIC_LAB
+        if (c->dKeys) (void)dev_free(c->dKeys);
+        if (c->dPerm) (void)dev_free(c->dPerm);
+        if (c->dHist) (void)dev_free(c->dHist);
+        if (c->dCursor) (void)dev_free(c->dCursor);
+        if (c->dFire) (void)dev_free(c->dFire);
         if (c->hFire) (void)hipHostFree(c->hFire);
-        if (c->dCand) (void)hipFree(c->dCand);
-        if (c->dR) (void)hipFree(c->dR);
-        if (c->dQ) (void)hipFree(c->dQ);
-        if (c->dG) (void)hipFree(c->dG);
-        if (c->dRedo) (void)hipFree(c->dRedo);
-        if (c->dSs) (void)hipFree(c->dSs);
-        if (c->dI8Stat) (void)hipFree(c->dI8Stat);
-        if (c->dMargin) (void)hipFree(c->dMargin);
-        if (c->dRefined) (void)hipFree(c->dRefined);
-        if (c->dPeakSpec) (void)hipFree(c->dPeakSpec);
-        if (c->dGw) (void)hipFree(c->dGw);
-        if (c->dWS) (void)hipFree(c->dWS);
-        if (c->dSw) (void)hipFree(c->dSw);
+#endif
+        if (c->dCand) (void)dev_free(c->dCand);
+        if (c->dR) (void)dev_free(c->dR);
+        if (c->dQ) (void)dev_free(c->dQ);
+        if (c->dG) (void)dev_free(c->dG);
+        if (c->dRedo) (void)dev_free(c->dRedo);
+        if (c->dSs) (void)dev_free(c->dSs);
+        if (c->dI8Stat) (void)dev_free(c->dI8Stat);
+        if (c->dMargin) (void)dev_free(c->dMargin);
+        if (c->dRefined) (void)dev_free(c->dRefined);
+        if (c->dPeakSpec) (void)dev_free(c->dPeakSpec);
+        if (c->dGw) (void)dev_free(c->dGw);
+        if (c->dWS) (void)dev_free(c->dWS);
+        if (c->dSw) (void)dev_free(c->dSw);
         host_unregister_all_locked(c);
         free_slots(c);
         if (c->ev_in) (void)hipEventDestroy(c->ev_in);
@@ -2176,9 +2374,16 @@ int baz_music_reserve(baz_music_ctx* c, uint32_t max_batch)
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->wide) return ensure_wide_workspace(c, std::min(max_batch, wide_pass_items(c)));
+    if (c->wide) {
+        const uint32_t pass = std::min(max_batch, wide_pass_items(c));
+        const int rw = ensure_wide_workspace(c, pass);
+        // ... and the candidate lists of the matrix-core scan's largest pass (they used to be allocated inside the first process call)
+        return (rw || !c->wide_mfma || c->wide_literal_only) ? rw : ensure_candidates(c, wide_cand_entries(c, pass));
+    }
     int r = ensure_workspace(c, max_batch);
-    if (r == BAZ_MUSIC_OK && c->dKT) r = ensure_sort_workspace(c, max_batch);
+#ifdef BAZ_MUSIC_LAB
+    if (r == BAZ_MUSIC_OK && c->sort_mode != 0) r = ensure_sort_workspace(c, max_batch);
+#endif
     return r ? r : reserve_candidates(c, max_batch);
 }
 
@@ -2449,11 +2654,10 @@ const char* baz_music_stage_name(baz_music_ctx* c, int stage)
     if (stage == BAZ_MUSIC_STAGE_SCAN && !c->wide) {
         // the kernel the LAST scan launch took (it depends on the wiring of the call and on the table in force: ADVICE r4);
         // before the first launch: what a call with the spectrum port would take
+        // (the four names are formatted once, in baz_music_create: the pointer handed out stays valid for the context's life)
         std::lock_guard<std::mutex> lk(c->mtx);
         const int kind = c->scan_kind >= 0 ? c->scan_kind : (i8_active(c) ? 1 : (i8p_active(c) ? 3 : 0));
-        char buf[128];
-        snprintf(buf, sizeof(buf), kind == 1 ? "bazmusic::scan_i8_kernel<%u," : (kind == 2 ? "bazmusic::scan_coarse_kernel<%u," : (kind == 3 ? "bazmusic::scan_i8p_kernel<%u," : "bazmusic::scan_mfma_kernel<%u,")), c->m);
-        c->stage_name[stage] = buf;
+        return c->scan_names[kind >= 0 && kind < 4 ? kind : 0];
     }
     return c->stage_name[stage].c_str();
 }
@@ -2516,7 +2720,7 @@ int baz_music_debug_coarse_margin(baz_music_ctx* c, const void* d_in, uint32_t b
     const uint32_t groups = (batch + per_group - 1) / per_group, nph = c->cs_tiles / (big ? 4 : 8);
     float* d_dump = nullptr;                     // lab (BAZ_MUSIC_DEBUG_DUMP=<file>): every ratio, [item][bin] float32
     const char* dump_path = BAZ_LAB_ENV("BAZ_MUSIC_DEBUG_DUMP");
-    if (dump_path && hipMalloc((void**)&d_dump, (size_t)batch * c->res * sizeof(float)) != hipSuccess) d_dump = nullptr;
+    if (dump_path && dev_malloc((void**)&d_dump, (size_t)batch * c->res * sizeof(float)) != hipSuccess) d_dump = nullptr;
     if (d_dump) (void)hipMemsetAsync(d_dump, 0, (size_t)batch * c->res * sizeof(float), c->stream);
 #define BAZ_VAL(MV, NV, RGV, TPV)                                                                                           \
     hipLaunchKernelGGL((scan_coarse_kernel<MV, NV, RGV, TPV, true>), dim3(groups), dim3(256), 0, c->stream, c->dQ, c->dCS, \
@@ -2541,7 +2745,7 @@ int baz_music_debug_coarse_margin(baz_music_ctx* c, const void* d_in, uint32_t b
         std::vector<float> h((size_t)batch * c->res);
         if (hipMemcpy(h.data(), d_dump, h.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE* f = fopen(dump_path, "wb")) { fwrite(h.data(), sizeof(float), h.size(), f); fclose(f); }
-        (void)hipFree(d_dump);
+        (void)dev_free(d_dump);
     }
     const unsigned int bits = (unsigned int)(packed >> 32);
     std::memcpy(worst, &bits, sizeof(float));
@@ -2755,10 +2959,17 @@ size_t baz_music_debug_table_image(baz_music_ctx* c, int which, void* out, size_
         case 4: src = c->dA2p; bytes = pad_steps * 64 * sizeof(double); break;
         case 5: src = c->dTA; bytes = (size_t)c->m * c->res * sizeof(float2); break;
         case 6: src = c->dA2; bytes = (size_t)c->res * sizeof(double); break;
+#ifdef BAZ_MUSIC_LAB
         case 8: src = c->dIP; bytes = c->dIP ? i8p_image_bytes(c->fb_steps) : 0; break;
+#endif
         case 7: {
             double p[TABLE_NPARAMS];
-            pack_table_params(active_table_set(c), c->dCS != nullptr, c->dIB != nullptr || c->dIP != nullptr, p);
+#ifdef BAZ_MUSIC_LAB
+            const bool any_i8 = c->dIB != nullptr || c->dIP != nullptr;
+#else
+            const bool any_i8 = c->dIB != nullptr;
+#endif
+            pack_table_params(active_table_set(c), c->dCS != nullptr, any_i8, p);
             if (out && out_bytes >= sizeof(p)) std::memcpy(out, p, sizeof(p));
             return sizeof(p);
         }
@@ -2788,17 +2999,10 @@ size_t baz_music_debug_host_table_image(uint32_t m, uint32_t n, uint32_t resolut
         bytes.resize(v.size() * sizeof(double));
         std::memcpy(bytes.data(), v.data(), bytes.size());
     };
-    auto a2_of = [&](uint32_t b) {
-        double v = 0.0;
-        for (uint32_t i = 0; i < m; ++i) {
-            const double re = table_ri[2 * ((size_t)b * m + i)], im = table_ri[2 * ((size_t)b * m + i) + 1];
-            v += re * re + im * im;
-        }
-        return v;
-    };
+    auto a2_of = [&](uint32_t b) { return baztab::tab_a2(table_ri + 2 * (size_t)b * m, m); };   // the device builders' own routine (contraction off)
     const bool has_cs = !wide && m <= 8;
     const bool has_i8 = !wide && m >= 6 && n <= 4 && i8_image_bytes(m, steps) <= I8_IMAGE_LIMIT;
-    const bool has_i8p = m <= 4 && n <= 4;
+    [[maybe_unused]] const bool has_i8p = m <= 4 && n <= 4;
     const bool has_a2p = wide ? (n <= 8) : short_form_applies(m, n);
     const bool has_tb = wide ? (n <= 8) : true;
     std::vector<double> F;
@@ -2830,12 +3034,14 @@ size_t baz_music_debug_host_table_image(uint32_t m, uint32_t n, uint32_t resolut
             if (!build_i8_image(F, m, res, steps, bytes, ip)) return 0;
             break;
         }
+#ifdef BAZ_MUSIC_LAB
         case 8: {
             if (!has_i8p) return 0;
             I8Params ip = {};
             if (!build_i8p_image(F, m, res, steps, bytes, ip)) return 0;
             break;
         }
+#endif
         case 4: {
             if (!has_a2p) return 0;
             std::vector<double> a2((size_t)(steps + 2) * 64, 1e300);
@@ -2893,8 +3099,12 @@ int baz_music_debug_sort_state(baz_music_ctx* c, uint64_t out[5])
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+#ifdef BAZ_MUSIC_LAB
     out[0] = c->sorted_calls; out[1] = c->unsorted_calls;
     out[2] = c->hFire ? c->hFire[0] : 0; out[3] = c->hFire ? c->hFire[1] : 0; out[4] = c->hFire ? (c->hFire[2] & 1ull) : 0;
+#else
+    for (int k = 0; k < 5; ++k) out[k] = 0;               // the release library never sorts and keeps no fire statistic
+#endif
     return BAZ_MUSIC_OK;
 }
 
@@ -2911,6 +3121,31 @@ uint64_t baz_music_bytes_per_item(const baz_music_ctx* c, int with_spectrum)
 {
     if (!c) return 0;
     return 8ull * c->nsamples + 8ull * c->n + (with_spectrum ? 4ull * c->res : 0ull);
+}
+
+// Lab build with BAZ_MUSIC_GUARD=1: checks the guard zones of every live device buffer of this library (synchronises the device) and returns
+// the number of zones found damaged since the process started (at this check or at an earlier free); 0 when the guard is off / in the release build.
+int baz_music_debug_guard_check(void)
+{
+#ifdef BAZ_MUSIC_LAB
+    if (!guard_on()) return 0;
+    std::lock_guard<std::mutex> lk(g_guard_mtx);
+    unsigned long long now = 0;
+    for (const auto& g : g_guards) now += (unsigned long long)guard_check_one(g.first, g.second);
+    return (int)std::min<unsigned long long>(g_guard_damaged + now, 0x7FFFFFFFull);
+#else
+    return 0;
+#endif
+}
+
+// 1 when this library allocates with guard zones (lab build, BAZ_MUSIC_GUARD=1), else 0
+int baz_music_debug_guard_active(void)
+{
+#ifdef BAZ_MUSIC_LAB
+    return guard_on() ? 1 : 0;
+#else
+    return 0;
+#endif
 }
 
 const char* baz_music_strerror(int code)

@@ -18,7 +18,11 @@
 // gfx950 only.
 #pragma once
 
-#include "scan_i8p_kernels.hip.h"     // (scan_i8_kernels.hip.h, scan_coarse_kernels.hip.h, music_kernels.hip.h: layouts and their constexpr helpers)
+#include "scan_i8_kernels.hip.h"      // (scan_coarse_kernels.hip.h, music_kernels.hip.h: layouts and their constexpr helpers)
+#include "scan_coarse_kernels.hip.h"
+#ifdef BAZ_MUSIC_LAB
+#include "scan_i8p_kernels.hip.h"
+#endif
 
 namespace baztab {
 
@@ -62,6 +66,7 @@ __host__ __device__ inline float f16_value(uint16_t h)
 // bilinear-form table of a^H Q a.  `a` = the bin's m complex fp32 entries; widened exactly, products exact, one rounding.
 __host__ __device__ inline double tab_F(const float* __restrict__ a, uint32_t m, uint32_t e)
 {
+#pragma clang fp contract(off)       // (both products are exact -- 24-bit factors --, so a contraction could not change the one rounding; stated anyway)
     const uint32_t r = e / m, c = e - r * m;
     if (r == c) {
         const double re = a[2 * r], im = a[2 * r + 1];
@@ -79,6 +84,7 @@ __host__ __device__ inline double tab_F(const float* __restrict__ a, uint32_t m,
 // ||a||^2 of one bin, antenna by antenna (the host loops' order)
 __host__ __device__ inline double tab_a2(const float* __restrict__ a, uint32_t m)
 {
+#pragma clang fp contract(off)       // v + (re^2 + im^2) as written on both sides: never fma(re, re, fma(im, im, v))
     double v = 0.0;
     for (uint32_t i = 0; i < m; ++i) {
         const double re = a[2 * i], im = a[2 * i + 1];
@@ -292,7 +298,8 @@ __global__ __launch_bounds__(256) void build_i8_kernel(const float* __restrict__
     }
 }
 
-// Level-packed int8 operands for 2 .. 4 antennas (scan_i8p_kernels.hip.h): one thread per bin = 16 terms x 7 digits; digit s of the
+#ifdef BAZ_MUSIC_LAB
+// Level-packed int8 operands for 2 .. 4 antennas (scan_i8p_kernels.hip.h; lab builds only): one thread per bin = 16 terms x 7 digits; digit s of the
 // terms goes to slot s of B (s <= 3) or slot s - 4 of B' (the image's second half), 16 B each.  Padded steps, bins outside the table,
 // terms e >= m^2 and B' slot 3 stay zero (the caller clears the image first).
 __global__ __launch_bounds__(256) void build_i8p_kernel(const float* __restrict__ tab, uint32_t m, uint32_t res, uint32_t steps, double sf,
@@ -330,5 +337,6 @@ __global__ __launch_bounds__(256) void build_i8p_kernel(const float* __restrict_
         *dst = make_uint4(dig[s][0], dig[s][1], dig[s][2], dig[s][3]);
     }
 }
+#endif   // BAZ_MUSIC_LAB
 
 }  // namespace baztab

@@ -44,6 +44,10 @@ def init_process_group(use_gpu: bool, local_rank: int = 0, try_nccl: bool = Fals
         if use_gpu:
             import torch
             torch.cuda.set_device(local_rank)
+        elif try_nccl:
+            import torch
+            if torch.cuda.is_available() and local_rank < torch.cuda.device_count():
+                torch.cuda.set_device(local_rank)          # a rehearsal on a box WITH GPUs: RCCL comes up, its tensors live on this rank's device
         if (use_gpu or try_nccl) and os.environ.get("BAZ_BENCH_BACKEND", "nccl") == "nccl":
             backend = "nccl"          # = RCCL on ROCm; used for the barrier / clock only
         _REQUESTED = backend

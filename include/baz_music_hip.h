@@ -188,13 +188,21 @@ BAZ_MUSIC_API size_t baz_music_debug_i8_image(uint32_t m, uint32_t resolution, c
 BAZ_MUSIC_API size_t baz_music_debug_table_image(baz_music_ctx* ctx, int which, void* out, size_t out_bytes);
 BAZ_MUSIC_API size_t baz_music_debug_host_table_image(uint32_t m, uint32_t n, uint32_t resolution, const float* table_ri,
                                                       int which, void* out, size_t out_bytes);
-/*   sorting     : without port 2 (m <= 8) a batch whose items are unrelated -- every item its own emitter angles -- makes the gated scan
- *                          evaluate the UNION of 16 rows' nulls per tile; while that scan reports a high share of exact evaluations the context
- *                          orders the items of every batch by the position of their two deepest nulls first (a counting sort on a 16-bit key from a
- *                          float32 sample of the spectrum; gr_baz_amd/csrc/sort_kernels.hip.h) and hands the scan the order as an index list.  ang /
- *                          lvl are bit-identical either way.  `sort_state`: launches of the gated scan with / without the sort, and the exact
- *                          evaluations / tile pairs walked / sorted flag of the last finished one. */
+/*   sorting     : LAB BUILD ONLY (libbaz_music_hip_lab.so, BAZ_MUSIC_SORT): measured and NOT shipped (profiles/r05_sort_negative.txt) -- the
+ *                          release library has none of its kernels, never orders a batch and keeps no fire statistic; there `sort_state`
+ *                          returns five zeros.  In the lab build, without port 2 (m <= 4) the context can order the items of a batch by the
+ *                          position of their two deepest nulls (a counting sort on a 16-bit key from a float32 sample of the spectrum;
+ *                          gr_baz_amd/csrc/sort_kernels.hip.h) and hand the gated scan the order as an index list; ang / lvl are bit-identical
+ *                          either way.  `sort_state`: launches of the gated scan with / without the sort, and the exact evaluations / tile
+ *                          pairs walked / sorted flag of the last finished one. */
 BAZ_MUSIC_API int baz_music_debug_sort_state(baz_music_ctx* ctx, uint64_t out[5]);
+/*   guard zones : LAB BUILD ONLY, process environment BAZ_MUSIC_GUARD=1: every device buffer of the library lies between two 64-KiB zones
+ *                          filled with a pattern (and is itself pre-filled with it).  `guard_check` synchronises the device, compares the
+ *                          zones of every live buffer and returns the number of zones found overwritten since the process started (a free
+ *                          checks its buffer too) -- 0 means no kernel wrote outside a buffer of this library; details go to stderr.
+ *                          `guard_active`: 1 when the guard is on.  Both return 0 in the release library. */
+BAZ_MUSIC_API int baz_music_debug_guard_check(void);
+BAZ_MUSIC_API int baz_music_debug_guard_active(void);
 /*   (host only) the bin ranges per item the int8 scan launches with: whole rounds of the `slots` resident workgroups. */
 BAZ_MUSIC_API uint32_t baz_music_debug_i8_nsplit(uint32_t batch, uint32_t nsteps, uint32_t slots);
 BAZ_MUSIC_API uint32_t baz_music_q_stride(uint32_t batch);

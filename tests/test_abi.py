@@ -102,10 +102,30 @@ def test_product_never_imports_the_oracle():
                                  txt, re.M):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
-    # bench.py may use the oracle only inside its cpu_baseline leg
+    # bench.py uses the oracle in exactly two functions -- cpu_baseline (the CPU leg) and verify_against_oracle (the checker of what a
+    # timed region left in the output buffers) -- and never inside a timed region: every call of the checker comes AFTER the timing
+    # loop of the function it is in
+    import ast
     src = open(os.path.join(ROOT, "bench.py")).read()
-    body_outside = src[:src.index("def cpu_baseline(")] + src[src.index("def main():"):]
-    assert not re.search(r"^\s*(from|import)\s+oracle\b", body_outside, re.M)
+    tree = ast.parse(src)
+    users = set()
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        for node in ast.walk(fn):
+            if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
+                users.add(fn.name)
+            if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+                users.add(fn.name)
+    assert users == {"cpu_baseline", "verify_against_oracle"}, users
+    assert not [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(n)]      # nothing at module level
+
+    def call_lines(fn, name):
+        return [n.lineno for n in ast.walk(fn) if isinstance(n, ast.Call) and getattr(n.func, "id", getattr(n.func, "attr", None)) == name]
+    fns = {n.name: n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)}
+    main_timed_end = max(call_lines(fns["main"], "max_over_ranks"))            # the last statement pair of a timed round
+    assert call_lines(fns["main"], "verify_against_oracle") and min(call_lines(fns["main"], "verify_against_oracle")) > main_timed_end
+    assert min(call_lines(fns["main"], "cpu_baseline")) > main_timed_end
+    for leg in ("extra_music", "extra_cfg5"):
+        assert min(call_lines(fns[leg], "verify_against_oracle")) > max(call_lines(fns[leg], "timed_loop")), leg
 
 
 def test_headers_are_plain_c():

@@ -45,11 +45,13 @@ def test_roofline_fields_of_the_kept_bench_line_are_consistent():
     assert cb["kind"] == "reference" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
 
 
-def test_host_fed_extra_of_the_bench_stays_in_its_own_process():
-    """bench.py's secondary host-fed entry runs scripts/hostfed_extra.py in a subprocess: without a GPU it reports an error
-    entry instead of raising (so it can never take the headline down)."""
-    out = _bench().host_fed_extra(timeout_s=120)
-    assert isinstance(out, dict) and ("error" in out or "runs" in out)
+def test_every_secondary_leg_of_the_bench_stays_in_its_own_process():
+    """bench.py runs each secondary leg as `python bench.py --extra-leg NAME` in a subprocess with a time limit: without a GPU the leg
+    dies ("needs a GPU") and the parent gets an error ENTRY instead of an exception -- so a leg can never take the headline down."""
+    for leg in ("cfg2_host_fed_gr37_model", "wide_m64_n2"):
+        out = _bench().run_leg_subprocess(leg, timeout_s=120)
+        assert isinstance(out, dict) and ("error" in out or "runs" in out or "snapshots_per_s" in out)
+        assert "leg_wall_s" in out
 
 
 def test_pmc_traffic_follows_from_the_kept_raw_counter_rows():

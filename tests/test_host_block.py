@@ -65,6 +65,30 @@ def test_helper_table_fast_path_and_its_fallback(monkeypatch):
         got = np.array(h.calculate_antenna_array_response(arr, res, l))
         assert np.array_equal(got.view(np.float64), w.view(np.float64))
     assert calls.count(True) == 3
+    # a BLAS that rounds only SOME rows of the matrix product differently (a block tail, a thread partition) -- rows the 64-row sample
+    # does not visit -- must not get through either: every element is compared with a restatement of the rounding the sample shows
+    monkeypatch.setattr(h.numpy, "inner", real_inner)
+    arr, res, l = cases[1]
+    sample = set([0, res - 1] + [(k * 2654435761) % res for k in range(1, 63)])
+    odd_rows = [r for r in range(res) if r not in sample][100:103]
+
+    def partly_off(a, b):
+        v = real_inner(a, b)
+        if np.ndim(a) == 2:
+            v = v.copy()
+            v[odd_rows, 0] *= (1.0 + 2.0 ** -52)
+        return v
+    monkeypatch.setattr(h.numpy, "inner", partly_off)
+    calls.clear()
+    got = np.array(h.calculate_antenna_array_response(arr, res, l))
+    assert np.array_equal(got.view(np.float64), want[1].view(np.float64))
+    assert calls.count(True) == (0 if fell_back else 1) or calls.count(True) == 1
+    # ... and the switch that forces the reference's loop
+    monkeypatch.setattr(h.numpy, "inner", real_inner)
+    monkeypatch.setenv("BAZ_MUSIC_HELPER_PER_ELEMENT", "1")
+    calls.clear()
+    got = np.array(h.calculate_antenna_array_response(*cases[0]))
+    assert np.array_equal(got.view(np.float64), want[0].view(np.float64)) and calls == [True]
     if fell_back:
         pytest.skip("this BLAS rounds numpy.inner over a matrix differently from the per-element call: the helper used its per-element loop")
 

@@ -275,3 +275,76 @@ def test_retune_between_batches_in_flight_never_tears(gpu_device):
     for lab, (a, s) in zip(order, outs):
         got = s[:8].cpu().numpy().astype(np.float64)
         assert np.max(np.abs(got - want[lab]) / want[lab]) <= 1e-5, "batch expected table %s" % lab
+
+
+# ---------------------------------------------------------------------------------------------------------- round 6
+# the retune-with-batches-in-flight machinery had GPU tests at cfg2 / cfg3 only; bench.py drove it on the run-time-m
+# path (32, 64 antennas), on the gated scan (port 2 not wired) and on cfg5's shape, and the driver's run of it died with a GPU
+# memory fault.  The same never-torn check as above on every one of those paths.
+IN_FLIGHT_SHAPES = [
+    # name, m, n, nsamples, res, batch, spectrum port wired
+    ("cfg5", 16, 2, 4096, 3600, 4096, True),
+    ("cfg2_default_wiring", 4, 2, 1024, 3600, 32768, False),
+    ("cfg3_default_wiring", 8, 2, 4096, 9000, 4096, False),
+    ("m9_short_form", 9, 2, 576, 1000, 4096, True),
+    ("wide24_n2", 24, 2, 1536, 720, 1024, True),
+    ("wide24_n8", 24, 8, 1536, 720, 512, True),
+    ("wide32_bench_leg", 32, 2, 4096, 3600, 4096, True),
+    ("wide64_bench_leg", 64, 2, 4096, 3600, 2048, True),
+    ("wide64_n8", 64, 8, 4096, 360, 512, True),
+    ("wide40_n12_literal_scan", 40, 12, 2560, 360, 256, True),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", IN_FLIGHT_SHAPES, ids=[s[0] for s in IN_FLIGHT_SHAPES])
+def test_retune_between_batches_in_flight_on_every_scan_path(gpu_device, shape):
+    import torch
+    from oracle import music_ref as mr
+    capi = _capi()
+    _, m, n, N, res, B, with_spec = shape
+    arr = mo.array_geometry(m)
+    tabs = {k: mo.steering_table_c64(arr, res, mo.FREQUENCY * f, mo.SPACING) for k, f in (("A", 1.0), ("B", 0.9), ("C", 1.1))}
+    base = mo.synth_items(32, m, N, arr, mo.FREQUENCY, mo.SPACING, snr_db=20.0, seed=606)
+    want = {k: mr.work_batch(np.ascontiguousarray(base[:4]), t, m, n) for k, t in tabs.items()}
+    x = torch.from_numpy(np.ascontiguousarray(np.tile(base, ((B + 31) // 32, 1))[:B]).view(np.float32)).to(gpu_device)
+    outs = [(torch.zeros(B, n, dtype=torch.float32, device=gpu_device), torch.zeros(B, n, dtype=torch.float32, device=gpu_device),
+             torch.zeros(B, res, dtype=torch.float32, device=gpu_device) if with_spec else None) for _ in range(6)]
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream(device=gpu_device)          # as bench.py drives it: a caller-owned stream
+    with capi.Context(m, n, N, res, tabs["A"]) as ctx:
+        ctx.set_stream(stream.cuda_stream)
+        ctx.reserve(B)
+        for rep in range(3):                               # three rounds: the sets change roles several times
+            order = []
+            for k, (a, l, s) in enumerate(outs):
+                ctx.process_device(x.data_ptr(), B, a.data_ptr(), l.data_ptr(), s.data_ptr() if with_spec else None)
+                order.append("ABC"[min(k // 2, 2)])
+                if k == 1:
+                    ctx.set_table(tabs["B"])
+                if k == 3:
+                    ctx.set_table(tabs["C"])
+            ctx.sync()
+            for lab, (a, l, s) in zip(order, outs):
+                ao, lo, so = want[lab]
+                assert np.array_equal(a[:4].cpu().numpy(), ao), "round %d: DoA bins of a batch expected under table %s" % (rep, lab)
+                assert np.max(np.abs(l[:4].cpu().numpy().astype(np.float64) - lo) / lo) <= 1e-5
+                if with_spec:
+                    got = s[:4].cpu().numpy().astype(np.float64)
+                    assert np.max(np.abs(got - so) / so) <= 1e-5, "round %d: batch expected table %s" % (rep, lab)
+            ctx.set_table(tabs["A"])
+        ctx.set_stream(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["wide64", "wide32", "cfg5", "cfg3ns"])
+def test_retune_soak_two_threads(gpu_device, name):
+    """tests/lab/soak_retune.py for 3 s per shape: one thread keeps 4 batches queued, another retunes as fast as set_table returns."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("soak_retune", os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab", "soak_retune.py"))
+    sr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sr)
+    r = sr.soak(name, *sr.SHAPES[name], 3.0, 4)
+    assert r["ok"], r
+    assert r["retunes"] >= 20 and r["tables_seen"]["A"] + r["tables_seen"]["B"] >= 5, r
