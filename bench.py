@@ -532,6 +532,9 @@ def run_legs_here(names):
             failed = True
         emit(out)
         torch.cuda.empty_cache()
+    if os.environ.get("BAZ_MUSIC_GUARD", "0") not in ("", "0") and os.environ.get("BAZ_MUSIC_LAB_LIB"):
+        # lab library with guard zones around every device buffer (scripts/gpu/r06a.sh): what the legs left behind
+        note("guard zones damaged over these legs: %d" % capi.guard_check(lab=True))
     return 1 if failed else 0
 
 

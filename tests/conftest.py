@@ -51,3 +51,32 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.fail("gpu-marked test started without a GPU: there is no CPU fallback for the HIP path")
     return torch.device("cuda:0")
+
+
+# ---- guard zones (round 6) --------------------------------------------------------------------------------------------------------
+# BAZ_MUSIC_LAB_LIB=lab BAZ_MUSIC_GUARD=1 python -m pytest tests -m gpu: every device buffer of the MUSIC library lies between two
+# 64-KiB zones filled with a pattern (gr_baz_amd/csrc/baz_music_hip.hip, dev_malloc); after EVERY test the zones of all live buffers
+# are compared with the pattern, and a test that made a kernel write outside its buffers fails by name.  Off (and free) otherwise.
+def _guard_active():
+    if os.environ.get("BAZ_MUSIC_GUARD", "0") in ("", "0") or not os.environ.get("BAZ_MUSIC_LAB_LIB"):
+        return False
+    from gr_baz_amd import capi
+    return capi.guard_active(lab=True)
+
+
+@pytest.fixture(autouse=True)
+def _guard_zones_intact(request):
+    yield
+    if request.node.get_closest_marker("gpu") is not None and _guard_active():
+        from gr_baz_amd import capi
+        damaged = capi.guard_check(lab=True)
+        assert damaged == 0, "%d guard zone(s) of the library's device buffers were overwritten (details on stderr)" % damaged
+
+
+def pytest_sessionfinish(session, exitstatus):
+    try:
+        if _guard_active():
+            from gr_baz_amd import capi
+            print("\n[guard zones] lab library under BAZ_MUSIC_GUARD=1: %d damaged zone(s) over the whole session" % capi.guard_check(lab=True))
+    except Exception as e:      # noqa: BLE001  (never turn a finished session into an error)
+        print("\n[guard zones] check failed:", e)
