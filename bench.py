@@ -56,7 +56,9 @@ STRONG_STREAMS = 64        # BASELINE configs[3]: 64 independent 4-antenna strea
 T_START = time.perf_counter()
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_MFMA_PEAK_TF = 78.6   # AMD datasheet; ubench: v_mfma_f64_16x16x4_f64 = 65 cycles/SIMD -> 77 TF (profiles/r01_ubench_fp64_rates.txt)
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r05_scan_pmc_traffic.json")
+# the newest kept PMC traffic profile (scripts/gpu/rNN_final.sh writes it before the evidence bench line is taken)
+TRAFFIC_PROFILE = next((p for p in (os.path.join(ROOT, "profiles", "%s_scan_pmc_traffic.json" % r) for r in ("r06", "r05")) if os.path.exists(p)),
+                       os.path.join(ROOT, "profiles", "r06_scan_pmc_traffic.json"))
 
 
 def kernel_sources_sha():

@@ -31,7 +31,7 @@
 using namespace bazmusic;
 
 // Environment switches.  The RELEASE library reads only the documented tuning knobs: BAZ_MUSIC_EXACT,
-// BAZ_MUSIC_COARSE, BAZ_MUSIC_SPLIT, BAZ_MUSIC_CHUNK_MIB, BAZ_MUSIC_PIN_LIMIT_MIB, BAZ_MUSIC_ZERO_COPY, BAZ_MUSIC_SINGLE_MIB -- none of them
+// BAZ_MUSIC_COARSE, BAZ_MUSIC_CHUNK_MIB, BAZ_MUSIC_PIN_LIMIT_MIB, BAZ_MUSIC_ZERO_COPY, BAZ_MUSIC_SINGLE_MIB -- none of them
 // can make a result wrong.  Everything else (ablations, older kernels, geometry overrides, dumps) exists only in the lab
 // build, -DBAZ_MUSIC_LAB = libbaz_music_hip_lab.so, which tests/lab and the A/B tests load explicitly
 // (tests/test_abi.py::test_release_library_reads_only_the_documented_knobs lists the strings of the release .so).
@@ -229,14 +229,6 @@ struct baz_music_ctx {
     int sub_evd = 1;               // signal subspace by orthogonal iteration where n <= 4 (run-time-m kernels: n <= 8) (lab: BAZ_MUSIC_SUB_EVD=0)
     int fused_covevd = 0;          // m = 4, K % 256 == 0: covariance + EVD in one kernel (BAZ_MUSIC_FUSE=0: lab, two kernels)
     uint32_t covevd_blocks = 512u; // grid of cov4_evd_kernel: the workgroups resident at once (2 per CU)
-    // Default wiring (port 2 not wired, gated scan), large batches (round 6): the batch is cut into parts; covariance + EVD of part p + 1 (HBM-read
-    // bound, on the launch stream) runs BESIDE the gated scan of part p (f16-matrix / LDS bound, on s_scan) -- see process_split_locked
-    hipStream_t s_scan = nullptr;
-    hipEvent_t ev_part[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_join = nullptr;
-    int split_parts = -1;          // -1: by batch size (split_policy); 0 / 1: never; 2 .. 8: that many parts (BAZ_MUSIC_SPLIT: A/B, tests)
-    uint32_t split_cov_blocks = 256u;   // grid of cov4_evd_kernel while a scan runs beside it: ONE workgroup per CU (192 + 256 registers per SIMD lane fit, 2 x 192 + 256 do not)
-    size_t cand_off = 0;           // entries: where the candidate lists of the part being launched start in dCand
     int covevd_task_items = 0;     // lab (BAZ_MUSIC_COVEVD_TASK_ITEMS = 64 / 32 / 16): items per wave task of cov4_evd_kernel, 0 = by batch size
     uint32_t cov4_resident_blocks = 256u;        // grid of cov4_x4_kernel (persistent waves): one workgroup per CU
     // coarse-gated scan (scan_coarse_kernels.hip.h): m <= 8, spectrum port not wired
@@ -780,14 +772,14 @@ int launch_evd_t(baz_music_ctx* c, const double2* dR, uint32_t batch, double* dQ
 
 // m = 4, K % 256 == 0: covariance and EVD in one kernel (cov4_evd_kernel); d_R_dbg optionally receives R (test tap)
 int launch_covevd(baz_music_ctx* c, const float* d_in, uint32_t batch, double* dQ, uint32_t qstride, double* dG,
-                  double2* d_R_dbg = nullptr, uint32_t blocks_cap = 0)
+                  double2* d_R_dbg = nullptr)
 {
     ProfScope ps(c, BAZ_MUSIC_STAGE_COV);
     // items per wave task: 64 where that still makes >= 256 tasks (one per CU), else 32 / 16 -- a small batch needs more waves reading than
     // lanes rotating (a host-fed 1,024-item call read its input over PCIe at 40 GB/s with 16 waves; cov4_evd_kernel)
     const uint32_t ti = c->covevd_task_items ? (uint32_t)c->covevd_task_items : (batch >= 16384u ? 64u : (batch >= 8192u ? 32u : 16u));
     const uint32_t ntasks = (batch + ti - 1) / ti;
-    const uint32_t blocks = std::min<uint32_t>((ntasks + 3) / 4, blocks_cap ? blocks_cap : c->covevd_blocks);
+    const uint32_t blocks = std::min<uint32_t>((ntasks + 3) / 4, c->covevd_blocks);
     hipLaunchKernelGGL(cov4_evd_kernel, dim3(blocks), dim3(256), 0, c->stream, d_in, dQ, dG, d_R_dbg, batch, c->K, c->n,
                        qstride, ti);
     HIP_TRY(c, hipGetLastError());
@@ -1000,14 +992,11 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
                   float* d_lvl, float* d_spec)
 {
     if constexpr (M <= 8 && NMAX <= 4) {
-        // (dQ may point at a PART of the workspace: items [off, off + batch) of a split call -- same row stride, so G and the candidate
-        // lists are offset alike)
-        if (!d_spec && coarse_applies(c) && dQ >= c->dQ && dQ < c->dQ + qstride) {
-            const size_t part_off = (size_t)(dQ - c->dQ);
+        if (!d_spec && coarse_applies(c) && dQ == c->dQ) {
             const CoarseGeom CG = coarse_geometry(c, batch);
-            if (c->cand_off + (size_t)batch * CG.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;
+            if ((size_t)batch * CG.nsplit * NMAX > c->cand_cap) return BAZ_MUSIC_E_INVALID;
             ScanRefine rf;
-            rf.Gs = c->refine_off ? nullptr : c->dG + part_off;
+            rf.Gs = c->refine_off ? nullptr : c->dG;
             rf.TB = c->dTB + c->tb_step_elems;
             rf.below = c->refine_below;
             rf.count = c->refine_nocount ? nullptr : c->dRefined + c->stat_parity;
@@ -1033,7 +1022,7 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
             unsigned long long* fstat = nullptr;
 #endif
 #define BAZ_COARSE_ARGS dim3(CG.groups * CG.nsplit), dim3(256), 0, c->stream, dQ, c->dCS, c->dCS + (size_t)(c->cs_tiles + 1) * cs_c_units(M), \
-                        c->dCand + c->cand_off, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, stats, nullptr, perm, fstat
+                        c->dCand, batch, c->res, qstride, CG.nphases, CG.nsplit, c->keep_mask, c->n, rf, c->cs, stats, nullptr, perm, fstat
 #ifdef BAZ_MUSIC_LAB
             if (c->sort_mode != 0 && M <= 4 && CG.tpp != 4 && !c->coarse_lab) {        // lab (BAZ_MUSIC_SORT): the index list and the fire statistic
                 if constexpr (M <= 4) hipLaunchKernelGGL((scan_coarse_kernel<M, NMAX, 4, 8, false, 0, true>), BAZ_COARSE_ARGS);
@@ -1238,11 +1227,11 @@ int launch_merge_t(baz_music_ctx* c, uint32_t batch, float* d_ang, float* d_lvl,
     // lab (BAZ_MUSIC_SORT): the gated scan just ran with its fire statistic on -- it travels to page-locked memory with this merge
     const bool gated = c->scan_kind == 2 && c->sort_mode != 0 && c->dFire && c->hFireDev;
     const unsigned long long tag = gated ? ((++c->fire_calls) << 1) | (c->last_gated_sorted ? 1ull : 0ull) : 0ull;
-    hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream, c->dCand + c->cand_off,
+    hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream, c->dCand,
                        d_spec, d_ang, d_lvl, batch, c->res, c->n, c->last_nsplit, c->keep_mask, c->dRefined + (c->stat_parity ^ 1),
                        gated ? c->dFire : nullptr, gated ? c->hFireDev : nullptr, tag);
 #else
-    hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream, c->dCand + c->cand_off,
+    hipLaunchKernelGGL((topn_merge_kernel<NMAX>), dim3((batch + 255) / 256), dim3(256), 0, c->stream, c->dCand,
                        d_spec, d_ang, d_lvl, batch, c->res, c->n, c->last_nsplit, c->keep_mask, c->dRefined + (c->stat_parity ^ 1),
                        nullptr, nullptr, 0ull);
 #endif
@@ -2029,77 +2018,9 @@ int check_launch_pointers(baz_music_ctx* c)
     return BAZ_MUSIC_OK;
 }
 
-// Default wiring, large batches: parts of the batch, covariance + EVD of part p + 1 beside the gated scan of part p.
-//   launch stream :  cov(0) | cov(1)        | cov(2)        | ...                      | wait(join)
-//   s_scan        :          wait(0) scan(0) merge(0) | wait(1) scan(1) merge(1) | ... | record(join)
-// The two kernels bound on different things -- cov4_evd_kernel on HBM reads (and, during its EVD phases, on the fp64 vector unit while HBM
-// idles), scan_coarse_kernel on the f16 matrix core and LDS -- and they fit one CU together when the covariance keeps to ONE workgroup
-// per CU (split_cov_blocks).  Every part runs the instructions the unsplit call runs on its items with the same operands: ang / lvl are
-// bit-identical (tests/test_split.py).  How many parts: split_policy().
-int split_policy(const baz_music_ctx* c, uint32_t batch)
-{
-    if (c->split_parts >= 0) return (c->split_parts >= 2 && batch >= 2048u * (uint32_t)c->split_parts) ? std::min(c->split_parts, 8) : 1;
-    if (batch >= 131072u) return 4;
-    if (batch >= 32768u) return 2;
-    return 1;
-}
-
-int process_split_locked(baz_music_ctx* c, const float* d_in, uint32_t batch, float* d_ang, float* d_lvl, int parts)
-{
-    int r = ensure_workspace(c, batch);
-    if (r) return r;
-    const uint32_t part = round_up((batch + (uint32_t)parts - 1) / (uint32_t)parts, 4096);
-    const uint32_t list_len = topn_list_len(c->n);
-    size_t need = 0;
-    for (uint32_t off = 0; off < batch; off += part) {
-        const uint32_t nb = std::min(part, batch - off);
-        need += (size_t)nb * coarse_geometry(c, nb).nsplit * list_len;
-    }
-    r = ensure_candidates(c, std::max(need, std::max(cand_entries(c, batch), cand_entries_upto(c, batch))));
-    if (r) return r;
-    r = check_launch_pointers(c);
-    if (r) return r;
-    if (!c->s_scan) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->s_scan, hipStreamNonBlocking));
-        for (auto& e : c->ev_part) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    }
-    const uint32_t qstride = baz_music_q_stride(batch);
-    hipStream_t launch_stream = c->stream;
-    size_t cand_at = 0;
-    int p = 0, rc = BAZ_MUSIC_OK;
-    for (uint32_t off = 0; off < batch && rc == BAZ_MUSIC_OK; off += part, ++p) {
-        const uint32_t nb = std::min(part, batch - off);
-        rc = launch_covevd(c, d_in + (size_t)off * c->nsamples * 2, nb, c->dQ + off, qstride, c->dG + off, nullptr, c->split_cov_blocks);
-        if (rc) break;
-        if (hipEventRecord(c->ev_part[p], launch_stream) != hipSuccess || hipStreamWaitEvent(c->s_scan, c->ev_part[p], 0) != hipSuccess) {
-            rc = hip_fail(c, hipGetLastError(), "split pipeline: event between covariance and scan");
-            break;
-        }
-        c->stream = c->s_scan;                   // (we hold c->mtx: the launch helpers enqueue on c->stream)
-        c->cand_off = cand_at;
-        rc = launch_scan(c, c->dQ + off, qstride, nb, d_ang + (size_t)off * c->n, d_lvl ? d_lvl + (size_t)off * c->n : nullptr, nullptr);
-        if (rc == BAZ_MUSIC_OK) rc = launch_merge(c, nb, d_ang + (size_t)off * c->n, d_lvl ? d_lvl + (size_t)off * c->n : nullptr, nullptr);
-        cand_at += (size_t)nb * c->last_nsplit * list_len;
-        c->cand_off = 0;
-        c->stream = launch_stream;
-    }
-    // the caller's stream continues behind the last merge (also after a failed launch: whatever was enqueued is ordered)
-    hipError_t e = hipEventRecord(c->ev_join, c->s_scan);
-    if (e == hipSuccess) e = hipStreamWaitEvent(launch_stream, c->ev_join, 0);
-    if (e != hipSuccess && rc == BAZ_MUSIC_OK) rc = hip_fail(c, e, "split pipeline: join");
-    if (rc == BAZ_MUSIC_OK) c->stat_next_clean = true;
-    return rc;
-}
-
 int process_device_locked(baz_music_ctx* c, const void* d_in, uint32_t batch, void* d_ang, void* d_lvl,
                           void* d_spec)
 {
-    if (!c->wide && !d_spec && !c->peak_mode && c->fused_covevd && coarse_applies(c)) {
-        const int parts = split_policy(c, batch);
-        if (parts >= 2)
-            return process_split_locked(c, static_cast<const float*>(d_in), batch, static_cast<float*>(d_ang), static_cast<float*>(d_lvl), parts);
-    }
     if (c->wide) {
         const int rw = process_wide_locked(c, d_in, batch, d_ang, d_lvl, d_spec);
         if (rw == BAZ_MUSIC_OK) c->stat_next_clean = true;    // (no scan statistic on this path: the counters stay 0)
@@ -2293,9 +2214,6 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
                 c->covevd_blocks = (uint32_t)per_cu * (uint32_t)std::max(1, prop.multiProcessorCount);
             else (void)hipGetLastError();
         }
-        if (const char* v = getenv("BAZ_MUSIC_SPLIT")) c->split_parts = std::max(0, std::min(8, atoi(v)));   // A/B, tests: 0 / 1 never, 2 .. 8 parts
-        c->split_cov_blocks = (uint32_t)std::max(1, prop.multiProcessorCount);
-        if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SPLIT_COV_BLOCKS_PER_CU")) if (atoi(v) > 0) c->split_cov_blocks = (uint32_t)atoi(v) * (uint32_t)std::max(1, prop.multiProcessorCount);
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SIG_SCAN")) c->sig_scan = atoi(v);                  // lab / tests
         if (const char* v = getenv("BAZ_MUSIC_COARSE")) c->coarse = atoi(v);                      // A/B, tests
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_COARSE_RG")) c->coarse_rg = atoi(v);                // lab
@@ -2411,10 +2329,6 @@ void baz_music_destroy(baz_music_ctx* c)
         if (c->dSw) (void)dev_free(c->dSw);
         host_unregister_all_locked(c);
         free_slots(c);
-        if (c->s_scan) (void)hipStreamSynchronize(c->s_scan);
-        for (auto e : c->ev_part) if (e) (void)hipEventDestroy(e);
-        if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-        if (c->s_scan) (void)hipStreamDestroy(c->s_scan);
         if (c->ev_in) (void)hipEventDestroy(c->ev_in);
         if (c->ev_out) (void)hipEventDestroy(c->ev_out);
         if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
@@ -2538,7 +2452,7 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
     // in two ran at 0.41-0.53 ms, as one chunk on one stream at 0.20-0.22 ms; pageable 2,048-item calls (46 MB) in four
     // chunks were SLOWER per item than 512-item calls in one (the runtime stages pageable copies and blocks in them, so
     // little overlaps).  Hence:
-    //   page-locked caller memory   below 64 MiB of traffic (BAZ_MUSIC_SINGLE_MIB) ONE chunk on ONE stream -- without copies
+    //   page-locked caller memory   below 64 MiB of traffic (BAZ_MUSIC_SINGLE_MIB; without the spectrum port: always) ONE chunk on ONE stream -- without copies
     //                               when zero-copy applies: a 1,024-item config-2 call (23 MB) ran at 2.06e6 items/s that way and
     //                               at 1.53e6 cut into three pipelined chunks (round 3, scripts/gpu/r03l.sh); above, >= 4 chunks of
     //                               >= 8 MiB and <= 32 MiB each;
@@ -2553,7 +2467,10 @@ int baz_music_process(baz_music_ctx* c, const float* in_ri, uint32_t batch, floa
         chunk = (uint32_t)std::min<size_t>(batch, std::max<size_t>(64, c->chunk_bytes / per_item));
     } else if (!locked) {
         chunk = (uint32_t)std::min<size_t>(batch, std::max<size_t>(64, (64u << 20) / per_item));
-    } else if ((size_t)batch * per_item < (size_t)c->single_limit_mib << 20) {
+    } else if (!spectrum || (size_t)batch * per_item < (size_t)c->single_limit_mib << 20) {
+        // (without the spectrum port a call moves its input only: the covariance kernel reads it over the link at the link's rate, and cutting the
+        // call can only add to that -- 8,192 / 16,384-item calls ran at 6.5 / 6.6e6 items/s as one zero-copy sequence, at 5.5e6 cut into chunks:
+        // profiles/r06_hostfed_chunk_sweep.txt)
         chunk = batch;
     } else {
         const size_t floor_items = std::max<size_t>(64, (8u << 20) / per_item);

@@ -153,12 +153,6 @@ BAZ_MUSIC_API int baz_music_debug_q(baz_music_ctx* ctx, const void* d_in, uint32
  *                          scan_coarse_kernels.hip.h).  This tap runs covariance + EVD of the batch and then BOTH forms on every
  *                          (item, bin); *worst = the largest observed error / allowance (sound below 1; derived with a factor
  *                          > 2 to spare).  BAZ_MUSIC_E_UNSUPPORTED for m > 8 or a table whose scale does not fit. */
-/*   split       : default wiring (port 2 not wired), 4 antennas, batches of 32,768 items and more: the call is cut into 2 (from 131,072 items:
- *                          4) parts and the covariance + EVD of part p + 1 runs on the launch stream BESIDE the gated scan of part p on a
- *                          second stream of the context (the first is bound by HBM reads, the second by the f16 matrix core); the launch
- *                          stream continues behind the last part's merge, so stream semantics are unchanged and ang / lvl are bit-identical
- *                          to the single launch sequence (tests/test_split.py).  BAZ_MUSIC_SPLIT at create: 0 = never, 2 .. 8 = that many
- *                          parts for batches of 2,048 items per part and more. */
 BAZ_MUSIC_API int baz_music_debug_coarse_margin(baz_music_ctx* ctx, const void* d_in, uint32_t batch, float* worst);
 /*   lab statistic: exact (16-item row group x 16-bin tile) evaluations of the coarse-gated scan's launches since the last
  *                          read (the counter resets); -1 unless the context was created under BAZ_MUSIC_COARSE_STATS=1. */

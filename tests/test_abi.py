@@ -175,7 +175,6 @@ def test_plain_c_consumer_finds_the_emitter(tmp_path, gpu_device):
 RELEASE_KNOBS = {
     "BAZ_MUSIC_EXACT",           # 1: every value on the fp64 matrix core (no int8 form) -- A/B
     "BAZ_MUSIC_COARSE",          # 0: the full fp64 scan also without the spectrum port -- A/B, bit-identical outputs
-    "BAZ_MUSIC_SPLIT",           # 0: never cut a default-wiring batch into parts (covariance beside scan) -- A/B, bit-identical outputs
     "BAZ_MUSIC_CHUNK_MIB", "BAZ_MUSIC_PIN_LIMIT_MIB", "BAZ_MUSIC_ZERO_COPY", "BAZ_MUSIC_SINGLE_MIB",     # host-fed path
 }
 

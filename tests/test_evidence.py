@@ -7,6 +7,11 @@ import pytest
 from conftest import ROOT
 
 
+# the newest round whose evidence is kept under profiles/ (scripts/gpu/rNN_final.sh)
+EV = next(r for r in ("r06", "r05") if os.path.exists(os.path.join(ROOT, "profiles", "%s_bench_line.json" % r))
+          and os.path.exists(os.path.join(ROOT, "profiles", "%s_scan_pmc_traffic.json" % r)))
+
+
 def _bench():
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
@@ -18,20 +23,20 @@ def _bench():
 def test_profiles_carry_the_sha_of_the_sources_they_were_taken_on():
     bench = _bench()
     here = bench.kernel_sources_sha()
-    traffic = json.load(open(os.path.join(ROOT, "profiles", "r05_scan_pmc_traffic.json")))
-    line = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")))
+    traffic = json.load(open(os.path.join(ROOT, "profiles", EV + "_scan_pmc_traffic.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", EV + "_bench_line.json")))
     assert len(traffic["kernel_sources_sha"]) == 16 and traffic["git_head"]
     assert line["kernel_sources_sha"] == traffic["kernel_sources_sha"], "bench line and PMC traffic come from different sources"
     assert line["roofline"]["traffic"] == traffic["scan_hbm_bytes_per_launch"] and line["roofline"]["traffic_stale"] is False
     assert traffic["items_per_launch"] == line["config"]["items_per_gpu_per_step"]
     if traffic["kernel_sources_sha"] != here:
         # legitimate while kernels are being changed; at the end of a round scripts/gpu/profile_final.sh re-takes the evidence
-        pytest.xfail("profiles/r05_* were taken on kernel sources %s, the tree holds %s: bench.py will report traffic_stale"
+        pytest.xfail("profiles/" + EV + "_* were taken on kernel sources %s, the tree holds %s: bench.py will report traffic_stale"
                      % (traffic["kernel_sources_sha"], here))
 
 
 def test_roofline_fields_of_the_kept_bench_line_are_consistent():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", EV + "_bench_line.json")))
     r = line["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
@@ -66,13 +71,13 @@ def test_pmc_traffic_follows_from_the_kept_raw_counter_rows():
         assert len(v) >= 3
         return sum(v) / len(v), len(v)
 
-    t = json.load(open(os.path.join(ROOT, "profiles", "r05_scan_pmc_traffic.json")))
-    w, nw = mean("r05_pmc_raw_write.csv", "WRITE_SIZE")
-    f, nf = mean("r05_pmc_raw_fetch.csv", "FETCH_SIZE")
+    t = json.load(open(os.path.join(ROOT, "profiles", EV + "_scan_pmc_traffic.json")))
+    w, nw = mean(EV + "_pmc_raw_write.csv", "WRITE_SIZE")
+    f, nf = mean(EV + "_pmc_raw_fetch.csv", "FETCH_SIZE")
     assert (nw, nf) == (t["dispatches_averaged"]["write_pass"], t["dispatches_averaged"]["fetch_pass"])
     assert w == pytest.approx(t["WRITE_SIZE_KiB"], rel=1e-12) and f == pytest.approx(t["FETCH_SIZE_KiB_raw"], rel=1e-12)
     assert abs(int(round(w * 1024.0 + 2.0 * f * 1024.0)) - t["scan_hbm_bytes_per_launch"]) <= 1   # (a mean of 7 dispatches: .5 may round either way)
     assert t["writes_over_algorithmic"] == pytest.approx(w * 1024.0 / t["algorithmic_bytes_per_launch"], rel=1e-12)
     # the launch the counters saw is the bench's launch: 262,144 items = 65,536 workgroups-worth of 16-item tiles x ranges
-    rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_pmc_raw_write.csv"))) if "scan_mfma_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", EV + "_pmc_raw_write.csv"))) if "scan_mfma_kernel" in r["Kernel_Name"]]
     assert len({(r["Grid_Size"], r["Workgroup_Size"]) for r in rows}) == 1
