@@ -816,193 +816,7 @@ def main():
     # a retune (set_array_response) while batches are in flight
     note("headline timed (%d rounds of %d steps); checking the last step's outputs against the oracle" % (len(rounds), args.steps))
     verified = verify_against_oracle(torch, np, x, ang, lvl, spec, table, M, N_EMIT, NSAMPLES, RES, 256)
-    ctx.set_stream(None)
-    ctx.close()
-    # What this box's memory system takes for a plain write of the same 3.78 GB (a torch fill of the spectrum buffer; hipEvents on the bench
-    # stream, outside the timed region, AFTER the outputs have been checked: it overwrites them): the dominant kernel is bound by its spectrum stores, and boxes of this pool differ by 20 % in exactly
-    # that -- the roofline fraction against the 8 TB/s peak does not say how far the kernel is from what can be had.
-    write_ceiling_gbs = None
-    try:
-        sp_one = spec[:group_items]
-        with torch.cuda.stream(stream):
-            for _ in range(3):
-                sp_one.fill_(1.0)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for _ in range(10):
-                sp_one.fill_(1.0)
-            e1.record(stream)
-        stream.synchronize()
-        write_ceiling_gbs = sp_one.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    except Exception:
-        pass
-
-    t_med = statistics.median(rounds)
-    total_items = sharding.sum_over_ranks(float(batch * args.steps), active, False)
-    ranks = [{"rank": rank, "items_per_step": batch, "streams": mine, "device": "none (dry run)"}]
-    if active:
-        import torch.distributed as dist
-        gathered = [None] * world
-        dist.all_gather_object(gathered, ranks[0])
-        ranks = gathered
-    assert len(ranks) == world and sorted(r["rank"] for r in ranks) == list(range(world)), ranks
-    if rank == 0:
-        info = sharding.backend_info() if active else {"backend": None, "requested": None, "fell_back": False, "fallback_reason": None}
-        print(json.dumps({
-            "metric": "MUSIC-DoA snapshots/s (4 ant, 1024 samp, 3600 bins)", "dry_run": True,
-            "value": total_items / t_med, "unit": "snapshots/s (SIMULATED steps: launcher rehearsal, not a measurement)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_med / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "none",
-            "config": {"workload": "dry run of cfg2's dealing: %d streams x %d items per rank per step, no device work"
-                                   % (len(mine), ITEMS_PER_STREAM),
-                       "items_per_gpu_per_step": batch, "items_per_step_all_gpus": int(total_items / args.steps + 0.5),
-                       "streams_total": n_streams, "launch_sequences_per_step": n_groups, "items_per_launch_sequence": group_items,
-                       "parallelism": "independent streams, s mod %d, no collective" % world,
-                       "collective_backend_for_barrier_and_clock": info["backend"],
-                       "collective_backend_requested": info["requested"],
-                       "collective_backend_fell_back": info["fell_back"],
-                       "collective_backend_fallback_reason": info["fallback_reason"],
-                       "ranks": ranks}}), flush=True)
-    if active:
-        import torch.distributed as dist
-        dist.destroy_process_group()
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("BAZ_BENCH_SCALING", "weak"),
-                    help="weak: 8 streams per GPU; strong: BASELINE configs[3], the same 64 streams dealt s mod N at every N")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary cfg2-no-spectrum / cfg3 / cfg5 measurements")
-    ap.add_argument("--ramp-seconds", type=float, default=0.25, help="untimed steady load before warm-up (clock ramp)")
-    ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat the K-step timed region until this much timed work")
-    ap.add_argument("--dry-ranks", action="store_true",
-                    help="launcher rehearsal without GPU work: N ranks, the dealing, barrier / clock and rank records only")
-    ap.add_argument("--extra-leg", default=None, metavar="NAME[,NAME...]",
-                    help="child mode: run the named secondary legs in this process (ALL = every leg, in order) and print one JSON object each")
-    ap.add_argument("--legs", default=None, metavar="NAME[,NAME...]", help="run only these secondary legs (default: all)")
-    args = ap.parse_args()
-
-    if args.extra_leg:
-        names = LEG_ORDER if args.extra_leg == "ALL" else [n for n in args.extra_leg.split(",") if n]
-        raise SystemExit(run_legs_here(names))
-
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
-        return self_launch(args.gpus)                        # plain `python bench.py --gpus N`: start the N ranks ourselves
-    if args.dry_ranks:
-        return dry_ranks_main(args)
-
-    import numpy as np
-    import torch
-    from gr_baz_amd import capi, sharding, synth
-
-    rank, local_rank, world = sharding.dist_env()
-    if world != max(1, args.gpus):                           # never print a line whose n_gpus is not what was asked for
-        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
-    if args.scaling == "strong" and STRONG_STREAMS % world:
-        raise SystemExit("--scaling strong deals %d streams: --gpus must divide it" % STRONG_STREAMS)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the MUSIC-DoA path has no CPU fallback")
-    ndev = torch.cuda.device_count()
-    if world > ndev:
-        if os.environ.get("BAZ_BENCH_SHARE_DEVICES") != "1":
-            raise SystemExit("%d ranks but only %d GPU(s) visible (one process per GPU)" % (world, ndev))
-        # test hook: several ranks on one GPU (exercises the N > 1 code path on a 1-GPU box); EVERY rank switches the
-        # barrier / clock backend, RCCL cannot put two ranks on one device
-        local_rank %= ndev
-        os.environ["BAZ_BENCH_BACKEND"] = "gloo"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    active = sharding.init_process_group(use_gpu=True, local_rank=local_rank)
-    binfo = sharding.backend_info() if active else {"backend": None, "requested": None, "fell_back": False, "fallback_reason": None}
-    backend = binfo["backend"]
-
-    arr, table = helper_table(np, synth, M, RES)
-
-    # this rank's streams: global stream s lives on rank s mod world (config 4), seed = 1002 + s
-    strong = args.scaling == "strong"
-    n_streams = STRONG_STREAMS if strong else STREAMS_PER_GPU * world
-    mine = sharding.streams_of_rank(n_streams, world, rank)
-    batch = len(mine) * ITEMS_PER_STREAM
-    # a launch sequence covers a group of up to 8 streams (262,144 items: the weak mode's whole step); the strong mode's
-    # step walks the rank's groups one after the other on the same stream
-    group_items = min(len(mine), STREAMS_PER_GPU) * ITEMS_PER_STREAM
-    assert batch % group_items == 0
-    n_groups = batch // group_items
-    x = torch.empty(batch, 2 * NSAMPLES, dtype=torch.float32, device=dev)
-    for i, s_id in enumerate(mine):
-        x[i * ITEMS_PER_STREAM:(i + 1) * ITEMS_PER_STREAM] = synth.synth_stream(
-            torch, dev, ITEMS_PER_STREAM, M, NSAMPLES, arr, FREQUENCY, SPACING, seed=1002 + s_id).reshape(ITEMS_PER_STREAM, -1)
-    ang = torch.zeros(batch, N_EMIT, dtype=torch.float32, device=dev)
-    lvl = torch.zeros_like(ang)
-    spec = torch.zeros(batch, RES, dtype=torch.float32, device=dev)
-
-    # One explicit stream for everything the engine does (ordered against the fills above by the synchronize below)
-    stream = torch.cuda.Stream(device=dev)
-    ctx = capi.Context(M, N_EMIT, NSAMPLES, RES, table, device_id=local_rank)
-    ctx.set_stream(stream.cuda_stream)
-    ctx.reserve(group_items)
-    torch.cuda.synchronize()
-    xb, ab, lb, sb = x.data_ptr(), ang.data_ptr(), lvl.data_ptr(), spec.data_ptr()
-    x_row, al_row, sp_row = 8 * NSAMPLES, 4 * N_EMIT, 4 * RES            # bytes per item
-
-    def step():
-        for gi in range(n_groups):
-            o = gi * group_items
-            ctx.process_device(xb + o * x_row, group_items, ab + o * al_row, lb + o * al_row, sb + o * sp_row)
-
-    # Clock ramp (untimed, before the W warm-up steps): the GPU's power management needs tens of milliseconds of
-    # continuous load to leave its idle clocks -- a 3-step (1 ms) warm-up measures the ramp, not the steady state a
-    # streaming block runs in (0.42 vs 0.36 ms/step on the same box, profiles/r01g_clock_ramp.txt).
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < args.ramp_seconds:
-        for _ in range(10):
-            step()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-
-    # Timed rounds: each is EXACTLY args.steps steps between barrier + synchronize on both sides, max over ranks.
-    ctx.profile(int(os.environ.get("BAZ_BENCH_PROFILE", "2")))   # 2: hipEvents around the dominant kernel only
-    rounds, scan_ms_total, scan_launches, timed_total = [], 0.0, 0, 0.0
-    while True:
-        sharding.barrier(active, True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        sharding.barrier(active, True)
-        tmax = sharding.max_over_ranks(elapsed, active, True)
-        rounds.append(tmax)
-        timed_total += tmax
-        sm, sn = ctx.stage_ms(capi.STAGE_SCAN)            # cumulative since profile(): dominant kernel, timed rounds only
-        scan_ms_total, scan_launches = sm, sn
-        if timed_total >= args.min_seconds or len(rounds) >= 200:
-            break
-    ctx.profile(False)
-    # informational per-stage breakdown from a separate short pass (events around every kernel add launch gaps,
-    # so they stay out of the timed region)
-    ctx.profile(1)
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    stage = [ctx.stage_ms(s) for s in range(capi.NUM_STAGES)]
-    ctx.profile(False)
-    cov_name = ctx.stage_name(capi.STAGE_COV)
-    scan_name = ctx.stage_name(capi.STAGE_SCAN)
-    bpi = ctx.bytes_per_item(True)
-    # outside the timed region: what the last timed step left in the output buffers against the CPU oracle, then the cost of
-    # a retune (set_array_response) while batches are in flight
-    print("bench.py: [%.1f s] headline timed; verifying" % (time.perf_counter() - T_START), file=sys.stderr, flush=True)
-    verified = verify_against_oracle(torch, np, x, ang, lvl, spec, table, M, N_EMIT, NSAMPLES, RES, 256)
-    print("bench.py: [%.1f s] headline retunes" % (time.perf_counter() - T_START), file=sys.stderr, flush=True)
-    retune_med, retune_max, retune_lock = time_retunes(np, synth, ctx, table, M, RES, arr, step, torch.cuda.synchronize, 5)
+    # (the cost of a retune beside the headline's steps is measured by the leg cfg2_retune_in_flight, in its own process)
     ctx.set_stream(None)
     ctx.close()
     # What this box's memory system takes for a plain write of the same 3.78 GB (a torch fill of the spectrum buffer; hipEvents on the bench

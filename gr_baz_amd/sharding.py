@@ -34,7 +34,9 @@ def init_process_group(use_gpu: bool, local_rank: int = 0, try_nccl: bool = Fals
     into its JSON line (collective_backend_*): a fall-back must never pass for an RCCL run."""
     import torch.distributed as dist
     rank, _, world = dist_env()
-    if world <= 1:
+    # BAZ_BENCH_FORCE_DIST=1: a group of ONE rank (tests/test_bench_multi.py on the 1-GPU box: RCCL really initialises under this
+    # code, the barrier and the clock really run through it -- everything an N-rank run does except a second rank)
+    if world <= 1 and os.environ.get("BAZ_BENCH_FORCE_DIST") != "1":
         return False
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -115,3 +115,20 @@ def test_64_block_instances_on_their_own_threads(gpu_device):
     assert max(per_dev.values()) - min(per_dev.values()) <= 1                      # dealt evenly
     assert d["items_per_s_all_blocks"] > 1e5
 
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_rccl_really_initialises_under_the_bench(gpu_device):
+    """No 8-GPU node has been available to this work, so the N > 1 runs above fall back to gloo (two ranks cannot share a device under
+    RCCL).  What CAN run on the 1-GPU box is the RCCL side of it with a group of one rank (BAZ_BENCH_FORCE_DIST=1): the communicator is
+    created on the device, the barrier (device_ids) and the max / sum all-reduces of the clock run on GPU tensors through RCCL, the rank
+    records are gathered -- and the line says nccl, not a fall-back."""
+    r, d = _bench("--gpus", "1", "--steps", "3", "--warmup", "2", "--no-extras", "--no-cpu-baseline", "--min-seconds", "0.2",
+                  env={"BAZ_BENCH_FORCE_DIST": "1"})
+    assert r.returncode == 0 and d is not None, r.stderr[-2000:]
+    c = d["config"]
+    assert c["collective_backend_requested"] == "nccl" and c["collective_backend_for_barrier_and_clock"] == "nccl", c
+    assert c["collective_backend_fell_back"] is False and not c["collective_backend_fallback_reason"]
+    assert d["n_gpus"] == 1 and len(c["ranks"]) == 1 and c["verified_ok"] is True
+    assert d["value"] > 1e8
