@@ -1204,6 +1204,8 @@ int launch_scan_t(baz_music_ctx* c, const double* dQ, uint32_t qstride, uint32_t
                 case 11: BAZ_SCAN_LAUNCH(true, true, 2048, (1 | 2 | 16)); break;          // register staging (the product's) at 3 waves per SIMD
                 case 12: BAZ_SCAN_LAUNCH(true, true, 4096, (1 | 2 | 16)); break;          // blocks in the compact order (negative: profiles/r05_write_order.txt)
                 case 13: BAZ_SCAN_LAUNCH(true, true, (8 | 2 | 4 | 4096), (1 | 2 | 16)); break;   // stores + staging + barriers only, compact order
+                case 14: BAZ_SCAN_LAUNCH(true, true, 8192, (1 | 2 | 16)); break;          // (round 6) s_setprio 3 around the MFMAs of a step
+                case 15: BAZ_SCAN_LAUNCH(true, true, 16384, (1 | 2 | 16)); break;         // ... s_setprio 3 around epilogue, staging and stores instead
                 default: BAZ_SCAN_LAUNCH(true, true, 0, (1 | 2 | 16)); break;
             }
             HIP_TRY(c, hipGetLastError());

@@ -1748,7 +1748,9 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? ((ABL & 2048) ? 3 : 4)
                         }
                     }
                 }
-            } else
+            } else {
+            if constexpr (ABL & 8192) __builtin_amdgcn_s_setprio(3);        // lab (round 6): the matrix phase of a wave ahead of its mates' vector work
+            if constexpr (ABL & 16384) __builtin_amdgcn_s_setprio(0);       // lab: ... or behind it
 #pragma unroll
             for (int sl = 0; sl < SCH; ++sl) {
                 const int s = p * SCH + sl;
@@ -1765,6 +1767,9 @@ __global__ __launch_bounds__(256, (M <= 4 && NMAX <= 2) ? ((ABL & 2048) ? 3 : 4)
                         acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[s], f23.y, acc[3], 0, 0, 0);
                     }
                 }
+            }
+            if constexpr (ABL & 8192) __builtin_amdgcn_s_setprio(0);
+            if constexpr (ABL & 16384) __builtin_amdgcn_s_setprio(3);
             }
 
             // 3. after the last phase of the step: epilogue arithmetic (no memory traffic yet).
