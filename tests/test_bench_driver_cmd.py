@@ -43,6 +43,7 @@ def _check_complete(line, steps=20, warmup=5):
     assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and cb["unit"] == "snapshots/s" and cb["sample"]
     c = line["config"]
     assert c["verified_ok"] is True and c["verified_items"] >= 256 and c["verified_max_rel_err"] <= 1e-5 and c["verified_bins_identical"]
+    assert c["headline_attempt"] in (1, 2)
 
 
 @pytest.mark.gpu
@@ -52,6 +53,7 @@ def test_the_drivers_exact_command(gpu_device):
     assert r.returncode == 0, "rc %d\n%s" % (r.returncode, r.stderr[-3000:])
     assert len(lines) == 2, "expected the complete line before the legs and the enriched one after them, got %d lines" % len(lines)
     first, last = lines
+    assert first["config"]["headline_attempt"] == 1 and first["config"]["headline_previous_failure"] is None
     assert r.stdout.rstrip().splitlines()[-1].startswith("{")                    # the LAST line of stdout is the line
     _check_complete(first)
     _check_complete(last)
@@ -98,6 +100,24 @@ def test_a_fault_in_a_leg_cannot_take_the_line(gpu_device, kind):
     for ok_leg in ("cfg2_without_spectrum_port", "cfg2_snr60"):                    # the leg before and the leg AFTER the fault
         assert "error" not in c["extra"][ok_leg] and c["extra"][ok_leg]["snapshots_per_s"] > 1e7 and c["extra"][ok_leg]["verified_ok"]
     assert c["default_wiring_snapshots_per_s"] > 1e7 and c["snr60_snapshots_per_s"] > 1e7 and c["wide_m64_snapshots_per_s"] is None
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_a_fault_in_the_measuring_process_itself_costs_one_restart(gpu_device):
+    """`python bench.py` measures in a child of itself.  The child of the first attempt abort()s before its line (what a GPU memory fault does to a
+    process): it is started once more, rc 0, the line is complete and says that it is the second attempt's."""
+    r, lines = _run(DRIVER_ARGV + ["--legs", "cfg2_snr60"], env={"BAZ_BENCH_INJECT_FAULT": "abort:headline@1"})
+    assert r.returncode == 0, "rc %d\n%s" % (r.returncode, r.stderr[-3000:])
+    assert len(lines) == 2
+    _check_complete(lines[0])
+    _check_complete(lines[1])
+    for ln in lines:
+        assert ln["config"]["headline_attempt"] == 2 and "signal 6" in ln["config"]["headline_previous_failure"]
+    assert "starting it once more" in r.stderr
+    # ... and an undisturbed run says attempt 1 (asserted on the driver's command above through _check_complete's caller); a fault in BOTH attempts is an error
+    r, lines = _run(DRIVER_ARGV + ["--no-extras", "--no-cpu-baseline"], env={"BAZ_BENCH_INJECT_FAULT": "abort:headline@1", "BAZ_BENCH_SUPERVISE": "0"})
+    assert r.returncode != 0 and not lines
 
 
 def test_leg_table_and_driver_flags_on_cpu():
