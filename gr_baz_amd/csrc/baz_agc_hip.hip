@@ -52,6 +52,8 @@ struct DeviceGuard {
 int ensure_chunks(baz_agc_ctx* c, size_t nchunks)
 {
     if (nchunks <= c->chunk_cap) return BAZ_AGC_OK;
+    // launches of earlier calls may still use the tables freed below: drain them first (round 6: nothing relies on hipFree synchronising)
+    if (c->chunk_cap) AGC_TRY(hipStreamSynchronize(c->stream));
     if (c->d_pair) (void)hipFree(c->d_pair);
     if (c->d_carry) (void)hipFree(c->d_carry);
     c->d_pair = nullptr; c->d_carry = nullptr; c->chunk_cap = 0;

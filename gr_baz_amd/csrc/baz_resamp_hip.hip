@@ -183,6 +183,8 @@ int64_t process2_device_locked(baz_resamp_ctx* c, const void* d_in, uint64_t in_
     if (ninput > 0xFFFFFFFFull) return BAZ_RESAMP_E_UNSUPPORTED;    // the phase table holds 32-bit input indices
     if ((c->mu >> 64) != 0) return BAZ_RESAMP_E_INVALID;            // d_mu is a fraction between calls
     if (noutput > c->walk_cap) {
+        // launches of earlier calls may still use the tables freed below: drain them first (round 6: nothing relies on hipFree synchronising)
+        if (c->walk_cap) RS_TRY(hipStreamSynchronize(c->stream));
         if (c->d_ii) (void)hipFree(c->d_ii);
         if (c->d_imu) (void)hipFree(c->d_imu);
         c->d_ii = c->d_imu = nullptr; c->walk_cap = 0;
@@ -219,6 +221,7 @@ int64_t process2_device_locked(baz_resamp_ctx* c, const void* d_in, uint64_t in_
 
 int ensure_staging(baz_resamp_ctx* c, size_t nin, size_t nout)
 {
+    if ((nin > c->s_in_cap && c->s_in_cap) || (nout > c->s_out_cap && c->s_out_cap)) RS_TRY(hipStreamSynchronize(c->stream));   // (as above)
     if (nin > c->s_in_cap) {
         if (c->s_in) (void)hipFree(c->s_in);
         c->s_in = nullptr; c->s_in_cap = 0;
