@@ -142,7 +142,9 @@ int baz_agc_create(baz_agc_ctx** out, uint32_t nstreams, float rate, float refer
     DeviceGuard guard(dev);
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&c->d_env, nstreams * sizeof(double)) != hipSuccess ||
-        hipMemset(c->d_env, 0, nstreams * sizeof(double)) != hipSuccess) {
+        // (hipMemset of device memory may return before the fill has run, and the null stream does not order it against this context's
+        // non-blocking stream: the fill goes on the stream that will use the buffer -- round 6, found with the MUSIC library's guard allocator)
+        hipMemsetAsync(c->d_env, 0, nstreams * sizeof(double), c->own_stream) != hipSuccess) {
         baz_agc_destroy(c);
         return BAZ_AGC_E_HIP;
     }
@@ -253,7 +255,7 @@ int baz_agc_reset(baz_agc_ctx* c)
     std::lock_guard<std::mutex> lk(c->mtx);
     DeviceGuard guard(c->device);
     AGC_TRY(hipStreamSynchronize(c->stream));
-    AGC_TRY(hipMemset(c->d_env, 0, c->nstreams * sizeof(double)));
+    AGC_TRY(hipMemsetAsync(c->d_env, 0, c->nstreams * sizeof(double), c->stream));     // stream-ordered before the next call's launches
     c->count = 0;
     return BAZ_AGC_OK;
 }

@@ -54,11 +54,12 @@ struct GuardRec { void* base; size_t bytes; };
 std::mutex g_guard_mtx;
 std::vector<std::pair<void*, GuardRec>> g_guards;     // user pointer -> allocation (a handful of buffers per context)
 unsigned long long g_guard_damaged = 0;               // zones found overwritten so far (at a free or at a check)
-bool guard_on()
+int guard_level()
 {
-    static const bool on = [] { const char* v = getenv("BAZ_MUSIC_GUARD"); return v && atoi(v) != 0; }();
-    return on;
+    static const int level = [] { const char* v = getenv("BAZ_MUSIC_GUARD"); return v ? atoi(v) : 0; }();
+    return level;
 }
+bool guard_on() { return guard_level() != 0; }
 // compares both zones of one allocation with the pattern (synchronises the device); returns the damaged zones (0 .. 2)
 int guard_check_one(void* user, const GuardRec& g)
 {
@@ -90,6 +91,10 @@ hipError_t dev_malloc(void** p, size_t bytes)
         hipError_t e = hipMalloc(&base, body + 2 * GUARD_BYTES);
         if (e != hipSuccess) return e;
         e = hipMemset(base, GUARD_PATTERN, body + 2 * GUARD_BYTES);     // (the body too: a read of an uninitialised buffer shows up as 0xA5A5...)
+        // The fill runs on the null stream and the library's streams are non-blocking ones: a buffer allocated INSIDE a launch sequence (the peak
+        // picker's private spectrum) was still being filled while the scan wrote it -- seen as a fuzz failure under the guard only.  Wait for it.
+        // (BAZ_MUSIC_GUARD=2: without the wait, to show that.)
+        if (e == hipSuccess && guard_level() != 2) e = hipDeviceSynchronize();
         if (e != hipSuccess) { (void)hipFree(base); return e; }
         *p = static_cast<unsigned char*>(base) + GUARD_BYTES;
         std::lock_guard<std::mutex> lk(g_guard_mtx);
@@ -908,7 +913,7 @@ int ensure_sort_workspace(baz_music_ctx* c, uint32_t batch)
     if (c->sort_mode == 0) return BAZ_MUSIC_OK;                   // (nothing of the sorting exists unless it was asked for)
     if (!c->dFire) {
         HIP_TRY(c, dev_malloc((void**)&c->dFire, 2 * sizeof(unsigned long long)));
-        HIP_TRY(c, hipMemset(c->dFire, 0, 2 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemsetAsync(c->dFire, 0, 2 * sizeof(unsigned long long), c->stream));
         HIP_TRY(c, hipHostMalloc((void**)&c->hFire, 4 * sizeof(unsigned long long), hipHostMallocDefault));
         std::memset(c->hFire, 0, 4 * sizeof(unsigned long long));
         HIP_TRY(c, hipHostGetDevicePointer((void**)&c->hFireDev, c->hFire, 0));
@@ -917,7 +922,7 @@ int ensure_sort_workspace(baz_music_ctx* c, uint32_t batch)
     if (!c->dHist) {
         HIP_TRY(c, dev_malloc((void**)&c->dHist, bazsort::KEY_BUCKETS * sizeof(uint32_t)));
         HIP_TRY(c, dev_malloc((void**)&c->dCursor, bazsort::KEY_BUCKETS * sizeof(uint32_t)));
-        HIP_TRY(c, hipMemset(c->dHist, 0, bazsort::KEY_BUCKETS * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemsetAsync(c->dHist, 0, bazsort::KEY_BUCKETS * sizeof(uint32_t), c->stream));
     }
     if (batch > c->sort_cap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -2144,6 +2149,8 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
     do {
         if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         c->stream = c->own_stream;
+        // (every fill of a device buffer below is a hipMemsetAsync ON THIS STREAM: hipMemset of device memory may return before the fill has run, and
+        // the null stream orders nothing against a non-blocking stream -- round 6, found when the guard allocator's own prefill raced with a scan)
         c->wide = wide;
         if (wide) {   // run-time-m kernels: only the transposed table and the statistic counters (which stay 0)
             if (resolution > (1u << 20)) { r = BAZ_MUSIC_E_UNSUPPORTED; break; }
@@ -2172,7 +2179,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
             if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_SUB_EVD")) c->sub_evd = atoi(v);                   // lab / tests
             if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_WIDE_LITERAL")) c->wide_literal_only = atoi(v);   // lab / tests
             if (dev_malloc((void**)&c->dRefined, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
-            if (hipMemset(c->dRefined, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
+            if (hipMemsetAsync(c->dRefined, 0, 2 * sizeof(unsigned long long), c->stream) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
             c->wide_cov_mfma = 1;
             c->wide_cov_blocks = 2u * (uint32_t)std::max(1, prop.multiProcessorCount);
             if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_WIDE_COV_MFMA")) c->wide_cov_mfma = (c->wide_cov_mfma && atoi(v)) ? 1 : 0;   // lab / tests
@@ -2224,7 +2231,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
         if (m <= 8) {
             c->cs_tiles = round_up((resolution + 15) / 16, 8);
             if (dev_malloc((void**)&c->dMargin, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
-            if (hipMemset(c->dMargin, 0, sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
+            if (hipMemsetAsync(c->dMargin, 0, sizeof(unsigned long long), c->stream) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         }
         if (const char* v = getenv("BAZ_MUSIC_EXACT")) c->i8_on = atoi(v) ? 0 : 1;                // A/B: 1 = the fp64 scan everywhere
         if (const char* v = BAZ_LAB_ENV("BAZ_MUSIC_I8_ABL")) c->i8_abl = atoi(v);                  // lab
@@ -2240,7 +2247,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
 #endif
         if (wants_i8_stat) {
             if (dev_malloc((void**)&c->dI8Stat, 8 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
-            if (hipMemset(c->dI8Stat, 0, 8 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
+            if (hipMemsetAsync(c->dI8Stat, 0, 8 * sizeof(unsigned long long), c->stream) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         }
         {
             // ONE workgroup per CU (4 persistent waves, 8 KiB in flight each = 8 MB chip-wide): measured against 2 / 3 / 4 /
@@ -2252,7 +2259,7 @@ int baz_music_create(baz_music_ctx** out, uint32_t m, uint32_t n, uint32_t nsamp
                 if (atoi(v) > 0) c->cov4_resident_blocks = (uint32_t)atoi(v) * (uint32_t)std::max(1, prop.multiProcessorCount);
         }
         if (dev_malloc((void**)&c->dRefined, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_NOMEM; break; }
-        if (hipMemset(c->dRefined, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
+        if (hipMemsetAsync(c->dRefined, 0, 2 * sizeof(unsigned long long), c->stream) != hipSuccess) { r = BAZ_MUSIC_E_HIP; break; }
         r = create_tables(c, table_ri);
     } while (0);
     if (r != BAZ_MUSIC_OK) {
@@ -2796,7 +2803,7 @@ int64_t baz_music_debug_coarse_fired(baz_music_ctx* c)
     DeviceGuard guard(c->device);
     unsigned long long v = 0;
     if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&v, c->dMargin, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemset(c->dMargin, 0, sizeof(v)) != hipSuccess) return -1;
+        hipMemsetAsync(c->dMargin, 0, sizeof(v), c->stream) != hipSuccess) return -1;
     return (int64_t)v;
 }
 
@@ -2899,7 +2906,7 @@ int baz_music_debug_i8_stats(baz_music_ctx* c, uint64_t* refined_tiles, uint64_t
     unsigned long long v[2] = {0, 0};
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(v, c->dI8Stat, sizeof(v), hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemset(c->dI8Stat, 0, sizeof(v)));
+    HIP_TRY(c, hipMemsetAsync(c->dI8Stat, 0, sizeof(v), c->stream));
     if (refined_tiles) *refined_tiles = v[0];
     if (tiles) *tiles = v[1];
     return BAZ_MUSIC_OK;
@@ -2915,7 +2922,7 @@ extern "C" __attribute__((visibility("default"))) int baz_music_debug_i8_times(b
     unsigned long long v[4] = {0, 0, 0, 0};
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(v, c->dI8Stat + 4, sizeof(v), hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemset(c->dI8Stat + 4, 0, sizeof(v)));
+    HIP_TRY(c, hipMemsetAsync(c->dI8Stat + 4, 0, sizeof(v), c->stream));
     for (int i = 0; i < 4; ++i) out[i] = v[i];
     return BAZ_MUSIC_OK;
 }

@@ -25,7 +25,8 @@ for case in range(ncases):
         ang = torch.zeros(batch, n, dtype=torch.float32, device=dev); lvl = torch.zeros_like(ang)
         spec = torch.zeros(batch, res, dtype=torch.float32, device=dev)
         ctx.process_device(x.data_ptr(), batch, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr()); ctx.sync()
-        if rng.random() < 0.5:       # page-locked caller memory: the chunked form that enqueues the whole call without host waits (four slots, round 6)
+        pinned = bool(rng.random() < 0.5)
+        if pinned:                   # page-locked caller memory: the chunked form that enqueues the whole call without host waits (four slots, round 6)
             pin = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().numpy()
             o = (pin(np.zeros((batch, n), np.float32)), pin(np.zeros((batch, n), np.float32)) if want_lvl else None,
                  pin(np.zeros((batch, res), np.float32)) if want_spec else None)
@@ -41,6 +42,6 @@ for case in range(ncases):
     if not ok:
         fails += 1
         da = ang.cpu().numpy()
-        print("FAIL case %d m=%d n=%d K=%d res=%d batch=%d snr=%g peak=%s lvl=%s spec=%s: ang mismatches %d" % (case, m, n, K, res, batch, snr, peak, want_lvl, want_spec, int((ha != da).sum())), flush=True)
+        print("FAIL case %d m=%d n=%d K=%d res=%d batch=%d snr=%g peak=%s lvl=%s spec=%s pinned=%s: ang mismatches %d, first rows %s" % (case, m, n, K, res, batch, snr, peak, want_lvl, want_spec, pinned, int((ha != da).sum()), np.flatnonzero(np.any(ha != da, axis=1))[:12].tolist()), flush=True)
 print("fuzz_host: %d cases, %d failures" % (ncases, fails))
 sys.exit(1 if fails else 0)
