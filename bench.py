@@ -595,25 +595,48 @@ def run_leg_subprocess(name, timeout_s=None):
 
 
 def supervise():
-    """Plain `python bench.py` with one GPU: the measurement runs in a CHILD of this process (same command line), whose stdout is passed on line by
-    line as it appears.  If the child is killed by a signal before it has printed its line -- the HIP runtime abort()s a process whose GPU work hits a
-    memory fault, which is what took the driver's round-5 run -- it is started ONCE more, and the line of the second attempt says so
-    (config.headline_attempt = 2, config.headline_previous_failure).  Nothing is retried after an orderly exit (wrong arguments, no GPU, a failed
-    verification) or once a line is out.  BAZ_BENCH_SUPERVISE=0 runs everything in this process."""
+    """Plain `python bench.py` with one GPU: the measurement runs in a CHILD of this process (same command line); this process holds no GPU context and
+    cannot be taken down by a GPU fault.  It passes exactly ONE JSON line on to stdout -- the contract's "rank 0 prints ONE JSON line" --: the LAST one the
+    child printed.  The child prints its complete line (metric, roofline, cpu_baseline, verification) before the secondary legs start and the same line with
+    the legs' figures after them; should it die in between, the first is what stdout gets.  If the child is killed by a signal before it has printed any
+    line -- the HIP runtime abort()s a process whose GPU work hits a memory fault, which is what took the driver's round-5 run -- it is
+    started ONCE more, and the line of the second attempt says so (config.headline_attempt = 2, config.headline_previous_failure).  Nothing is retried after
+    an orderly exit (wrong arguments, no GPU, a failed verification) or once a line exists.  BAZ_BENCH_SUPERVISE=0 runs everything in this process."""
+    import signal
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    state = {"latest": None, "out": False}
+
+    def put_line():
+        if state["latest"] is not None and not state["out"]:
+            state["out"] = True
+            sys.stdout.write(state["latest"])
+            sys.stdout.flush()
+
+    def on_term(signum, frame):          # (the driver's time limit: hand over what there is)
+        put_line()
+        os._exit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            signal.signal(sig, on_term)
+        except Exception:
+            pass
     previous = ""
     for attempt in (1, 2):
         env = dict(os.environ, BAZ_BENCH_CHILD="1", BAZ_BENCH_ATTEMPT=str(attempt), BAZ_BENCH_PREVIOUS_FAILURE=previous)
         p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1, env=env)        # stderr: inherited
-        printed = False
         for ln in p.stdout:
-            sys.stdout.write(ln)
-            sys.stdout.flush()
-            printed = printed or ln.startswith("{")
+            if ln.startswith("{"):
+                state["latest"] = ln if ln.endswith("\n") else ln + "\n"
+            else:
+                sys.stdout.write(ln)
+                sys.stdout.flush()
         rc = p.wait()
-        if rc >= 0 or printed or attempt == 2:
-            return rc if rc >= 0 else 128 - rc           # (a signal death after the line was out: the shell's convention, e.g. 134 for SIGABRT)
+        if rc >= 0 or state["latest"] is not None or attempt == 2:
+            if rc < 0 and state["latest"] is not None:
+                note("the measuring process was killed by signal %d after its complete line and before the legs' figures: that line is the one printed" % (-rc))
+            put_line()
+            return rc if rc >= 0 else 128 - rc           # (a signal death: the shell's convention, e.g. 134 for SIGABRT)
         previous = "attempt 1 was killed by signal %d before it printed its line" % (-rc)
         note("the measuring process was killed by signal %d before it printed anything; starting it once more" % (-rc))
     return 1
@@ -972,9 +995,17 @@ def main():
             if unknown:
                 raise SystemExit("unknown leg(s) %s (known: %s)" % (unknown, ", ".join(LEG_ORDER)))
         cfgd["extras_pending"] = len(legs)
-        # THE LINE, complete (metric, roofline, cpu_baseline, verified_*), before any secondary leg runs: whatever happens below
-        # cannot take it back.  With legs to run, the same line follows once more as the LAST line, enriched with their figures.
-        print(json.dumps(line), flush=True)
+        # THE LINE, complete (metric, roofline, cpu_baseline, verified_*), before any secondary leg runs: whatever happens below cannot take it
+        # back.  Without legs it is the one line of the contract.  With legs to run, the same line follows once more, enriched with their figures,
+        # and exactly ONE of the two reaches the caller's stdout: supervised (plain `python bench.py`, see supervise()) both go to the parent, which
+        # prints the last one it has got; unsupervised the early copy goes to stderr only.
+        if not legs or os.environ.get("BAZ_BENCH_CHILD") == "1":
+            print(json.dumps(line), flush=True)
+        if legs:
+            print("bench.py: [%.1f s] complete line before the legs: %s" % (time.perf_counter() - T_START, json.dumps(line)), file=sys.stderr, flush=True)
+            if os.environ.get("BAZ_BENCH_INJECT_FAULT", "") == "abort:after_first_line":      # test hook
+                note("INJECTED FAULT: the measuring process abort()s after its complete line, before the legs")
+                os.abort()
         if legs:
             # this process keeps nothing on the device while the legs run (they are sized for a whole GPU)
             del x, spec, ang, lvl

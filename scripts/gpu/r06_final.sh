@@ -46,7 +46,7 @@ cp profiles/${P}_* $O/profiles/ 2>/dev/null            # what is there so far tr
 echo "t=$(( $(date +%s) - T0 )) s before the bench line"
 # the graded command, verbatim (one evidence take per round, of exactly what the driver runs)
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_stdout.txt 2> $O/bench_err.txt; echo "driver command rc=$?" | tee $O/bench_rc.txt
-grep '^{' $O/bench_stdout.txt | tail -1 > $O/bench_line.json; grep '^{' $O/bench_stdout.txt | head -1 > $O/bench_line_first.json
+grep '^{' $O/bench_stdout.txt | tail -1 > $O/bench_line.json; grep -o 'complete line before the legs: {.*' $O/bench_err.txt | sed 's/^complete line before the legs: //' | head -1 > $O/bench_line_first.json   # (stdout holds ONE line; the early copy is on stderr)
 [ -s $O/bench_line.json ] && cp $O/bench_line.json profiles/${P}_bench_line.json && cp profiles/${P}_bench_line.json $O/profiles/
 head -8 $O/bench_kernel_stats.csv | cut -c1-200; tail -8 $O/pmc_traffic_out.txt; python -c "
 import json; d=json.load(open('$O/bench_line.json')); c=d['config']; print(d['value'], d['ms_per_step'], d['rounds']); print(d['roofline']); print(d.get('cpu_baseline')); print('extras run', c.get('extras_run'), 'failed', c.get('extras_failed'), c.get('extras_failed_legs'), 'verified', c.get('verified_ok'), c.get('extras_all_verified_ok'))

@@ -2,11 +2,12 @@
 
     python bench.py --gpus 1 --steps 20 --warmup 5
 
-must exit 0 and leave, as the LAST line of stdout, one JSON object with BASELINE.json's metric, a `roofline` whose fraction lies in
+must exit 0 and leave on stdout exactly ONE JSON object (the contract) with BASELINE.json's metric, a `roofline` whose fraction lies in
 (0, 1), a `cpu_baseline` with a positive value, the in-run verification green and no failed secondary leg.  Round 5's driver run died
-with a GPU memory fault inside a secondary leg before anything had been printed; since round 6 the complete line is printed BEFORE the
-secondary legs start (each of which runs in its own process), and once more -- enriched -- after them.  The second half of this file
-injects faults into legs and checks that the line survives them."""
+with a GPU memory fault inside a secondary leg before anything had been printed; since round 6 the measuring process hands its complete
+line to a supervising parent (and to stderr) BEFORE the secondary legs start -- each of which runs in its own process -- and the same
+line, enriched, after them; the parent prints the last one it has got.  The second half of this file injects faults into legs, into the
+measuring process before its first line and after it, and checks that a complete line comes out every time."""
 import json
 import os
 import subprocess
@@ -26,6 +27,14 @@ def _run(argv, env=None, timeout=900):
     r = subprocess.run([sys.executable, "bench.py"] + argv, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=e)
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     return r, lines
+
+
+def _early_line(r):
+    """The complete line the measuring process put out before the legs (stderr copy)."""
+    tag = "complete line before the legs: "
+    got = [l.split(tag, 1)[1] for l in r.stderr.splitlines() if tag in l]
+    assert len(got) == 1, "expected one early line on stderr, found %d" % len(got)
+    return json.loads(got[0])
 
 
 def _check_complete(line, steps=20, warmup=5):
@@ -51,10 +60,9 @@ def _check_complete(line, steps=20, warmup=5):
 def test_the_drivers_exact_command(gpu_device):
     r, lines = _run(DRIVER_ARGV)
     assert r.returncode == 0, "rc %d\n%s" % (r.returncode, r.stderr[-3000:])
-    assert len(lines) == 2, "expected the complete line before the legs and the enriched one after them, got %d lines" % len(lines)
-    first, last = lines
+    assert len(lines) == 1 and len(r.stdout.strip().splitlines()) == 1, "stdout must hold ONE JSON line, got %d" % len(lines)
+    first, last = _early_line(r), lines[0]
     assert first["config"]["headline_attempt"] == 1 and first["config"]["headline_previous_failure"] is None
-    assert r.stdout.rstrip().splitlines()[-1].startswith("{")                    # the LAST line of stdout is the line
     _check_complete(first)
     _check_complete(last)
     assert first["value"] == last["value"] and first["roofline"] == last["roofline"]
@@ -87,10 +95,10 @@ def test_a_fault_in_a_leg_cannot_take_the_line(gpu_device, kind):
         env["BAZ_BENCH_LEG_TIMEOUT_S"] = "20"
     r, lines = _run(DRIVER_ARGV + ["--legs", legs], env=env)
     assert r.returncode == 0, "rc %d\n%s" % (r.returncode, r.stderr[-3000:])
-    assert len(lines) == 2
+    assert len(lines) == 1
+    _check_complete(_early_line(r))
     _check_complete(lines[0])
-    _check_complete(lines[1])
-    c = lines[1]["config"]
+    c = lines[0]["config"]
     assert c["extras_run"] == 3 and c["extras_failed"] == 1 and c["extras_failed_legs"] == "wide_m64_n2"
     assert "error" in c["extra"]["wide_m64_n2"]
     if kind == "hang":
@@ -109,12 +117,16 @@ def test_a_fault_in_the_measuring_process_itself_costs_one_restart(gpu_device):
     process): it is started once more, rc 0, the line is complete and says that it is the second attempt's."""
     r, lines = _run(DRIVER_ARGV + ["--legs", "cfg2_snr60"], env={"BAZ_BENCH_INJECT_FAULT": "abort:headline@1"})
     assert r.returncode == 0, "rc %d\n%s" % (r.returncode, r.stderr[-3000:])
-    assert len(lines) == 2
+    assert len(lines) == 1
     _check_complete(lines[0])
-    _check_complete(lines[1])
-    for ln in lines:
-        assert ln["config"]["headline_attempt"] == 2 and "signal 6" in ln["config"]["headline_previous_failure"]
+    assert lines[0]["config"]["headline_attempt"] == 2 and "signal 6" in lines[0]["config"]["headline_previous_failure"]
+    assert lines[0]["config"]["extras_run"] == 1 and lines[0]["config"]["extras_failed"] == 0
     assert "starting it once more" in r.stderr
+    # the measuring process dies AFTER its complete line and before the legs' figures: that line is the one line of stdout (and the exit code tells)
+    r, lines = _run(DRIVER_ARGV + ["--legs", "cfg2_snr60"], env={"BAZ_BENCH_INJECT_FAULT": "abort:after_first_line"})
+    assert r.returncode == 134 and len(lines) == 1, (r.returncode, len(lines))
+    _check_complete(lines[0])
+    assert lines[0]["config"]["extras_pending"] == 1 and "extra" not in lines[0]["config"] and lines[0] == _early_line(r)
     # ... and an undisturbed run says attempt 1 (asserted on the driver's command above through _check_complete's caller); a fault in BOTH attempts is an error
     r, lines = _run(DRIVER_ARGV + ["--no-extras", "--no-cpu-baseline"], env={"BAZ_BENCH_INJECT_FAULT": "abort:headline@1", "BAZ_BENCH_SUPERVISE": "0"})
     assert r.returncode != 0 and not lines
