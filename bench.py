@@ -25,10 +25,17 @@ roofline : dominant kernel = the scan (scan_mfma_kernel); achieved = its algorit
            bytes per launch from the rocprofv3 PMC passes kept under profiles/ -- used ONLY when that profile was
            taken on the kernel sources this run executes (sha256 over gr_baz_amd/csrc + include), else null and
            "traffic_stale": true.
-extras   : config.extra carries secondary, clearly labelled measurements (rank 0, N=1): cfg2 WITHOUT the spectrum port
-           (the GRC default wiring), the unfavourable cfg2 cases (an incoherent batch with and without the spectrum port,
-           60 dB SNR), cfg3 (8 ant, 4096 samp, 36000 bins: fp64-matrix bound; and without port 2), 32 antennas, and the cfg5 chain (16 ant: resampler ->
-           AGC -> MUSIC on one stream), each with its own ms, bound and fraction.
+output   : exactly ONE JSON line on stdout.  Plain `python bench.py` (one GPU) measures in a CHILD of itself (supervise()): the child hands its
+           complete line -- metric, roofline, cpu_baseline, verification -- to the GPU-free parent (and to stderr) BEFORE the secondary legs start and
+           the same line with the legs' figures after them; the parent prints the last one it has got, restarts the child once if a signal killed
+           it before any line existed (config.headline_attempt), and otherwise passes its exit code on.
+extras   : config.extra carries secondary, clearly labelled measurements (rank 0, N=1), EACH IN ITS OWN PROCESS (python bench.py --extra-leg NAME,
+           time limit 150 s): the cost of retunes beside the headline's steps, cfg2 WITHOUT the spectrum port (the GRC default wiring), the
+           unfavourable cfg2 cases (an incoherent batch with and without the spectrum port, 60 dB SNR), cfg3 (8 ant, 4096 samp, 36000 bins; and without
+           port 2), 32 and 64 antennas, the cfg5 chain (16 ant: resampler -> AGC -> MUSIC on one stream) and the host-fed flowgraph model, each with its
+           own ms, bound, fraction and oracle check.  A leg that faults, hangs or raises becomes config.extra.<leg>.error + config.extras_failed; the
+           exit code speaks for the headline's verification only.  (Round 5's driver run died with a GPU memory fault inside one of these, in-process
+           then, before anything had been printed: DESIGN.md 6.1.)
 cpu_baseline : rank 0, N=1 only: oracle/_ref (the reference's own baz_music_doa.cc compiled in place, kind
            "reference") when its prebuilt .so is present, else the plain-C restatement (oracle/music_ref.c, kind
            "port"); one work() per item like the GNU Radio scheduler drives the reference, on all host cores
