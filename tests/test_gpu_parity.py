@@ -949,3 +949,26 @@ def test_set_table_from_another_thread_is_never_torn(gpu_device):
             stop.set()
             th.join()
     assert seen  # usually {"A", "B"}
+
+
+# ------------------------------------------------------------------ round 6: the scan writes EVERY spectrum value
+@pytest.mark.parametrize("name", golden_names())
+def test_every_spectrum_value_is_written(name, gpu_device):
+    """The spectrum tensor is pre-filled with a sentinel; after one call no element may still hold it -- whatever the row classes, the bin ranges, the
+    padded last step, the refined tiles (found useful when a guard-zone run made a stale-looking spectrum suspicious: the values were all written, the
+    guard's own pre-fill was late)."""
+    import torch
+    g = load_golden(name)
+    B, res = g["items"].shape[0], g["res"]
+    SENT = 12345.678
+    with _capi().Context(g["m"], g["n"], g["nsamples"], res, g["table"]) as ctx:
+        x = torch.from_numpy(np.ascontiguousarray(g["items"]).view(np.float32)).to(gpu_device)
+        ang = torch.zeros(B, g["n"], dtype=torch.float32, device=gpu_device)
+        lvl = torch.zeros_like(ang)
+        for rows in (B, max(1, B - 3)):                       # the whole batch and a ragged one
+            spec = torch.full((B, res), SENT, dtype=torch.float32, device=gpu_device)
+            torch.cuda.synchronize()
+            ctx.process_device(x.data_ptr(), rows, ang.data_ptr(), lvl.data_ptr(), spec.data_ptr())
+            ctx.sync()
+            assert int((spec[:rows] == SENT).sum()) == 0, "%s: spectrum values left unwritten" % name
+            assert int((spec[rows:] != SENT).sum()) == 0, "%s: rows beyond the batch were written" % name
